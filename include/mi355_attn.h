@@ -1,0 +1,205 @@
+/*
+ * mi355_attn.h — C ABI of libmi355_attn.so: paged-KV attention for MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the hot path of foundation-model-stack/vllm-triton-backend:
+ * chunked/context prefill attention + paged-KV decode over vLLM block tables. Every entry point
+ * states the reference interface it replaces (paths relative to the reference repository,
+ * LIB/ = ibm-triton-lib/ibm_triton_lib/).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *   - every function returns 0 on success or a negative MI355_ERR_* code; the message of the last
+ *     failure on the calling thread is available from mi355_last_error();
+ *   - no allocation, no host/device synchronisation, no exceptions: kernels are enqueued on the
+ *     stream handed in (a hipStream_t), so calls can be captured into a hipGraph;
+ *   - all buffers are caller owned; scratch comes from a caller-provided workspace whose size is
+ *     given by mi355_attn_workspace_bytes();
+ *   - strides are in ELEMENTS of the tensor's dtype.
+ */
+#ifndef MI355_ATTN_H
+#define MI355_ATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ATTN_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#if defined(__GNUC__)
+#define MI355_API __attribute__((visibility("default")))
+#else
+#define MI355_API
+#endif
+
+/* error codes */
+#define MI355_OK 0
+#define MI355_ERR_BAD_ARG (-1)     /* NULL pointer, negative size, inconsistent shapes            */
+#define MI355_ERR_UNSUPPORTED (-2) /* valid request this build has no kernel for                  */
+#define MI355_ERR_HIP (-3)         /* the HIP runtime refused the launch                          */
+#define MI355_ERR_WORKSPACE (-4)   /* workspace missing or smaller than mi355_attn_workspace_bytes */
+
+/* element types */
+typedef enum mi355_dtype {
+  MI355_F32 = 0,
+  MI355_F16 = 1,
+  MI355_BF16 = 2,
+  MI355_FP8_E4M3 = 3, /* OCP e4m3fn (gfx950 native; NOT MI300's fnuz) */
+  MI355_FP8_E5M2 = 4
+} mi355_dtype;
+
+/* which kernel family mi355_unified_attention launches (mirrors `force_selection`,
+ * LIB/kernels/triton_unified_attention.py:859,:884) */
+typedef enum mi355_kernel_select {
+  MI355_SELECT_AUTO = 0,
+  MI355_SELECT_2D = 2,     /* one pass over the whole KV range per Q block ("2D" kernel, :275-523) */
+  MI355_SELECT_3D = 3,     /* split-KV partials + reduce_segments ("3D" path, :526-836)            */
+  MI355_SELECT_GENERIC = 9 /* the shape-agnostic correctness kernel (any dtype/head size/layout)   */
+} mi355_kernel_select;
+
+/* opaque hipStream_t */
+typedef void* mi355_stream_t;
+
+/*
+ * Parameters of one unified attention call.
+ *
+ * Replaces the argument list of `unified_attention(q, k, v, out, cu_seqlens_q, max_seqlen_q,
+ * seqused_k, max_seqlen_k, avg_seqlen_q, avg_seqlen_k, softmax_scale, causal, window_size,
+ * block_table, softcap, q_descale, k_descale, v_descale, alibi_slopes, force_selection)`
+ * (LIB/kernels/triton_unified_attention.py:839-860) plus the strides its launcher derives
+ * (:905-923).
+ *
+ * KV-cache addressing covers both cache layouts of the reference with one formula:
+ *   K element (page p, slot o, kv head h, dim d) lives at
+ *       k_cache + p*k_stride_page + o*k_stride_slot + h*k_stride_head
+ *               + (d / k_x)*k_stride_dx + (d % k_x)*k_stride_d
+ *   V element at  v_cache + p*v_stride_page + o*v_stride_slot + h*v_stride_head + d*v_stride_d.
+ *   flash layout  [num_pages, page, Hk, D] (triton_unified_attention.py:279-280): k_x = D,
+ *       k_stride_dx = 0, k_stride_d = v_stride_d = 1;
+ *   legacy v0 layout K [num_pages, Hk, D/x, page, x], V [num_pages, Hk, D, page]
+ *       (LIB/kernels/legacy/triton_paged_decode_attention_2d.py:103-104): k_x = x.
+ *
+ * Optional "new token" source (context_attention_fwd, LIB/kernels/legacy/triton_prefix_prefill.py
+ * :589-606): when k_new/v_new are non-NULL, sequences with query_len > 1 read key positions
+ * >= context_len from the linear tensors k_new/v_new [num_tokens, Hk, D] (row of position j is
+ * cu_seqlens_q[i] + j - context_len) instead of from the cache.
+ */
+typedef struct mi355_attn_params {
+  /* tensors */
+  const void* q;               /* [num_tokens, Hq, D], last dim contiguous                      */
+  void* out;                   /* [num_tokens, Hq, D], last dim contiguous, written in place    */
+  const void* k_cache;         /* see layout note                                                */
+  const void* v_cache;
+  const int32_t* block_table;  /* [num_seqs, >= ceil(max_seqlen_k / page_size)] physical pages   */
+  const int32_t* cu_seqlens_q; /* [num_seqs + 1] exclusive prefix sum of query lengths           */
+  const int32_t* seqused_k;    /* [num_seqs] total key length (context + query) per sequence     */
+  const float* alibi_slopes;   /* [Hq] or NULL                                                   */
+  const float* k_scale;        /* device fp32 scalar (element 0 is read) or NULL = 1.0; fp8 KV   */
+  const float* v_scale;
+  const void* k_new;           /* optional linear new-token K/V, see above; NULL for the unified */
+  const void* v_new;           /*   path                                                          */
+
+  /* element types */
+  int32_t q_dtype;             /* mi355_dtype of q, out, k_new, v_new                            */
+  int32_t kv_dtype;            /* mi355_dtype of the caches (== q_dtype, or an fp8 type)         */
+
+  /* sizes */
+  int32_t num_tokens;          /* T  = q.shape[0]                                                */
+  int32_t num_seqs;            /* S  = len(seqused_k)                                            */
+  int32_t num_q_heads;         /* Hq                                                             */
+  int32_t num_kv_heads;        /* Hk, Hq % Hk == 0                                               */
+  int32_t head_size;           /* D                                                              */
+  int32_t page_size;           /* tokens per KV page ("block_size" in vLLM)                      */
+  int32_t max_seqlen_q;        /* host-known upper bounds; used for dispatch and grid sizing     */
+  int32_t max_seqlen_k;
+
+  /* strides, in elements */
+  int64_t q_stride_token, q_stride_head;
+  int64_t out_stride_token, out_stride_head;
+  int64_t k_stride_page, k_stride_slot, k_stride_head, k_stride_dx, k_stride_d;
+  int32_t k_x;
+  int32_t reserved0;
+  int64_t v_stride_page, v_stride_slot, v_stride_head, v_stride_d;
+  int64_t block_table_stride;
+  int64_t new_stride_token, new_stride_head; /* strides of k_new / v_new                         */
+
+  /* scalars */
+  float scale;                 /* softmax scale                                                  */
+  float softcap;               /* > 0 enables cap * tanh(s / cap) (:25-29,:914)                   */
+  int32_t sliding_window;      /* 0 = off; else keep keys with query_pos - key_pos < window      */
+                               /*   (= 1 + window_size[0], :915)                                  */
+  int32_t skip_decodes;        /* 1: leave rows of sequences with query_len == 1 untouched       */
+                               /*   (triton_prefix_prefill.py:83-84)                              */
+  int32_t only_decodes;        /* 1: process only sequences with query_len == 1                  */
+                               /*   (filter_by_query_len, triton_paged_decode_attention_2d.py:143-148) */
+  int32_t kernel_select;       /* mi355_kernel_select                                            */
+  int32_t num_segments;        /* split-KV segment count for MI355_SELECT_3D; 0 = library picks  */
+  int32_t reserved1;
+} mi355_attn_params;
+
+/*
+ * Parameters of the paged-cache write.
+ * Replaces `torch.ops._C_cache_ops.reshape_and_cache_flash(key, value, key_cache, value_cache,
+ * slot_mapping, kv_cache_dtype, k_scale, v_scale)` as called at LIB/backend/triton_attn.py:396-405
+ * (CPU restatement in the reference: scripts/vllm_utils.py:377-401).
+ * For token t: slot = slot_mapping[t]; slot < 0 is skipped (triton_attn.py:149-151); otherwise
+ * cache[slot / page_size, slot % page_size, :, :] = key[t] (value likewise); with an fp8 cache the
+ * stored value is saturating fp8(x / scale).
+ */
+typedef struct mi355_cache_params {
+  const void* key;             /* [num_tokens, Hk, D]                                            */
+  const void* value;
+  void* k_cache;               /* [num_pages, page_size, Hk, D] (flash layout)                   */
+  void* v_cache;
+  const int64_t* slot_mapping; /* [num_tokens] int64 (vLLM) ...                                   */
+  const int32_t* slot_mapping_i32; /* ... or int32 (reference harness, scripts/benchmark.py:1225); exactly one non-NULL */
+  const float* k_scale;        /* device fp32 scalar or NULL = 1.0                               */
+  const float* v_scale;
+  int32_t src_dtype;           /* mi355_dtype of key/value                                       */
+  int32_t cache_dtype;         /* mi355_dtype of the caches                                      */
+  int32_t num_tokens, num_kv_heads, head_size, page_size;
+  int64_t key_stride_token, key_stride_head;
+  int64_t value_stride_token, value_stride_head;
+  int64_t k_stride_page, k_stride_slot, k_stride_head;
+  int64_t v_stride_page, v_stride_slot, v_stride_head;
+} mi355_cache_params;
+
+/* library version (MI355_ATTN_VERSION of the build) */
+MI355_API int mi355_attn_version(void);
+
+/* message of the last error on this thread ("" if none); never NULL */
+MI355_API const char* mi355_last_error(void);
+
+/* name of the kernel family the last successful mi355_unified_attention call on this thread
+ * dispatched to ("decode_splitkv", "prefill_mfma", "generic", ...); for tests and profiling */
+MI355_API const char* mi355_last_kernel(void);
+
+/*
+ * Bytes of scratch mi355_unified_attention needs for these parameters (host-side arithmetic only;
+ * depends on sizes and upper bounds, never on device data, so it is capture-stable).
+ * Replaces the three per-call torch.empty scratch tensors at triton_unified_attention.py:950-971.
+ */
+MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
+
+/*
+ * Unified causal paged attention (prefill, chunked prefill, decode, mixed batches).
+ * Replaces `unified_attention` and the three kernels it launches
+ * (LIB/kernels/triton_unified_attention.py:839-1030: kernel_unified_attention_2d :275-523,
+ *  kernel_unified_attention_3d :526-754, reduce_segments :757-836); with k_new/v_new and the legacy
+ * strides it also serves `context_attention_fwd` (legacy/triton_prefix_prefill.py:588-765),
+ * `paged_attention_triton_2d/3d` (legacy/triton_paged_decode_attention_2d.py:283-398,
+ * legacy/triton_paged_decode_attention_3d.py:348-499) and `chunked_prefill_paged_decode`
+ * (legacy/triton_chunked_prefill_paged_decode.py:28-117).
+ */
+MI355_API int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
+                            mi355_stream_t stream);
+
+/* Paged-cache write, see mi355_cache_params. */
+MI355_API int mi355_reshape_and_cache_flash(const mi355_cache_params* p, mi355_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_ATTN_H */

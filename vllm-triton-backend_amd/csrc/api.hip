@@ -1,0 +1,125 @@
+// C ABI of libmi355_attn.so (include/mi355_attn.h): argument validation and kernel dispatch.
+// Host-side only; mirrors the dispatch of unified_attention
+// (LIB/kernels/triton_unified_attention.py:861-884): batches containing a prefill take the
+// single-pass Q-block kernel, decode-only batches take split-KV + reduce.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace mi355 {
+
+static thread_local char g_error[512] = "";
+static thread_local const char* g_kernel = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+void set_kernel_name(const char* name) { g_kernel = name; }
+
+static bool is_q_dtype(int d) { return d == MI355_F32 || d == MI355_F16 || d == MI355_BF16; }
+static bool is_fp8(int d) { return d == MI355_FP8_E4M3 || d == MI355_FP8_E5M2; }
+
+static int validate(const mi355_attn_params* p) {
+  if (!p) { set_error("params is NULL"); return MI355_ERR_BAD_ARG; }
+  if (p->num_tokens < 0 || p->num_seqs < 0) { set_error("negative num_tokens/num_seqs"); return MI355_ERR_BAD_ARG; }
+  if (p->num_tokens == 0 || p->num_seqs == 0) return MI355_OK;
+  if (!p->q || !p->out || !p->k_cache || !p->v_cache || !p->block_table || !p->cu_seqlens_q || !p->seqused_k) {
+    set_error("q/out/k_cache/v_cache/block_table/cu_seqlens_q/seqused_k must be non-NULL");
+    return MI355_ERR_BAD_ARG;
+  }
+  if ((p->k_new == nullptr) != (p->v_new == nullptr)) { set_error("k_new and v_new must be given together"); return MI355_ERR_BAD_ARG; }
+  if (!is_q_dtype(p->q_dtype)) { set_error("q dtype %d is not one of f32/f16/bf16", p->q_dtype); return MI355_ERR_UNSUPPORTED; }
+  if (p->kv_dtype != p->q_dtype && !is_fp8(p->kv_dtype)) {
+    set_error("kv dtype %d must equal the q dtype %d or be an fp8 type", p->kv_dtype, p->q_dtype);
+    return MI355_ERR_UNSUPPORTED;
+  }
+  if (p->num_q_heads <= 0 || p->num_kv_heads <= 0 || p->num_q_heads % p->num_kv_heads != 0) {
+    set_error("num_q_heads %d must be a positive multiple of num_kv_heads %d", p->num_q_heads, p->num_kv_heads);
+    return MI355_ERR_BAD_ARG;
+  }
+  if (p->head_size <= 0 || p->page_size <= 0 || p->k_x <= 0 || p->head_size % p->k_x != 0) {
+    set_error("bad head_size %d / page_size %d / k_x %d", p->head_size, p->page_size, p->k_x);
+    return MI355_ERR_BAD_ARG;
+  }
+  if (p->sliding_window < 0) { set_error("sliding_window must be >= 0"); return MI355_ERR_BAD_ARG; }
+  if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
+  return MI355_OK;
+}
+
+// AUTO policy. The reference picks 3D iff max_seqlen_q == 1 (:884). We do the same for the
+// split-KV decode kernel, send everything else the MFMA prefill kernel covers there, and the
+// remainder to the generic kernel.
+enum class Path { Generic, Decode, Prefill };
+
+static Path choose(const mi355_attn_params& p) {
+  const int sel = p.kernel_select;
+  if (sel == MI355_SELECT_GENERIC) return Path::Generic;
+  const bool dec_ok = decode_supported(p);
+  const bool pre_ok = prefill_supported(p);
+  if (sel == MI355_SELECT_3D) return dec_ok ? Path::Decode : Path::Generic;
+  if (sel == MI355_SELECT_2D) return pre_ok ? Path::Prefill : Path::Generic;
+  if (p.max_seqlen_q <= 1 && dec_ok) return Path::Decode;
+  if (pre_ok) return Path::Prefill;
+  if (dec_ok) return Path::Decode;
+  return Path::Generic;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+int mi355_attn_version(void) { return MI355_ATTN_VERSION; }
+
+const char* mi355_last_error(void) { return g_error; }
+
+const char* mi355_last_kernel(void) { return g_kernel; }
+
+size_t mi355_attn_workspace_bytes(const mi355_attn_params* p) {
+  if (!p || p->num_tokens <= 0 || p->num_seqs <= 0) return 0;
+  // sized for the split-KV path whenever that path could be taken, so that the answer does not
+  // depend on the dispatch decision
+  return decode_workspace_bytes(*p);
+}
+
+int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
+                            mi355_stream_t stream) {
+  int rc = validate(p);
+  if (rc != MI355_OK) return rc;
+  if (p->num_tokens == 0 || p->num_seqs == 0) return MI355_OK;
+  hipStream_t s = (hipStream_t)stream;
+  switch (choose(*p)) {
+    case Path::Decode:
+      rc = launch_decode(*p, workspace, workspace_bytes, s);
+      break;
+    case Path::Prefill:
+      rc = launch_prefill(*p, s);
+      break;
+    default:
+      rc = launch_generic(*p, s);
+      if (rc == MI355_OK) set_kernel_name("generic");
+      break;
+  }
+  return rc;
+}
+
+int mi355_reshape_and_cache_flash(const mi355_cache_params* p, mi355_stream_t stream) {
+  if (!p) { set_error("params is NULL"); return MI355_ERR_BAD_ARG; }
+  if (p->num_tokens < 0) { set_error("negative num_tokens"); return MI355_ERR_BAD_ARG; }
+  if (p->num_tokens == 0) return MI355_OK;
+  if (!p->key || !p->value || !p->k_cache || !p->v_cache) { set_error("key/value/k_cache/v_cache must be non-NULL"); return MI355_ERR_BAD_ARG; }
+  if ((p->slot_mapping == nullptr) == (p->slot_mapping_i32 == nullptr)) {
+    set_error("exactly one of slot_mapping / slot_mapping_i32 must be non-NULL");
+    return MI355_ERR_BAD_ARG;
+  }
+  if (p->num_kv_heads <= 0 || p->head_size <= 0 || p->page_size <= 0) { set_error("bad num_kv_heads/head_size/page_size"); return MI355_ERR_BAD_ARG; }
+  return launch_cache_write(*p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// reshape_and_cache_flash: scatter new-token K/V rows into the paged cache.
+//
+// Replaces torch.ops._C_cache_ops.reshape_and_cache_flash as called at
+// LIB/backend/triton_attn.py:396-405 (semantics restated in the reference by
+// scripts/vllm_utils.py:377-401; negative slots are padding and skipped, triton_attn.py:149-151).
+// HBM-bound copy: one workgroup per token, 16-byte vector loads/stores across the Hk*D row when
+// source and cache have the same 2-byte type and the row is contiguous; element-wise otherwise
+// (fp32, fp8 quantising store).
+#include "common.h"
+
+namespace mi355 {
+
+struct CacheArgs {
+  mi355_cache_params p;
+};
+
+__device__ __forceinline__ int64_t slot_of(const mi355_cache_params& p, int t) {
+  return p.slot_mapping ? p.slot_mapping[t] : (int64_t)p.slot_mapping_i32[t];
+}
+
+// same 16-bit type, contiguous head rows: copy 8 elements (16 B) per lane
+__global__ __launch_bounds__(256) void cache_write_vec16_kernel(const CacheArgs a) {
+  const mi355_cache_params& p = a.p;
+  const int t = blockIdx.x;
+  const int64_t slot = slot_of(p, t);
+  if (slot < 0) return;
+  const int64_t page = slot / p.page_size;
+  const int64_t off = slot % p.page_size;
+  const int chunks_per_head = p.head_size / 8;
+  const int n = p.num_kv_heads * chunks_per_head;
+  const uint16_t* ks = (const uint16_t*)p.key + (int64_t)t * p.key_stride_token;
+  const uint16_t* vs = (const uint16_t*)p.value + (int64_t)t * p.value_stride_token;
+  uint16_t* kd = (uint16_t*)p.k_cache + page * p.k_stride_page + off * p.k_stride_slot;
+  uint16_t* vd = (uint16_t*)p.v_cache + page * p.v_stride_page + off * p.v_stride_slot;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int h = i / chunks_per_head, c = i % chunks_per_head;
+    const uint4 kx = *(const uint4*)(ks + (int64_t)h * p.key_stride_head + c * 8);
+    const uint4 vx = *(const uint4*)(vs + (int64_t)h * p.value_stride_head + c * 8);
+    *(uint4*)(kd + (int64_t)h * p.k_stride_head + c * 8) = kx;
+    *(uint4*)(vd + (int64_t)h * p.v_stride_head + c * 8) = vx;
+  }
+}
+
+template <typename ST, typename CT>
+__global__ __launch_bounds__(256) void cache_write_elem_kernel(const CacheArgs a) {
+  const mi355_cache_params& p = a.p;
+  const int t = blockIdx.x;
+  const int64_t slot = slot_of(p, t);
+  if (slot < 0) return;
+  const int64_t page = slot / p.page_size;
+  const int64_t off = slot % p.page_size;
+  constexpr bool kQuant = sizeof(typename CT::storage) == 1;
+  const float k_inv = (kQuant && p.k_scale) ? 1.0f / p.k_scale[0] : 1.0f;
+  const float v_inv = (kQuant && p.v_scale) ? 1.0f / p.v_scale[0] : 1.0f;
+  const int n = p.num_kv_heads * p.head_size;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int h = i / p.head_size, d = i % p.head_size;
+    float kx = elem<ST>::load(p.key, (int64_t)t * p.key_stride_token + (int64_t)h * p.key_stride_head + d);
+    float vx = elem<ST>::load(p.value, (int64_t)t * p.value_stride_token + (int64_t)h * p.value_stride_head + d);
+    if (kQuant) { kx *= k_inv; vx *= v_inv; }
+    elem<CT>::store(p.k_cache, page * p.k_stride_page + off * p.k_stride_slot + (int64_t)h * p.k_stride_head + d, kx);
+    elem<CT>::store(p.v_cache, page * p.v_stride_page + off * p.v_stride_slot + (int64_t)h * p.v_stride_head + d, vx);
+  }
+}
+
+template <typename ST>
+static int launch_src(const mi355_cache_params& p, hipStream_t stream) {
+  CacheArgs a{p};
+  dim3 grid(p.num_tokens), block(256);
+  if (p.cache_dtype == p.src_dtype) {
+    hipLaunchKernelGGL((cache_write_elem_kernel<ST, ST>), grid, block, 0, stream, a);
+  } else if (p.cache_dtype == MI355_FP8_E4M3) {
+    hipLaunchKernelGGL((cache_write_elem_kernel<ST, e4m3_t>), grid, block, 0, stream, a);
+  } else if (p.cache_dtype == MI355_FP8_E5M2) {
+    hipLaunchKernelGGL((cache_write_elem_kernel<ST, e5m2_t>), grid, block, 0, stream, a);
+  } else {
+    set_error("reshape_and_cache_flash: cache dtype %d with source dtype %d is not supported", p.cache_dtype, p.src_dtype);
+    return MI355_ERR_UNSUPPORTED;
+  }
+  return check_hip(hipGetLastError(), "cache_write launch");
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int launch_cache_write(const mi355_cache_params& p, hipStream_t stream) {
+  if (p.num_tokens == 0) return MI355_OK;
+  const bool two_byte = p.src_dtype == MI355_F16 || p.src_dtype == MI355_BF16;
+  const bool vec_ok = two_byte && p.cache_dtype == p.src_dtype && p.head_size % 8 == 0 &&
+                      aligned16(p.key) && aligned16(p.value) && aligned16(p.k_cache) && aligned16(p.v_cache) &&
+                      p.key_stride_token % 8 == 0 && p.key_stride_head % 8 == 0 &&
+                      p.value_stride_token % 8 == 0 && p.value_stride_head % 8 == 0 &&
+                      p.k_stride_page % 8 == 0 && p.k_stride_slot % 8 == 0 && p.k_stride_head % 8 == 0 &&
+                      p.v_stride_page % 8 == 0 && p.v_stride_slot % 8 == 0 && p.v_stride_head % 8 == 0;
+  if (vec_ok) {
+    CacheArgs a{p};
+    hipLaunchKernelGGL(cache_write_vec16_kernel, dim3(p.num_tokens), dim3(256), 0, stream, a);
+    return check_hip(hipGetLastError(), "cache_write_vec16 launch");
+  }
+  switch (p.src_dtype) {
+    case MI355_F32: return launch_src<f32_t>(p, stream);
+    case MI355_F16: return launch_src<f16_t>(p, stream);
+    case MI355_BF16: return launch_src<bf16_t>(p, stream);
+    default:
+      set_error("reshape_and_cache_flash: source dtype %d is not supported", p.src_dtype);
+      return MI355_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace mi355

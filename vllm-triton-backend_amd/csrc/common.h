@@ -1,0 +1,181 @@
+// Shared device/host helpers for libmi355_attn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi355_attn.h"
+
+namespace mi355 {
+
+// ---------------------------------------------------------------------------------------------
+// element-type tags. Storage is raw bits; arithmetic is always fp32.
+// ---------------------------------------------------------------------------------------------
+struct f32_t { using storage = float; };
+struct f16_t { using storage = uint16_t; };
+struct bf16_t { using storage = uint16_t; };
+struct e4m3_t { using storage = uint8_t; };  // OCP e4m3fn
+struct e5m2_t { using storage = uint8_t; };  // OCP e5m2
+
+__device__ __forceinline__ float bits_to_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f32_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// bf16 <-> f32 (round to nearest even, NaN preserved by the hardware convert)
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return bits_to_f32(uint32_t(h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 on gfx950
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+// OCP fp8 decode in software (exact; used by the generic kernel and to validate the hardware
+// converts used by the fast kernels).
+__device__ __forceinline__ float e4m3_to_f32(uint8_t v) {
+  const uint32_t sign = (uint32_t)(v & 0x80) << 24;
+  const uint32_t e = (v >> 3) & 0xF, m = v & 0x7;
+  float mag;
+  if (e == 0) {
+    mag = (float)m * 0.001953125f;  // m * 2^-9 (subnormal)
+  } else if (e == 15 && m == 7) {
+    mag = __builtin_nanf("");
+  } else {
+    mag = bits_to_f32(((e + 120u) << 23) | (m << 20));  // bias 7 -> 127
+  }
+  return bits_to_f32(f32_to_bits(mag) | sign);
+}
+__device__ __forceinline__ float e5m2_to_f32(uint8_t v) {
+  // e5m2 is the top byte of an IEEE half
+  return f16_to_f32((uint16_t)v << 8);
+}
+
+// saturating (finite) f32 -> fp8, round to nearest even; matches __HIP_SATFINITE semantics
+__device__ __forceinline__ uint8_t f32_to_e4m3_sat(float f) {
+  if (f != f) return 0x7F;
+  const uint32_t sign = (f32_to_bits(f) >> 24) & 0x80;
+  float a = __builtin_fabsf(f);
+  if (a >= 448.0f) return (uint8_t)(sign | 0x7E);
+  // scale so that the e4m3 subnormal/normal grid maps onto integers, round with rintf
+  // normal: value = (8+m) * 2^(e-10); find e from the float exponent
+  int ex;
+  (void)__builtin_frexpf(a, &ex);  // a = fr * 2^ex, fr in [0.5,1)  => a in [2^(ex-1), 2^ex)
+  int e = ex - 1 + 7;              // biased exponent candidate
+  if (e < 1) e = 1;                // subnormal range shares the e==1 step size 2^-9
+  const float step = __builtin_ldexpf(1.0f, e - 10);  // spacing of representable values
+  float q = __builtin_rintf(a / step);                // in [0,16]
+  uint32_t qi = (uint32_t)q;
+  uint32_t out;
+  if (e == 1 && qi < 8) {
+    out = qi;  // subnormal (exp field 0)
+  } else {
+    if (qi == 16) { qi = 8; e += 1; }
+    out = ((uint32_t)e << 3) | (qi - 8);
+  }
+  if (out > 0x7E) out = 0x7E;
+  return (uint8_t)(sign | out);
+}
+__device__ __forceinline__ uint8_t f32_to_e5m2_sat(float f) {
+  if (f != f) return 0x7F;
+  const uint32_t sign = (f32_to_bits(f) >> 24) & 0x80;
+  float a = __builtin_fabsf(f);
+  if (a >= 57344.0f) return (uint8_t)(sign | 0x7B);
+  int ex;
+  (void)__builtin_frexpf(a, &ex);
+  int e = ex - 1 + 15;
+  if (e < 1) e = 1;
+  const float step = __builtin_ldexpf(1.0f, e - 17);  // (4+m) * 2^(e-17)
+  float q = __builtin_rintf(a / step);                // in [0,8]
+  uint32_t qi = (uint32_t)q;
+  uint32_t out;
+  if (e == 1 && qi < 4) {
+    out = qi;
+  } else {
+    if (qi == 8) { qi = 4; e += 1; }
+    out = ((uint32_t)e << 2) | (qi - 4);
+  }
+  if (out > 0x7B) out = 0x7B;
+  return (uint8_t)(sign | out);
+}
+
+template <typename T> struct elem;
+template <> struct elem<f32_t> {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct elem<f16_t> {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return f16_to_f32(((const uint16_t*)p)[i]); }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = f32_to_f16(v); }
+  static __device__ __forceinline__ float round(float v) { return f16_to_f32(f32_to_f16(v)); }
+};
+template <> struct elem<bf16_t> {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return bf16_to_f32(((const uint16_t*)p)[i]); }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = f32_to_bf16(v); }
+  static __device__ __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+template <> struct elem<e4m3_t> {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return e4m3_to_f32(((const uint8_t*)p)[i]); }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint8_t*)p)[i] = f32_to_e4m3_sat(v); }
+};
+template <> struct elem<e5m2_t> {
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return e5m2_to_f32(((const uint8_t*)p)[i]); }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint8_t*)p)[i] = f32_to_e5m2_sat(v); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// sequence lookup: largest i with cu[i] <= token  (reference: find_seq_idx, token mode,
+// LIB/kernels/triton_unified_attention.py:32-52)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_seq_by_token(const int32_t* __restrict__ cu, int num_seqs, int token) {
+  int left = 0, right = num_seqs;
+  while (left < right) {
+    const int mid = (left + right) >> 1;
+    if (cu[mid] <= token) left = mid + 1; else right = mid;
+  }
+  return left - 1;
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// x * tanh(s / x) (reference: apply_softcap, triton_unified_attention.py:24-29, restated with tanhf
+// so that |s/x| > 88 does not overflow)
+__device__ __forceinline__ float softcap_fn(float s, float cap) { return cap * tanhf(s / cap); }
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+void set_kernel_name(const char* name);
+
+// launchers implemented per translation unit; each returns MI355_OK / MI355_ERR_*
+int launch_generic(const mi355_attn_params& p, hipStream_t stream);
+int launch_cache_write(const mi355_cache_params& p, hipStream_t stream);
+
+bool decode_supported(const mi355_attn_params& p);
+size_t decode_workspace_bytes(const mi355_attn_params& p);
+int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream);
+
+bool prefill_supported(const mi355_attn_params& p);
+int launch_prefill(const mi355_attn_params& p, hipStream_t stream);
+
+inline int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return MI355_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return MI355_ERR_HIP;
+}
+
+}  // namespace mi355
