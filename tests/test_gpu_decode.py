@@ -1,0 +1,147 @@
+"""-m gpu: split-KV decode kernel vs the CPU oracle on seeded inputs (sizes the oracle finishes in
+seconds), plus size-independent properties at BASELINE's C3 size."""
+
+import math
+
+import pytest
+import torch
+
+import golden_io
+from oracle import paged_attention_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(inp, dtype, *, force, window=0, softcap=0.0, alibi=None, expect=None, kv_dtype=None, kv_scale=None):
+    import gpu_util
+
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], sliding_window=window, softcap=softcap, alibi_slopes=alibi,
+                                       k_scale=kv_scale or 1.0, v_scale=kv_scale or 1.0, mode="3d")
+    d = gpu_util.to_dev(inp)
+    if alibi is not None:
+        d["alibi_slopes"] = alibi.to(gpu_util.DEV)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], window=window, softcap=softcap, force=force, kv_scale=kv_scale)
+    if expect is not None:
+        assert kernel.startswith(expect), kernel
+    atol, rtol = golden_io.tolerance(dtype, kv_dtype)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk", [(32, 8), (8, 8), (16, 1), (40, 8), (6, 2)])
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_decode_heads_and_head_sizes(dtype, hq, hk, d):
+    kv_lens = [1, 15, 16, 17, 31, 32, 33, 700, 1023, 257]
+    inp = orc.make_paged_inputs(5, [1] * len(kv_lens), kv_lens, hq, hk, d, 16, dtype)
+    _check(inp, dtype, force=None, expect="decode")
+
+
+@pytest.mark.parametrize("page", [16, 32, 64, 128])
+def test_decode_page_sizes(page):
+    kv_lens = [5, 129, 640, 77, 300]
+    inp = orc.make_paged_inputs(6, [1] * len(kv_lens), kv_lens, 16, 4, 128, page, torch.bfloat16)
+    _check(inp, torch.bfloat16, force=None, expect="decode")
+
+
+@pytest.mark.parametrize("segments", [1, 2, 3, 16, 64])
+def test_decode_split_counts_agree(segments):
+    """Any split count must give the same answer (merge is exact up to fp32 rounding)."""
+    import gpu_util
+    from mi355_attn.kernels import unified as ua_mod
+
+    kv_lens = [2000, 33, 1, 4096, 515]
+    inp = orc.make_paged_inputs(7, [1] * len(kv_lens), kv_lens, 32, 8, 128, 16, torch.bfloat16)
+    d = gpu_util.to_dev(inp)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="3d")
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = ua_mod.fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], 1, d["seqused_k"], max(kv_lens),
+                                      inp["scale"], (-1, -1), d["block_table"], 0.0, None, None, None, 3, num_segments=segments)
+    ua_mod.launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+def test_decode_features_window_softcap_alibi():
+    kv_lens = [300, 17, 256, 1, 129, 1000]
+    inp = orc.make_paged_inputs(8, [1] * len(kv_lens), kv_lens, 8, 2, 128, 16, torch.float16)
+    alibi = torch.tensor([2.0 ** (-(i + 1)) for i in range(8)], dtype=torch.float32)
+    _check(inp, torch.float16, force=None, window=8, expect="decode")
+    _check(inp, torch.float16, force=None, window=100, expect="decode")
+    _check(inp, torch.float16, force=None, softcap=30.0, expect="decode")
+    _check(inp, torch.float16, force=None, alibi=alibi, expect="decode")
+    _check(inp, torch.float16, force=None, window=64, softcap=20.0, alibi=alibi, expect="decode")
+
+
+def test_decode_kernel_on_multi_token_queries():
+    """force 3D on a batch with query_len > 1: every token is handled as its own causal decode."""
+    inp = orc.make_paged_inputs(9, [7, 1, 40, 3], [70, 45, 70, 300], 8, 2, 128, 16, torch.bfloat16)
+    _check(inp, torch.bfloat16, force=3, expect="decode")
+
+
+def test_decode_stale_nan_beyond_sequence_is_ignored():
+    """Slots past seq_len inside the last page (and unused pages) may hold anything, incl. NaN."""
+    import gpu_util
+
+    kv_lens = [33, 100, 5]
+    inp = orc.make_paged_inputs(10, [1] * 3, kv_lens, 8, 2, 128, 16, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="3d")
+    used = torch.zeros(inp["k_cache"].shape[:2], dtype=torch.bool)
+    for i, n in enumerate(kv_lens):
+        for j in range(n):
+            used[inp["block_table"][i, j // 16], j % 16] = True
+    inp["k_cache"][~used] = float("nan")
+    inp["v_cache"][~used] = float("nan")
+    d = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(d, inp["scale"])
+    assert kernel.startswith("decode")
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+def test_decode_c3_full_size_properties():
+    """BASELINE C3 (B=64, Hq=32, Hk=8, D=128, kv=8192, bf16, page 16) — too big for the oracle, so check
+    size-independent properties: (1) V == const  =>  out == const exactly-ish (softmax weights sum to 1);
+    (2) permuting the physical pages (with the block table) leaves the output bit-identical;
+    (3) a sample of (seq, head) rows equals the oracle."""
+    import gpu_util
+
+    dev = gpu_util.DEV
+    B, Hq, Hk, D, kv, page = 64, 32, 8, 128, 8192, 16
+    g = torch.Generator(device="cpu").manual_seed(0)
+    pps = kv // page
+    nb = B * pps + 7
+    k = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    v = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    q = (torch.rand(B, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    bt = torch.randperm(nb, generator=g)[: B * pps].to(torch.int32).view(B, pps)
+    t = dict(q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=torch.arange(B + 1, dtype=torch.int32),
+             seqused_k=torch.full((B,), kv, dtype=torch.int32))
+    scale = 1.0 / math.sqrt(D)
+    d = gpu_util.to_dev(t)
+    out, kernel = gpu_util.run_unified(d, scale)
+    assert kernel == "decode_splitkv"
+    # (3) sample rows vs oracle
+    for i in (0, 37, 63):
+        sub = dict(q=q[i:i + 1], k_cache=k, v_cache=v, block_table=bt[i:i + 1], cu_seqlens_q=torch.tensor([0, 1], dtype=torch.int32),
+                   seqused_k=torch.tensor([kv], dtype=torch.int32))
+        ref = orc.unified_attention_oracle(sub["q"], k, v, sub["cu_seqlens_q"], sub["seqused_k"], sub["block_table"], scale, mode="3d")
+        torch.testing.assert_close(out[i:i + 1].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    # (2) page permutation invariance, bit-exact
+    perm = torch.randperm(nb, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nb)
+    d2 = dict(d)
+    d2["k_cache"] = d["k_cache"][perm.to(dev)]
+    d2["v_cache"] = d["v_cache"][perm.to(dev)]
+    d2["block_table"] = inv.to(dev)[d["block_table"].long()].to(torch.int32)
+    out2, _ = gpu_util.run_unified(d2, scale)
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    # (1) constant V
+    d3 = dict(d)
+    d3["v_cache"] = torch.full_like(d["v_cache"], 0.5)
+    out3, _ = gpu_util.run_unified(d3, scale)
+    torch.testing.assert_close(out3.float(), torch.full_like(out3, 0.5).float(), atol=4e-3, rtol=0)
