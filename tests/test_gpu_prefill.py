@@ -1,0 +1,121 @@
+"""-m gpu: MFMA prefill kernel vs the CPU oracle on seeded inputs, plus properties at BASELINE C2 size."""
+
+import math
+
+import pytest
+import torch
+
+import golden_io
+from oracle import paged_attention_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(inp, dtype, *, force=None, window=0, softcap=0.0, alibi=None, expect="prefill"):
+    import gpu_util
+
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], sliding_window=window, softcap=softcap, alibi_slopes=alibi, mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    if alibi is not None:
+        d["alibi_slopes"] = alibi.to(gpu_util.DEV)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], window=window, softcap=softcap, force=force)
+    assert kernel.startswith(expect), kernel
+    atol, rtol = golden_io.tolerance(dtype)
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk", [(8, 2), (4, 4), (8, 1), (6, 2), (10, 2), (32, 1)])
+@pytest.mark.parametrize("d", [64, 128])
+def test_prefill_mixed_batches(dtype, hq, hk, d):
+    query_lens = [1, 5, 129, 1, 64, 33, 200]
+    kv_lens = [9, 5, 129, 300, 257, 100, 777]
+    inp = orc.make_paged_inputs(21, query_lens, kv_lens, hq, hk, d, 16, dtype)
+    _check(inp, dtype)
+
+
+@pytest.mark.parametrize("page", [16, 32, 128])
+def test_prefill_page_sizes(page):
+    inp = orc.make_paged_inputs(22, [70, 1, 300], [70, 513, 411], 8, 2, 128, page, torch.bfloat16)
+    _check(inp, torch.bfloat16)
+
+
+def test_prefill_features_window_softcap_alibi():
+    query_lens = [40, 1, 9, 130]
+    kv_lens = [70, 45, 33, 400]
+    inp = orc.make_paged_inputs(23, query_lens, kv_lens, 8, 2, 128, 16, torch.float16)
+    alibi = torch.tensor([2.0 ** (-(i + 1)) for i in range(8)], dtype=torch.float32)
+    _check(inp, torch.float16, window=8)
+    _check(inp, torch.float16, window=100)
+    _check(inp, torch.float16, softcap=30.0)
+    _check(inp, torch.float16, alibi=alibi)
+    _check(inp, torch.float16, window=64, softcap=20.0, alibi=alibi)
+
+
+def test_prefill_2d_forced_on_decode_batch():
+    inp = orc.make_paged_inputs(24, [1] * 4, [300, 17, 129, 1], 8, 2, 128, 16, torch.bfloat16)
+    _check(inp, torch.bfloat16, force=2)
+
+
+def test_prefill_strided_q_and_out():
+    """q/out are slices of a fused qkv buffer in vLLM: token stride != Hq*D."""
+    import gpu_util
+
+    inp = orc.make_paged_inputs(25, [33, 7], [64, 7], 8, 2, 128, 16, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    T = d["q"].shape[0]
+    big = torch.zeros(T, 8 + 4, 128, dtype=torch.bfloat16, device=gpu_util.DEV)
+    big[:, :8] = d["q"]
+    d["q"] = big[:, :8]
+    obig = torch.full((T, 8 + 4, 128), float("nan"), dtype=torch.bfloat16, device=gpu_util.DEV)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], out=obig[:, 2:10])
+    assert kernel.startswith("prefill")
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    assert torch.isnan(obig[:, :2]).all() and torch.isnan(obig[:, 10:]).all()  # nothing written outside
+
+
+def test_prefill_c2_full_size_properties():
+    """BASELINE C2 (Hq=32, Hk=8, D=128, q=kv=4096, bf16): sampled rows vs the oracle, constant-V
+    property, page-permutation invariance (bit-exact)."""
+    import gpu_util
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, L, page = 32, 8, 128, 4096, 16
+    g = torch.Generator().manual_seed(0)
+    nb = L // page + 5
+    k = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    v = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    q = (torch.rand(L, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    bt = torch.randperm(nb, generator=g)[: L // page].to(torch.int32).view(1, -1)
+    t = dict(q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=torch.tensor([0, L], dtype=torch.int32),
+             seqused_k=torch.tensor([L], dtype=torch.int32))
+    scale = 1.0 / math.sqrt(D)
+    d = gpu_util.to_dev(t)
+    out, kernel = gpu_util.run_unified(d, scale)
+    assert kernel == "prefill_mfma"
+    assert not torch.isnan(out).any()
+    # sampled query tokens vs the oracle: token at position pos == decode with kv_len pos+1
+    for pos in (0, 1, 63, 64, 1000, 2047, 4095):
+        sub_cu = torch.tensor([0, 1], dtype=torch.int32)
+        ref = orc.unified_attention_oracle(q[pos:pos + 1], k, v, sub_cu, torch.tensor([pos + 1], dtype=torch.int32), bt, scale, mode="2d",
+                                           block_n=64)
+        torch.testing.assert_close(out[pos:pos + 1].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    # page permutation invariance, bit-exact
+    perm = torch.randperm(nb, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nb)
+    d2 = dict(d)
+    d2["k_cache"] = d["k_cache"][perm.to(dev)]
+    d2["v_cache"] = d["v_cache"][perm.to(dev)]
+    d2["block_table"] = inv.to(dev)[d["block_table"].long()].to(torch.int32)
+    out2, _ = gpu_util.run_unified(d2, scale)
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    # constant V => constant output
+    d3 = dict(d)
+    d3["v_cache"] = torch.full_like(d["v_cache"], -0.25)
+    out3, _ = gpu_util.run_unified(d3, scale)
+    torch.testing.assert_close(out3.float(), torch.full_like(out3, -0.25).float(), atol=2e-3, rtol=0)

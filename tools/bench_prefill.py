@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Quick prefill microbench (config C2 by default): HIP-event timing of mi355_attn.unified_attention."""
+import argparse
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vllm-triton-backend_amd")]
+import torch  # noqa: E402
+
+from mi355_attn import _lib  # noqa: E402
+from mi355_attn.kernels import unified as ua_mod  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--hq", type=int, default=32)
+    ap.add_argument("--hk", type=int, default=8)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--page", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16
+    torch.manual_seed(0)
+    B, L, page = args.batch, args.seq, args.page
+    pps = (L + page - 1) // page
+    nb = int(B * pps * 1.25)
+    k = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+    v = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+    q = (torch.rand(B * L, args.hq, args.d, device=dev) * 2 - 1).to(dt)
+    bt = torch.randperm(nb, device=dev)[: B * pps].to(torch.int32).view(B, pps)
+    cu = (torch.arange(B + 1, dtype=torch.int32, device=dev) * L).to(torch.int32)
+    sl = torch.full((B,), L, dtype=torch.int32, device=dev)
+    out = torch.empty_like(q)
+    flops = 4 * L * L * args.d * args.hq / 2 * B
+    p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, None, None, None, None)
+    for _ in range(3):
+        ua_mod.launch(p, dev)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(args.iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ua_mod.launch(p, dev)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    print(f"B={B} L={L} kernel={_lib.last_kernel()} median {med*1e6:8.1f} us  min {ts[0]*1e6:8.1f} us  {flops/med/1e12:7.1f} TFLOP/s "
+          f"(min-time {flops/ts[0]/1e12:7.1f})  frac_of_2.5PF={flops/med/2.5e15:5.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

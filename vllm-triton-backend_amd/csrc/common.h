@@ -151,6 +151,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Exchange with the lane 32 (16) away. v_permlane{32,16}_swap swaps halves (odd/even rows) of TWO
+// registers; hipcc (ROCm 7.2) folds the two results into one when both operands are the same SSA
+// value, so the copy is made opaque first.
+__device__ __forceinline__ float lane_xor32(float v) {
+  uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
+  asm volatile("" : "+v"(b));
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  // lanes < 32: r[0] = own, r[1] = lane+32's; lanes >= 32: r[0] = lane-32's, r[1] = own
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor16(float v) {
+  uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
+  asm volatile("" : "+v"(b));
+  auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  // even rows: r[0] = own, r[1] = lane+16's; odd rows: r[0] = lane-16's, r[1] = own
+  return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+}
+
 // x * tanh(s / x) (reference: apply_softcap, triton_unified_attention.py:24-29, restated with tanhf
 // so that |s/x| > 88 does not overflow)
 __device__ __forceinline__ float softcap_fn(float s, float cap) { return cap * tanhf(s / cap); }

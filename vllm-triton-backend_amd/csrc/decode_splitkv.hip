@@ -68,19 +68,14 @@ template <> struct mma<f16_t> {
   static __device__ __forceinline__ u32x2_t pack4(float a, float b, float c, float d) { return u32x2_t{pack2(a, b), pack2(c, d)}; }
 };
 
-// max over the four lanes {g, g+16, g+32, g+48}
+// max / sum over the four lanes {g, g+16, g+32, g+48}
 __device__ __forceinline__ float max_over_lane_groups(float v) {
-  uint32_t u = __builtin_bit_cast(uint32_t, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0]/r[1]: own value and the lane 32 away
-  v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-  u = __builtin_bit_cast(uint32_t, v);
-  auto q = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
+  v = fmaxf(v, lane_xor32(v));
+  return fmaxf(v, lane_xor16(v));
 }
 __device__ __forceinline__ float sum_over_lane_groups(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  v += lane_xor32(v);
+  return v + lane_xor16(v);
 }
 
 template <typename T, int D, int WAVES>

@@ -1,5 +1,355 @@
+// Chunked / context prefill attention over the paged KV cache for gfx950.
+//
+// Replaces kernel_unified_attention_2d (LIB/kernels/triton_unified_attention.py:275-523): causal
+// attention of a "Q block" (BLOCK_Q consecutive query tokens x all G query heads of one KV head)
+// against keys [0, context_len + position], KV fetched through the block table. MFMA-bound.
+//
+// Structure (one workgroup = 4 waves = 128 Q-block rows, each wave 32 rows; KV tile = 64 keys):
+//   * rows are ordered (token, head-in-group) exactly like the reference (offs_m // G, offs_m % G,
+//     :343-346), so all G heads of a KV head share every K/V tile (GQA broadcast through LDS);
+//   * K/V tiles are fetched HBM -> VGPR with row-shaped 16-byte loads one tile ahead of their use
+//     (issued before the MFMA phase, written to LDS after it) and shared by the 4 waves via LDS:
+//     K rows padded to 2D+16 bytes (conflict-free ds_read_b128 A-operand reads), V rows padded to
+//     2D+64 bytes (conflict-free ds_read_b64_tr_b16 transposed reads);
+//   * S^T = K.Q^T with v_mfma_f32_32x32x16 ("swapped" product): lane (q = lane&31, half = lane>>5)
+//     then owns one query row: its 16+16 accumulator registers are 32 of the tile's 64 keys, so the
+//     online softmax is in-register (one v_permlane32_swap per tile for the row max) and m, l, alpha
+//     are lane-local;
+//   * O^T += V^T.P^T: the bf16-packed accumulator registers of S^T are directly the B operand
+//     (k-slot j of half h = key 16s + 8(j>>2) + 4h + (j&3)); the transposed V read is addressed to
+//     deliver the same key order, so P never moves between lanes or through LDS;
+//   * softmax in the exp2 domain with scale*log2(e) folded in; causal/window masks only on tiles
+//     that straddle a boundary; the KV loop stops at the Q block's last visible key (causal tile
+//     skipping, :384-400) and starts at the sliding window's first visible tile (the reference
+//     only masks).
+// Launch grid mirrors the reference's static upper bound (T / BLOCK_Q + S Q-blocks, :886-889,
+// :935-943), heaviest (latest) Q blocks first.
 #include "common.h"
+
 namespace mi355 {
-bool prefill_supported(const mi355_attn_params&) { return false; }
-int launch_prefill(const mi355_attn_params&, hipStream_t) { set_error("prefill kernel not built"); return MI355_ERR_UNSUPPORTED; }
+
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 pf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short ps16x4_t;
+typedef __attribute__((ext_vector_type(8))) short ps16x8_t;
+typedef __attribute__((ext_vector_type(16))) float pf32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int pu32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int pu32x2_t;
+
+constexpr int kBlockM = 128;   // Q-block rows per workgroup
+constexpr int kTileN = 64;     // keys per KV tile
+constexpr float kLog2eP = 1.4426950408889634f;
+
+struct PrefillArgs {
+  mi355_attn_params p;
+  int group;     // G
+  int block_q;   // tokens per Q block = kBlockM / G
+};
+
+template <typename T> struct pmma;
+template <> struct pmma<bf16_t> {
+  static __device__ __forceinline__ pf32x16_t run(ps16x8_t a, ps16x8_t b, pf32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8_t, a), __builtin_bit_cast(pbf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  }
+};
+template <> struct pmma<f16_t> {
+  static __device__ __forceinline__ pf32x16_t run(ps16x8_t a, ps16x8_t b, pf32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8_t, a), __builtin_bit_cast(pf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
+  }
+};
+
+// largest i with cu[i] / block_q + i <= qblock (reference: find_seq_idx in Q-block mode, :32-52)
+__device__ __forceinline__ int find_seq_by_qblock(const int32_t* __restrict__ cu, int num_seqs, int qblock, int block_q) {
+  int left = 0, right = num_seqs;
+  while (left < right) {
+    const int mid = (left + right) >> 1;
+    if (cu[mid] / block_q + mid <= qblock) left = mid + 1; else right = mid;
+  }
+  return left - 1;
 }
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) {
+  constexpr int PPR = D / 8;                 // 16-byte pieces per key row
+  constexpr int NLD = PPR / 4;               // loads per thread per tile (64 keys * PPR pieces / 256 threads)
+  constexpr int RSK = D * 2 + 16;            // K row stride in LDS (bytes)
+  constexpr int RSV = D * 2 + 64;            // V row stride in LDS (bytes)
+  constexpr int KSTEPS = D / 16;             // k-steps of K.Q^T
+  constexpr int DBLK = D / 32;               // 32-wide output blocks of P.V
+
+  __shared__ __attribute__((aligned(16))) char k_lds[kTileN * RSK];
+  __shared__ __attribute__((aligned(16))) char v_lds[kTileN * RSV];
+
+  const mi355_attn_params& p = a.p;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = a.group, BQ = a.block_q;
+
+  // heaviest Q blocks (largest index = longest causal prefix within a sequence) first
+  const int qblock = (int)(gridDim.x - 1 - blockIdx.x);
+  const int head = blockIdx.y;
+  const int seq = find_seq_by_qblock(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
+  if (seq < 0) return;
+  const int q_start = p.cu_seqlens_q[seq];
+  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
+  const int qb_local = qblock - (q_start / BQ + seq);
+  if (qb_local * BQ >= q_len) return;                      // surplus program (:338-339)
+  if (p.skip_decodes && q_len == 1) return;
+  if (p.only_decodes && q_len != 1) return;
+  const int seq_len = p.seqused_k[seq];
+  const int ctx_len = seq_len - q_len;
+  const int tok0 = qb_local * BQ;                          // first query token (local) of this Q block
+
+  // ---- this lane's query row -------------------------------------------------------------------
+  const int qr = lane & 31, half = lane >> 5;
+  const int m_row = wave * 32 + qr;                        // row inside the Q block
+  const int tok_local = tok0 + m_row / G;                  // query position inside the sequence's query
+  const int hq = head * G + m_row % G;
+  const bool row_ok = (m_row < BQ * G) && (tok_local < q_len);
+  const int q_abs = ctx_len + tok_local;                   // absolute position; sees keys j <= q_abs
+
+  // wave-uniform bounds of the rows this wave / workgroup owns
+  const int w_tok_lo = tok0 + (wave * 32) / G;
+  const int w_tok_hi = min(min(tok0 + (wave * 32 + 31) / G, tok0 + BQ - 1), q_len - 1);
+  const int wg_tok_hi = min(tok0 + BQ - 1, q_len - 1);
+  int n_keys_wg = min(ctx_len + wg_tok_hi + 1, seq_len);   // max_seq_prefix_len (:384-393)
+  if (n_keys_wg < 0) n_keys_wg = 0;
+  const int wave_keys = min(ctx_len + w_tok_hi + 1, seq_len);  // this wave has nothing to do beyond
+  const bool wave_has_rows = w_tok_lo <= w_tok_hi;
+  int first_key_wg = 0;
+  if (p.sliding_window > 0) first_key_wg = max(0, ctx_len + tok0 - p.sliding_window + 1);
+  const int tile_lo = first_key_wg / kTileN;
+  const int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): lane (qr, half) holds Q[row][16ks + 8half .. +7] ----
+  ps16x8_t qf[KSTEPS];
+  {
+    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)(q_start + tok_local) * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      pu32x4_t v = {0, 0, 0, 0};
+      if (row_ok) v = *(const pu32x4_t*)(qp + 16 * ks);
+      qf[ks] = __builtin_bit_cast(ps16x8_t, v);
+    }
+  }
+  const float slope = (p.alibi_slopes && row_ok) ? p.alibi_slopes[hq] : 0.0f;
+  const float scale2 = p.scale * kLog2eP;
+  const bool plain = !(p.softcap > 0.0f) && !p.alibi_slopes;
+
+  // ---- staging: thread t loads pieces t + 256*i of the 64 x PPR tile ------------------------------
+  const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
+  const uint16_t* kbase = (const uint16_t*)p.k_cache + (int64_t)head * p.k_stride_head;
+  const uint16_t* vbase = (const uint16_t*)p.v_cache + (int64_t)head * p.v_stride_head;
+  const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
+  int st_key[NLD], st_off[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + 256 * i;
+    st_key[i] = idx / PPR;                 // key inside the tile
+    st_off[i] = (idx % PPR) * 8;           // element offset inside the row
+  }
+  pu32x4_t kreg[NLD], vreg[NLD];
+  auto issue_loads = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int gi = min(tile * (kTileN / 16) + (st_key[i] >> 4), last_group);  // stay inside the sequence's pages
+      const int key0 = gi << 4;
+      const int page = bt[key0 / p.page_size];
+      const int slot = key0 % p.page_size + (st_key[i] & 15);
+      kreg[i] = *(const pu32x4_t*)(kbase + (int64_t)page * p.k_stride_page + (int64_t)slot * p.k_stride_slot + st_off[i]);
+      vreg[i] = *(const pu32x4_t*)(vbase + (int64_t)page * p.v_stride_page + (int64_t)slot * p.v_stride_slot + st_off[i]);
+    }
+  };
+  auto write_lds = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      pu32x4_t v = vreg[i];
+      // slots past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
+      if (tile * kTileN + st_key[i] >= seq_len) v = pu32x4_t{0, 0, 0, 0};
+      *(pu32x4_t*)(k_lds + st_key[i] * RSK + st_off[i] * 2) = kreg[i];
+      *(pu32x4_t*)(v_lds + st_key[i] * RSV + st_off[i] * 2) = v;
+    }
+  };
+
+  float m_run = -INFINITY, l_run = 0.0f;
+  pf32x16_t o_acc[DBLK];
+#pragma unroll
+  for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
+
+  if (tile_lo < tile_hi) {
+    issue_loads(tile_lo);
+    write_lds(tile_lo);
+  }
+  __syncthreads();
+
+  // per-lane constants of the LDS reads
+  const char* k_rd = k_lds + qr * RSK + half * 16;                                  // + kb*32*RSK + ks*32
+  const int gq1 = (lane >> 4) & 1, li = lane & 15;
+  const char* v_rd = v_lds + (4 * half + (li >> 2)) * RSV + (16 * gq1 + 4 * (li & 3)) * 2;  // + sk*16*RSV + db*64
+
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const bool has_next = tile + 1 < tile_hi;
+    if (has_next) issue_loads(tile + 1);
+
+    const int key_base = tile * kTileN;
+    if (wave_has_rows && key_base < wave_keys) {
+      // ---- S^T = K . Q^T ---------------------------------------------------------------------------
+      pf32x16_t s_acc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const pu32x4_t kf = *(const pu32x4_t*)(k_rd + kb * 32 * RSK + ks * 32);
+          s_acc[kb] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf), qf[ks], s_acc[kb]);
+        }
+      }
+      // ---- softmax (log2 domain) -------------------------------------------------------------------
+      // register r of block kb <-> key key_base + 32kb + (r&3) + 8(r>>2) + 4half
+      const bool need_mask = (key_base + kTileN - 1 > ctx_len + w_tok_lo) || (key_base + kTileN > seq_len) ||
+                             (p.sliding_window > 0 && key_base < ctx_len + w_tok_hi - p.sliding_window + 1);
+      float mx = -INFINITY;
+      if (plain && !need_mask) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            s_acc[kb][r] *= scale2;
+            mx = fmaxf(mx, s_acc[kb][r]);
+          }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float x = s_acc[kb][r] * p.scale;
+            if (p.softcap > 0.0f) x = softcap_fn(x, p.softcap);
+            bool ok = row_ok && key <= q_abs && key < seq_len;
+            if (p.sliding_window > 0) ok = ok && (q_abs - key) < p.sliding_window;
+            x = ok ? x : -INFINITY;
+            if (p.alibi_slopes) x += slope * (float)(key - ctx_len);
+            x *= kLog2eP;
+            s_acc[kb][r] = x;
+            mx = fmaxf(mx, x);
+          }
+      }
+      mx = fmaxf(mx, lane_xor32(mx));  // the other half-wave holds the other 32 keys of this query row
+      float m_new = fmaxf(m_run, mx);
+      if (!(m_new > -INFINITY)) m_new = 0.0f;                     // row fully masked so far (:486-489)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.0f;
+      ps16x8_t pf[4];                                             // B operands of the 4 k-steps of P.V
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          e[r] = __builtin_amdgcn_exp2f(s_acc[kb][r] - m_new);
+          psum += e[r];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const pu32x4_t w = {pmma<T>::pack2(e[8 * s + 0], e[8 * s + 1]), pmma<T>::pack2(e[8 * s + 2], e[8 * s + 3]),
+                              pmma<T>::pack2(e[8 * s + 4], e[8 * s + 5]), pmma<T>::pack2(e[8 * s + 6], e[8 * s + 7])};
+          pf[2 * kb + s] = __builtin_bit_cast(ps16x8_t, w);
+        }
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      // ---- O^T = alpha * O^T + V^T . P^T -----------------------------------------------------------
+#pragma unroll
+      for (int b = 0; b < DBLK; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk) {
+          const char* va = v_rd + sk * 16 * RSV + b * 64;
+          const ps16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va));
+          const ps16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va + 8 * RSV));
+          const ps16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          o_acc[b] = pmma<T>::run(vf, pf[sk], o_acc[b]);
+        }
+      }
+    }
+    __syncthreads();               // every wave is done reading this tile
+    if (has_next) write_lds(tile + 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O = O^T / l, lane (qr, half) register r of block b <-> d = 32b + (r&3) + 8(r>>2) + 4half
+  l_run += lane_xor32(l_run);
+  if (!row_ok) return;
+  const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+  uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
+#pragma unroll
+  for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
+                          pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+      *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static bool paligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
+
+bool prefill_supported(const mi355_attn_params& p) {
+  if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
+  if (p.kv_dtype != p.q_dtype) return false;
+  if (!(p.head_size == 64 || p.head_size == 128)) return false;
+  if (p.k_new || p.v_new) return false;
+  if (p.page_size % 16 != 0) return false;
+  if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
+  const int G = p.num_q_heads / p.num_kv_heads;
+  if (G > kBlockM) return false;
+  if (!paligned16(p.q) || !paligned16(p.k_cache) || !paligned16(p.v_cache)) return false;
+  if (((uintptr_t)p.out & 7) != 0) return false;
+  const int64_t strides[] = {p.q_stride_token, p.q_stride_head, p.k_stride_page, p.k_stride_slot, p.k_stride_head,
+                             p.v_stride_page, p.v_stride_slot, p.v_stride_head};
+  for (int64_t s : strides) if (s % 8 != 0) return false;
+  if (p.out_stride_token % 4 != 0 || p.out_stride_head % 4 != 0) return false;
+  return true;
+}
+
+template <typename T, int D>
+static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
+  PrefillArgs a;
+  a.p = p;
+  a.group = p.num_q_heads / p.num_kv_heads;
+  a.block_q = kBlockM / a.group;
+  const int qblocks = p.num_tokens / a.block_q + p.num_seqs;  // static upper bound (:886-889,:935-943)
+  hipLaunchKernelGGL((prefill_mfma_kernel<T, D>), dim3(qblocks, p.num_kv_heads), dim3(256), 0, stream, a);
+  const int rc = check_hip(hipGetLastError(), "prefill_mfma_kernel launch");
+  if (rc == MI355_OK) set_kernel_name("prefill_mfma");
+  return rc;
+}
+
+int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
+  if (!prefill_supported(p)) {
+    set_error("prefill kernel does not support this configuration");
+    return MI355_ERR_UNSUPPORTED;
+  }
+  const bool bf = p.q_dtype == MI355_BF16;
+  switch (p.head_size) {
+    case 64: return bf ? launch_prefill_t<bf16_t, 64>(p, stream) : launch_prefill_t<f16_t, 64>(p, stream);
+    case 128: return bf ? launch_prefill_t<bf16_t, 128>(p, stream) : launch_prefill_t<f16_t, 128>(p, stream);
+  }
+  set_error("prefill: head_size %d not built", p.head_size);
+  return MI355_ERR_UNSUPPORTED;
+}
+
+}  // namespace mi355
