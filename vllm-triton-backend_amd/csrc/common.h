@@ -169,6 +169,27 @@ __device__ __forceinline__ float lane_xor16(float v) {
   return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
 }
 
+// Four wave-uniform 32-bit loads through the scalar cache, returned only after they have landed.
+// hipcc falls back to vector loads (and then drains every older vector load with them, because
+// vmcnt retires in order) for uniform loads it cannot prove read-only, so block-table lookups in
+// a software-pipelined loop go through this instead. `base` and `idx*` must be wave-uniform.
+__device__ __forceinline__ void scalar_load4(const int32_t* base, int i0, int i1, int i2, int i3, int& r0, int& r1, int& r2, int& r3) {
+  const int o0 = __builtin_amdgcn_readfirstlane(i0 * 4), o1 = __builtin_amdgcn_readfirstlane(i1 * 4);
+  const int o2 = __builtin_amdgcn_readfirstlane(i2 * 4), o3 = __builtin_amdgcn_readfirstlane(i3 * 4);
+  const uint64_t b = (uint64_t)base;
+  const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint64_t bu = ((uint64_t)bhi << 32) | blo;
+  asm volatile(
+      "s_load_dword %0, %4, %5\n\t"
+      "s_load_dword %1, %4, %6\n\t"
+      "s_load_dword %2, %4, %7\n\t"
+      "s_load_dword %3, %4, %8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3)
+      : "s"(bu), "s"(o0), "s"(o1), "s"(o2), "s"(o3)
+      : "memory");
+}
+
 // x * tanh(s / x) (reference: apply_softcap, triton_unified_attention.py:24-29, restated with tanhf
 // so that |s/x| > 88 does not overflow)
 __device__ __forceinline__ float softcap_fn(float s, float cap) { return cap * tanhf(s / cap); }

@@ -42,8 +42,9 @@ constexpr float kLog2eP = 1.4426950408889634f;
 
 struct PrefillArgs {
   mi355_attn_params p;
-  int group;     // G
-  int block_q;   // tokens per Q block = kBlockM / G
+  int group;      // G
+  int block_q;    // tokens per Q block = kBlockM / G
+  int page_shift; // log2(page_size)
 };
 
 template <typename T> struct pmma;
@@ -74,8 +75,10 @@ __device__ __forceinline__ int find_seq_by_qblock(const int32_t* __restrict__ cu
   return left - 1;
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) {
+// FEAT = soft-cap / ALiBi / sliding window compiled in; the plain instantiation only knows the
+// causal + sequence-length mask.
+template <typename T, int D, bool FEAT>
+__global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs a) {
   constexpr int PPR = D / 8;                 // 16-byte pieces per key row
   constexpr int NLD = PPR / 4;               // loads per thread per tile (64 keys * PPR pieces / 256 threads)
   constexpr int RSK = D * 2 + 16;            // K row stride in LDS (bytes)
@@ -83,8 +86,8 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
   constexpr int KSTEPS = D / 16;             // k-steps of K.Q^T
   constexpr int DBLK = D / 32;               // 32-wide output blocks of P.V
 
-  __shared__ __attribute__((aligned(16))) char k_lds[kTileN * RSK];
-  __shared__ __attribute__((aligned(16))) char v_lds[kTileN * RSV];
+  constexpr int KBUF = kTileN * RSK, VBUF = kTileN * RSV, BUF = KBUF + VBUF;   // one stage: K tile then V tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];                    // two stages
 
   const mi355_attn_params& p = a.p;
   const int tid = threadIdx.x;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
   const int wave_keys = min(ctx_len + w_tok_hi + 1, seq_len);  // this wave has nothing to do beyond
   const bool wave_has_rows = w_tok_lo <= w_tok_hi;
   int first_key_wg = 0;
-  if (p.sliding_window > 0) first_key_wg = max(0, ctx_len + tok0 - p.sliding_window + 1);
+  if (FEAT && p.sliding_window > 0) first_key_wg = max(0, ctx_len + tok0 - p.sliding_window + 1);
   const int tile_lo = first_key_wg / kTileN;
   const int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
 
@@ -139,42 +142,65 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
       qf[ks] = __builtin_bit_cast(ps16x8_t, v);
     }
   }
-  const float slope = (p.alibi_slopes && row_ok) ? p.alibi_slopes[hq] : 0.0f;
+  const float slope = (FEAT && p.alibi_slopes && row_ok) ? p.alibi_slopes[hq] : 0.0f;
   const float scale2 = p.scale * kLog2eP;
-  const bool plain = !(p.softcap > 0.0f) && !p.alibi_slopes;
+  const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
 
   // ---- staging: thread t loads pieces t + 256*i of the 64 x PPR tile ------------------------------
+  // Load round i of a wave touches exactly one 16-key group, so the page lookup is wave-uniform:
+  // scalar loads + scalar address arithmetic, one tile ahead of the vector loads that use it.
   const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
   const uint16_t* kbase = (const uint16_t*)p.k_cache + (int64_t)head * p.k_stride_head;
   const uint16_t* vbase = (const uint16_t*)p.v_cache + (int64_t)head * p.v_stride_head;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
-  int st_key[NLD], st_off[NLD];
+  const int page_mask = p.page_size - 1;
+  int st_key[NLD], st_off[NLD];             // key inside the tile / element offset inside the row
+  uint32_t k_toff[NLD], v_toff[NLD];        // this thread's element offset from the group's first row
+  int st_grp[NLD];                          // 16-key group inside the tile (wave-uniform)
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int idx = tid + 256 * i;
-    st_key[i] = idx / PPR;                 // key inside the tile
-    st_off[i] = (idx % PPR) * 8;           // element offset inside the row
+    st_key[i] = idx / PPR;
+    st_off[i] = (idx % PPR) * 8;
+    st_grp[i] = __builtin_amdgcn_readfirstlane(st_key[i] >> 4);
+    k_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.k_stride_slot + st_off[i]);
+    v_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.v_stride_slot + st_off[i]);
   }
+  int pg_next[4];                           // physical pages of the NEXT tile's four 16-key groups (SGPRs)
+  auto lookup_pages = [&](int tile) {
+    int idx[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) idx[g4] = (min(tile * 4 + g4, last_group) << 4) >> a.page_shift;  // stay inside the sequence's pages
+    scalar_load4(bt, idx[0], idx[1], idx[2], idx[3], pg_next[0], pg_next[1], pg_next[2], pg_next[3]);
+  };
   pu32x4_t kreg[NLD], vreg[NLD];
-  auto issue_loads = [&](int tile) {
+  auto issue_loads = [&](int tile) {        // uses pg_next, which must hold this tile's pages
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int gi = min(tile * (kTileN / 16) + (st_key[i] >> 4), last_group);  // stay inside the sequence's pages
-      const int key0 = gi << 4;
-      const int page = bt[key0 / p.page_size];
-      const int slot = key0 % p.page_size + (st_key[i] & 15);
-      kreg[i] = *(const pu32x4_t*)(kbase + (int64_t)page * p.k_stride_page + (int64_t)slot * p.k_stride_slot + st_off[i]);
-      vreg[i] = *(const pu32x4_t*)(vbase + (int64_t)page * p.v_stride_page + (int64_t)slot * p.v_stride_slot + st_off[i]);
+      const int gi = min(tile * (kTileN / 16) + st_grp[i], last_group);
+      const int slot0 = (gi << 4) & page_mask;
+      int page;
+      if constexpr (PPR >= 16) {            // a load round covers one group (D=128) or half of one (D=256)
+        page = pg_next[(256 * i) / (16 * PPR)];
+      } else if constexpr (PPR == 8) {      // D=64: waves 0-1 / 2-3 of round i take groups 2i / 2i+1
+        page = (wave >> 1) ? pg_next[2 * i + 1] : pg_next[2 * i];
+      } else {                              // D=32: one group per wave
+        page = wave == 0 ? pg_next[0] : wave == 1 ? pg_next[1] : wave == 2 ? pg_next[2] : pg_next[3];
+      }
+      const uint16_t* kp = kbase + (int64_t)page * p.k_stride_page + (int64_t)slot0 * p.k_stride_slot;
+      const uint16_t* vp = vbase + (int64_t)page * p.v_stride_page + (int64_t)slot0 * p.v_stride_slot;
+      kreg[i] = *(const pu32x4_t*)(kp + k_toff[i]);
+      vreg[i] = *(const pu32x4_t*)(vp + v_toff[i]);
     }
   };
-  auto write_lds = [&](int tile) {
+  auto write_lds = [&](int tile, char* stage) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       pu32x4_t v = vreg[i];
       // slots past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
       if (tile * kTileN + st_key[i] >= seq_len) v = pu32x4_t{0, 0, 0, 0};
-      *(pu32x4_t*)(k_lds + st_key[i] * RSK + st_off[i] * 2) = kreg[i];
-      *(pu32x4_t*)(v_lds + st_key[i] * RSV + st_off[i] * 2) = v;
+      *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2) = kreg[i];
+      *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2) = v;
     }
   };
 
@@ -186,19 +212,32 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
     for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
 
   if (tile_lo < tile_hi) {
+    lookup_pages(tile_lo);
     issue_loads(tile_lo);
-    write_lds(tile_lo);
+    if (tile_lo + 1 < tile_hi) lookup_pages(tile_lo + 1);
+    write_lds(tile_lo, smem);
   }
   __syncthreads();
 
-  // per-lane constants of the LDS reads
-  const char* k_rd = k_lds + qr * RSK + half * 16;                                  // + kb*32*RSK + ks*32
+  // Make the Q fragments' loads retire HERE: otherwise the compiler's in-loop wait for them
+  // (needed on the first iteration only) is a vmcnt(0) that also drains every K/V prefetch.
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
+
+  // per-lane offsets of the LDS reads inside a stage
+  const int k_rd_off = qr * RSK + half * 16;                                          // + kb*32*RSK + ks*32
   const int gq1 = (lane >> 4) & 1, li = lane & 15;
-  const char* v_rd = v_lds + (4 * half + (li >> 2)) * RSV + (16 * gq1 + 4 * (li & 3)) * 2;  // + sk*16*RSV + db*64
+  const int v_rd_off = KBUF + (4 * half + (li >> 2)) * RSV + (16 * gq1 + 4 * (li & 3)) * 2;  // + sk*16*RSV + db*64
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const bool has_next = tile + 1 < tile_hi;
-    if (has_next) issue_loads(tile + 1);
+    if (has_next) {
+      issue_loads(tile + 1);
+      if (tile + 2 < tile_hi) lookup_pages(tile + 2);
+    }
+    char* stage = smem + ((tile - tile_lo) & 1) * BUF;
+    const char* k_rd = stage + k_rd_off;
+    const char* v_rd = stage + v_rd_off;
 
     const int key_base = tile * kTileN;
     if (wave_has_rows && key_base < wave_keys) {
@@ -216,16 +255,28 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
       }
       // ---- softmax (log2 domain) -------------------------------------------------------------------
       // register r of block kb <-> key key_base + 32kb + (r&3) + 8(r>>2) + 4half
-      const bool need_mask = (key_base + kTileN - 1 > ctx_len + w_tok_lo) || (key_base + kTileN > seq_len) ||
-                             (p.sliding_window > 0 && key_base < ctx_len + w_tok_hi - p.sliding_window + 1);
+      bool need_mask = (key_base + kTileN - 1 > ctx_len + w_tok_lo) || (key_base + kTileN > seq_len);
+      if (FEAT) need_mask = need_mask || (p.sliding_window > 0 && key_base < ctx_len + w_tok_hi - p.sliding_window + 1);
       float mx = -INFINITY;
+      float sc = 1.0f;   // factor still to be applied to s_acc inside the exp2 argument
       if (plain && !need_mask) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
+        mx *= scale2;      // scale2 > 0: max commutes with the scaling
+        sc = scale2;
+      } else if (!FEAT || plain && !(p.sliding_window > 0)) {
+        // causal / end-of-sequence mask only
+        const int lim = row_ok ? min(q_abs, seq_len - 1) : -1;   // last visible key of this row
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
           for (int r = 0; r < 16; ++r) {
-            s_acc[kb][r] *= scale2;
-            mx = fmaxf(mx, s_acc[kb][r]);
+            const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float x = key <= lim ? s_acc[kb][r] * scale2 : -INFINITY;
+            s_acc[kb][r] = x;
+            mx = fmaxf(mx, x);
           }
       } else {
 #pragma unroll
@@ -255,7 +306,7 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
         float e[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          e[r] = __builtin_amdgcn_exp2f(s_acc[kb][r] - m_new);
+          e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, -m_new));
           psum += e[r];
         }
 #pragma unroll
@@ -268,10 +319,13 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
       l_run = l_run * alpha + psum;
       m_run = m_new;
       // ---- O^T = alpha * O^T + V^T . P^T -----------------------------------------------------------
+      const bool rescale = !__all(alpha == 1.0f);                 // exact: skipped only when no row's max moved
 #pragma unroll
       for (int b = 0; b < DBLK; ++b) {
+        if (rescale) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
+        }
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) {
           const char* va = v_rd + sk * 16 * RSV + b * 64;
@@ -282,8 +336,8 @@ __global__ __launch_bounds__(256) void prefill_mfma_kernel(const PrefillArgs a) 
         }
       }
     }
-    __syncthreads();               // every wave is done reading this tile
-    if (has_next) write_lds(tile + 1);
+    // the other stage was last read one iteration ago and every wave has passed a barrier since
+    if (has_next) write_lds(tile + 1, smem + (((tile - tile_lo) & 1) ^ 1) * BUF);
     __syncthreads();
   }
 
@@ -312,8 +366,9 @@ bool prefill_supported(const mi355_attn_params& p) {
   if (p.kv_dtype != p.q_dtype) return false;
   if (!(p.head_size == 64 || p.head_size == 128)) return false;
   if (p.k_new || p.v_new) return false;
-  if (p.page_size % 16 != 0) return false;
+  if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
+  if (p.k_stride_slot >= (1 << 24) || p.v_stride_slot >= (1 << 24)) return false;      // 32-bit in-page offsets
   const int G = p.num_q_heads / p.num_kv_heads;
   if (G > kBlockM) return false;
   if (!paligned16(p.q) || !paligned16(p.k_cache) || !paligned16(p.v_cache)) return false;
@@ -325,16 +380,25 @@ bool prefill_supported(const mi355_attn_params& p) {
   return true;
 }
 
-template <typename T, int D>
+template <typename T, int D, bool FEAT>
 static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   PrefillArgs a;
   a.p = p;
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = kBlockM / a.group;
+  a.page_shift = __builtin_ctz((unsigned)p.page_size);
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;  // static upper bound (:886-889,:935-943)
-  hipLaunchKernelGGL((prefill_mfma_kernel<T, D>), dim3(qblocks, p.num_kv_heads), dim3(256), 0, stream, a);
+  constexpr size_t lds = 2 * (size_t)kTileN * ((D * 2 + 16) + (D * 2 + 64));
+  static bool attr_set = false;   // >64 KiB of dynamic LDS needs an opt-in, once per kernel
+  if (!attr_set) {
+    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_mfma_kernel<T, D, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                              "hipFuncSetAttribute(prefill)");
+    if (rc0 != MI355_OK) return rc0;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((prefill_mfma_kernel<T, D, FEAT>), dim3(qblocks, p.num_kv_heads), dim3(256), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_mfma_kernel launch");
-  if (rc == MI355_OK) set_kernel_name("prefill_mfma");
+  if (rc == MI355_OK) set_kernel_name(FEAT ? "prefill_mfma_feat" : "prefill_mfma");
   return rc;
 }
 
@@ -344,10 +408,16 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
     return MI355_ERR_UNSUPPORTED;
   }
   const bool bf = p.q_dtype == MI355_BF16;
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+#define MI355_PREFILL_CASE(DD)                                                                            \
+  case DD:                                                                                                \
+    if (feat) return bf ? launch_prefill_t<bf16_t, DD, true>(p, stream) : launch_prefill_t<f16_t, DD, true>(p, stream); \
+    return bf ? launch_prefill_t<bf16_t, DD, false>(p, stream) : launch_prefill_t<f16_t, DD, false>(p, stream);
   switch (p.head_size) {
-    case 64: return bf ? launch_prefill_t<bf16_t, 64>(p, stream) : launch_prefill_t<f16_t, 64>(p, stream);
-    case 128: return bf ? launch_prefill_t<bf16_t, 128>(p, stream) : launch_prefill_t<f16_t, 128>(p, stream);
+    MI355_PREFILL_CASE(64)
+    MI355_PREFILL_CASE(128)
   }
+#undef MI355_PREFILL_CASE
   set_error("prefill: head_size %d not built", p.head_size);
   return MI355_ERR_UNSUPPORTED;
 }
