@@ -101,6 +101,19 @@ __device__ __forceinline__ uint8_t f32_to_e5m2_sat(float f) {
   return (uint8_t)(sign | out);
 }
 
+// two f32 -> one dword of two 16-bit floats with ONE v_cvt_pk_* instruction (the scalar casts in
+// f32_to_bf16/f32_to_f16 cost a convert per element plus shift/or to pack)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));
+}
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, h2));
+}
+
 template <typename T> struct elem;
 template <> struct elem<f32_t> {
   static __device__ __forceinline__ float load(const void* p, int64_t i) { return ((const float*)p)[i]; }

@@ -54,7 +54,7 @@ template <> struct mma<bf16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    return pack_bf16x2(lo, hi);
   }
   static __device__ __forceinline__ u32x2_t pack4(float a, float b, float c, float d) { return u32x2_t{pack2(a, b), pack2(c, d)}; }
 };
@@ -63,7 +63,7 @@ template <> struct mma<f16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
+    return pack_f16x2(lo, hi);
   }
   static __device__ __forceinline__ u32x2_t pack4(float a, float b, float c, float d) { return u32x2_t{pack2(a, b), pack2(c, d)}; }
 };

@@ -45,6 +45,7 @@ struct PrefillArgs {
   int group;      // G
   int block_q;    // tokens per Q block = kBlockM / G
   int page_shift; // log2(page_size)
+  uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
 };
 
 template <typename T> struct pmma;
@@ -53,7 +54,7 @@ template <> struct pmma<bf16_t> {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8_t, a), __builtin_bit_cast(pbf16x8_t, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    return pack_bf16x2(lo, hi);
   }
 };
 template <> struct pmma<f16_t> {
@@ -61,7 +62,7 @@ template <> struct pmma<f16_t> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8_t, a), __builtin_bit_cast(pf16x8_t, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
+    return pack_f16x2(lo, hi);
   }
 };
 
@@ -95,9 +96,11 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.group, BQ = a.block_q;
 
-  // heaviest Q blocks (largest index = longest causal prefix within a sequence) first
-  const int qblock = (int)(gridDim.x - 1 - blockIdx.x);
-  const int head = blockIdx.y;
+  // 1-D grid, KV head fastest: workgroups are dealt round-robin to the 8 XCDs, so with Hk = 8 every
+  // XCD's L2 serves exactly one KV head's K/V (re-read by all of that head's Q blocks) instead of
+  // all of them. Heaviest Q blocks (largest index = longest causal prefix) first.
+  const int head = (int)(blockIdx.x % p.num_kv_heads);
+  const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);
   const int seq = find_seq_by_qblock(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
   if (seq < 0) return;
   const int q_start = p.cu_seqlens_q[seq];
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
       } else {                              // D=32: one group per wave
         page = wave == 0 ? pg_next[0] : wave == 1 ? pg_next[1] : wave == 2 ? pg_next[2] : pg_next[3];
       }
-      const uint16_t* kp = kbase + (int64_t)page * p.k_stride_page + (int64_t)slot0 * p.k_stride_slot;
-      const uint16_t* vp = vbase + (int64_t)page * p.v_stride_page + (int64_t)slot0 * p.v_stride_slot;
+      const uint16_t* kp = kbase + ((uint64_t)(uint32_t)page * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride);
+      const uint16_t* vp = vbase + ((uint64_t)(uint32_t)page * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
       kreg[i] = *(const pu32x4_t*)(kp + k_toff[i]);
       vreg[i] = *(const pu32x4_t*)(vp + v_toff[i]);
     }
@@ -242,16 +245,29 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
     const int key_base = tile * kTileN;
     if (wave_has_rows && key_base < wave_keys) {
       // ---- S^T = K . Q^T ---------------------------------------------------------------------------
+      // All K fragments of a 32-key block are requested before its first MFMA, and the next block's
+      // reads are issued behind the MFMAs that free their registers, so the matrix pipe never waits
+      // for a single ds_read round trip (sched_group_barrier pins that order).
       pf32x16_t s_acc[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.0f;
+      pu32x4_t kf[KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          const pu32x4_t kf = *(const pu32x4_t*)(k_rd + kb * 32 * RSK + ks * 32);
-          s_acc[kb] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf), qf[ks], s_acc[kb]);
-        }
+      for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const pu32x4_t*)(k_rd + ks * 32);
+      __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);   // DS reads
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        s_acc[0] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], s_acc[0]);
+        kf[ks] = *(const pu32x4_t*)(k_rd + 32 * RSK + ks * 32);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        s_acc[1] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], s_acc[1]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
       // ---- softmax (log2 domain) -------------------------------------------------------------------
       // register r of block kb <-> key key_base + 32kb + (r&3) + 8(r>>2) + 4half
@@ -320,19 +336,34 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
       m_run = m_new;
       // ---- O^T = alpha * O^T + V^T . P^T -----------------------------------------------------------
       const bool rescale = !__all(alpha == 1.0f);                 // exact: skipped only when no row's max moved
+      if (rescale) {
 #pragma unroll
-      for (int b = 0; b < DBLK; ++b) {
-        if (rescale) {
+        for (int b = 0; b < DBLK; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
-        }
+      }
+      // transposed V reads run one 32-wide output block ahead of the MFMAs that consume them
+      ps16x4_t vt[2][8];
+      auto read_v_block = [&](int b, ps16x4_t (&dst)[8]) {
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) {
           const char* va = v_rd + sk * 16 * RSV + b * 64;
-          const ps16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va));
-          const ps16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va + 8 * RSV));
+          dst[2 * sk] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va));
+          dst[2 * sk + 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va + 8 * RSV));
+        }
+      };
+      read_v_block(0, vt[0]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int b = 0; b < DBLK; ++b) {
+        if (b + 1 < DBLK) read_v_block(b + 1, vt[(b + 1) & 1]);
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk) {
+          const ps16x4_t v0 = vt[b & 1][2 * sk], v1 = vt[b & 1][2 * sk + 1];
           const ps16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           o_acc[b] = pmma<T>::run(vf, pf[sk], o_acc[b]);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (b + 1 < DBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
       }
     }
@@ -369,6 +400,8 @@ bool prefill_supported(const mi355_attn_params& p) {
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
   if (p.k_stride_slot >= (1 << 24) || p.v_stride_slot >= (1 << 24)) return false;      // 32-bit in-page offsets
+  if (p.k_stride_page >= (1LL << 31) || p.v_stride_page >= (1LL << 31) || p.k_stride_page < 0 || p.v_stride_page < 0 ||
+      p.k_stride_slot < 0 || p.v_stride_slot < 0) return false;
   const int G = p.num_q_heads / p.num_kv_heads;
   if (G > kBlockM) return false;
   if (!paligned16(p.q) || !paligned16(p.k_cache) || !paligned16(p.v_cache)) return false;
@@ -387,6 +420,8 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = kBlockM / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
+  a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
+  a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;  // static upper bound (:886-889,:935-943)
   constexpr size_t lds = 2 * (size_t)kTileN * ((D * 2 + 16) + (D * 2 + 64));
   static bool attr_set = false;   // >64 KiB of dynamic LDS needs an opt-in, once per kernel
@@ -396,7 +431,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
     if (rc0 != MI355_OK) return rc0;
     attr_set = true;
   }
-  hipLaunchKernelGGL((prefill_mfma_kernel<T, D, FEAT>), dim3(qblocks, p.num_kv_heads), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((prefill_mfma_kernel<T, D, FEAT>), dim3(qblocks * p.num_kv_heads), dim3(256), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_mfma_kernel launch");
   if (rc == MI355_OK) set_kernel_name(FEAT ? "prefill_mfma_feat" : "prefill_mfma");
   return rc;
