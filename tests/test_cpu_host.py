@@ -1,0 +1,215 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/mi355_attn.h declares, the
+ctypes mirrors match the C structs, host-side argument checks behave like the reference's, the vLLM
+plugin surface has the reference's contract, and there is no silent CPU fallback."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi355_attn.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from mi355_attn import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    text = open(HEADER).read()
+    declared = re.findall(r"MI355_API\s+[\w\s\*]+?\b(mi355_\w+)\s*\(", text)
+    assert set(declared) == set(lib.EXPORTS), (declared, lib.EXPORTS)
+    handle = lib.load()
+    for name in declared:
+        assert getattr(handle, name) is not None
+    assert handle.mi355_attn_version() == int(re.search(r"#define MI355_ATTN_VERSION (\d+)", text).group(1))
+    assert lib.last_error() == ""
+
+
+def test_ctypes_structs_match_the_c_header(lib, tmp_path):
+    """Compile a tiny C program against include/mi355_attn.h and compare sizeof/offsetof with ctypes."""
+    fields_a = [f[0] for f in lib.AttnParams._fields_]
+    fields_c = [f[0] for f in lib.CacheParams._fields_]
+    src = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void){",
+           'printf("A %zu\\n", sizeof(mi355_attn_params));', 'printf("C %zu\\n", sizeof(mi355_cache_params));']
+    src += [f'printf("A.{f} %zu\\n", offsetof(mi355_attn_params, {f}));' for f in fields_a]
+    src += [f'printf("C.{f} %zu\\n", offsetof(mi355_cache_params, {f}));' for f in fields_c]
+    src += ["return 0;}"]
+    cfile = tmp_path / "layout.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(cfile)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(out["A"]) == C.sizeof(lib.AttnParams)
+    assert int(out["C"]) == C.sizeof(lib.CacheParams)
+    for f in fields_a:
+        assert int(out[f"A.{f}"]) == getattr(lib.AttnParams, f).offset, f
+    for f in fields_c:
+        assert int(out[f"C.{f}"]) == getattr(lib.CacheParams, f).offset, f
+
+
+def test_argument_validation_without_a_gpu(lib):
+    h = lib.load()
+    assert h.mi355_unified_attention(None, None, 0, None) == lib.MI355_ERR_BAD_ARG
+    assert "NULL" in lib.last_error()
+    p = lib.AttnParams()
+    assert h.mi355_unified_attention(C.byref(p), None, 0, None) == lib.MI355_OK        # zero tokens: nothing to do
+    p.num_tokens, p.num_seqs = 4, 1
+    assert h.mi355_unified_attention(C.byref(p), None, 0, None) == lib.MI355_ERR_BAD_ARG  # NULL tensors
+    with pytest.raises(ValueError):
+        lib.check(lib.MI355_ERR_BAD_ARG, "x")
+    with pytest.raises(NotImplementedError):
+        lib.check(lib.MI355_ERR_UNSUPPORTED, "x")
+    with pytest.raises(RuntimeError):
+        lib.check(lib.MI355_ERR_HIP, "x")
+    c = lib.CacheParams()
+    assert h.mi355_reshape_and_cache_flash(None, None) == lib.MI355_ERR_BAD_ARG
+    assert h.mi355_reshape_and_cache_flash(C.byref(c), None) == lib.MI355_OK             # zero tokens
+
+
+def test_workspace_bytes_is_host_arithmetic(lib):
+    """Sized from host-known bounds only (capture-stable) and enough for T*Hq*splits*(D+2) floats."""
+    h = lib.load()
+    buf = np.zeros(64, dtype=np.uint8)  # any non-NULL 16-byte aligned pointers: nothing is dereferenced
+    addr = (buf.ctypes.data + 15) & ~15
+    p = lib.AttnParams()
+    for f in ("q", "out", "k_cache", "v_cache", "block_table", "cu_seqlens_q", "seqused_k"):
+        setattr(p, f, addr)
+    p.q_dtype = p.kv_dtype = lib.BF16
+    p.num_tokens, p.num_seqs, p.num_q_heads, p.num_kv_heads, p.head_size, p.page_size = 64, 64, 32, 8, 128, 16
+    p.max_seqlen_q, p.max_seqlen_k = 1, 8192
+    p.q_stride_token, p.q_stride_head, p.out_stride_token, p.out_stride_head = 4096, 128, 4096, 128
+    p.k_stride_page, p.k_stride_slot, p.k_stride_head, p.k_stride_d, p.k_x = 16384, 1024, 128, 1, 128
+    p.v_stride_page, p.v_stride_slot, p.v_stride_head, p.v_stride_d = 16384, 1024, 128, 1
+    p.block_table_stride = 512
+    n = h.mi355_attn_workspace_bytes(C.byref(p))
+    assert n > 0 and n % (64 * 32 * (128 + 2) * 4) == 0
+    splits = n // (64 * 32 * (128 + 2) * 4)
+    assert 1 < splits <= 64
+    p.max_seqlen_k = 16
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0          # single tile: no split, no scratch
+    p.q_dtype = p.kv_dtype = lib.F32
+    p.max_seqlen_k = 8192
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0          # generic kernel needs none
+
+
+def test_no_cpu_fallback():
+    from mi355_attn.kernels import reshape_and_cache_flash, unified_attention
+
+    q = torch.zeros(2, 4, 64)
+    kc = torch.zeros(3, 16, 2, 64)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        unified_attention(q=q, k=kc, v=kc, out=q.clone(), cu_seqlens_q=torch.tensor([0, 2], dtype=torch.int32), max_seqlen_q=2,
+                          seqused_k=torch.tensor([2], dtype=torch.int32), max_seqlen_k=2, avg_seqlen_q=2, avg_seqlen_k=2, softmax_scale=1.0,
+                          causal=True, window_size=(-1, -1), block_table=torch.zeros(1, 1, dtype=torch.int32), softcap=0, q_descale=None,
+                          k_descale=None, v_descale=None)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        reshape_and_cache_flash(torch.zeros(2, 2, 64), torch.zeros(2, 2, 64), kc, kc.clone(), torch.tensor([0, 1]), "auto", None, None)
+    # the reference's pre-launch asserts (triton_unified_attention.py:861-867)
+    with pytest.raises(AssertionError, match="causal"):
+        unified_attention(q, kc, kc, q, None, 1, None, 1, 1, 1, 1.0, False, (-1, -1), None, 0, None, None, None)
+    with pytest.raises(AssertionError, match="Q scales"):
+        unified_attention(q, kc, kc, q, None, 1, None, 1, 1, 1, 1.0, True, (-1, -1), None, 0, torch.ones(1), None, None)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing shipped may import, call or link it."""
+    pkg = os.path.join(ROOT, "vllm-triton-backend_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|paged_attention_oracle|cpu_sdpa_baseline|oracle/_ref", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f"{f} references the oracle"
+
+
+def test_plugin_surface_matches_the_reference_contract():
+    from mi355_attn.backend import attn, platform, register
+
+    assert register() == "mi355_attn.backend.platform.MI355Platform"
+    B = attn.MI355AttentionBackend
+    assert B.get_name() == "TRITON_ATTN_VLLM_V1" and B.accept_output_buffer is True
+    assert B.get_supported_head_sizes() == [32, 64, 96, 128, 160, 192, 224, 256]
+    assert B.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16, 8, 128)
+    with pytest.raises(ValueError, match="multiple of 16"):
+        B.get_kv_cache_shape(10, 24, 8, 128)
+    with pytest.raises(ValueError, match="Head size 80 is not supported"):
+        B.validate_head_size(80)
+    assert B.use_cascade_attention() is False
+    assert B.get_impl_cls() is attn.MI355AttentionImpl and B.get_builder_cls() is attn.MI355AttentionMetadataBuilder
+    assert B.get_metadata_cls() is attn.MI355AttentionMetadata
+    assert attn.MI355AttentionMetadataBuilder.full_cudagraph_supported is True
+
+    Impl = attn.MI355AttentionImpl
+    with pytest.raises(ValueError, match="block-sparse"):
+        Impl(8, 128, 0.1, 2, None, None, "auto", blocksparse_params={})
+    with pytest.raises(NotImplementedError, match="Encoder"):
+        Impl(8, 128, 0.1, 2, None, None, "auto", attn_type=attn.AttentionType.ENCODER)
+    with pytest.raises(ValueError, match="Head size"):
+        Impl(8, 100, 0.1, 2, None, None, "auto")
+    impl = Impl(8, 128, 0.1, 2, [0.5] * 8, 128, "auto", logits_soft_cap=None)
+    assert impl.sliding_window == (127, 0) and impl.logits_soft_cap == 0 and impl.num_queries_per_kv == 4
+    assert Impl(8, 128, 0.1, 2, None, None, "auto").sliding_window == (-1, -1)
+    out = torch.zeros(3, 8, 128)
+    with pytest.raises(AssertionError, match="Output tensor"):
+        impl.forward(None, out, None, None, None, None, output=None)
+    with pytest.raises(NotImplementedError, match="output quantization"):
+        impl.forward(None, out, None, None, None, None, output=out, output_scale=torch.ones(1))
+    assert impl.forward(None, out, None, None, None, None, output=out) is out      # profiling run: untouched
+
+    # platform hook: V1 only, falls through to vLLM's choice when the GPU is not a gfx950
+    platform.envs.VLLM_USE_V1 = False
+    with pytest.raises(RuntimeError, match="only supports vLLM V1"):
+        platform.MI355Platform.get_attn_backend_cls(None, 128, torch.bfloat16, "auto", 16, False, False)
+    platform.envs.VLLM_USE_V1 = True
+
+
+def test_metadata_builder_mirrors_the_reference():
+    from mi355_attn.backend import attn
+
+    class BT:
+        def __init__(self):
+            self.dev = torch.arange(12, dtype=torch.int32).view(3, 4)
+            self.slot_mapping = torch.full((8,), 7, dtype=torch.int64)
+            self.slot_mapping_cpu = torch.arange(100, 108, dtype=torch.int64)
+
+        def get_device_tensor(self):
+            return self.dev
+
+    runner = types.SimpleNamespace(seq_lens_np=np.array([10, 3, 7, 99]), query_start_loc_np=np.array([0, 4, 5, 6, 0]), device="cpu",
+                                   attention_chunk_size=None)
+    common = types.SimpleNamespace(num_reqs=3, num_actual_tokens=6, max_query_len=4, query_start_loc=torch.tensor([0, 4, 5, 6], dtype=torch.int32),
+                                   seq_lens=torch.tensor([10, 3, 7], dtype=torch.int32))
+    bt = BT()
+    b = attn.MI355AttentionMetadataBuilder(runner, types.SimpleNamespace(block_size=16), bt)
+    m = b.build(0, common)
+    assert (m.num_actual_tokens, m.max_query_len, m.max_seq_len, m.avg_seq_len, m.avg_query_len) == (6, 4, 10, 6, 2)
+    assert m.slot_mapping.tolist() == [100, 101, 102, 103, 104, 105]
+    assert bt.slot_mapping.tolist()[6:] == [-1, -1]                       # padding slots are skipped by the cache write
+    assert m.block_table.shape == (3, 4) and m.use_cascade is False and m.local_attn_metadata is None
+    assert b.can_run_in_cudagraph(common) is True
+    cap = b.build_for_cudagraph_capture(common)
+    assert cap.seq_lens.tolist() == [1, 1, 1]
+
+
+def test_sequence_assignment_is_balanced_and_deterministic():
+    from mi355_attn import parallel
+
+    qlens = [1] * 32 + [2048] * 16 + [4096] * 16
+    kvs = [4096] * 64
+    owned = parallel.assign_sequences(qlens, kvs, 8)
+    assert sorted(i for o in owned for i in o) == list(range(64))
+    loads = [sum(parallel.attention_cost(qlens[i], kvs[i]) for i in o) for o in owned]
+    assert max(loads) / (sum(loads) / 8) < 1.05
+    assert owned == parallel.assign_sequences(qlens, kvs, 8)

@@ -1,0 +1,132 @@
+"""-m gpu: legacy op signatures (v0 cache layout) against the reference-kernel goldens, and the
+vLLM-facing Impl.forward (cache write + attention) against the oracle."""
+
+import types
+
+import pytest
+import torch
+
+import golden_io
+from oracle import paged_attention_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", golden_io.names("legacy_paged"))
+def test_legacy_paged_attention_golden(name):
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels.legacy import paged_attention_2d, paged_attention_3d
+
+    meta, t = golden_io.load(name)
+    d = gpu_util.to_dev(t)
+    S, Hq, D = t["q"].shape
+    Hk = t["v_cache_v0"].shape[1]
+    out = torch.full_like(d["q"], float("nan"))
+    one = torch.ones(1, dtype=torch.float32, device=gpu_util.DEV)
+    fn = paged_attention_3d if meta["segments"] else paged_attention_2d
+    fn(out, d["q"], d["k_cache_v0"], d["v_cache_v0"], meta["scale"], one, one, "auto", d["block_table"], d["seqused_k"],
+       d.get("alibi_slopes"), t["v_cache_v0"].shape[3], S, Hq, Hq // Hk, D)
+    torch.cuda.synchronize()
+    atol, rtol = golden_io.tolerance(t["q"].dtype)
+    torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol)
+    assert _lib.last_kernel() == "generic"
+
+
+@pytest.mark.parametrize("name", golden_io.names("legacy_ctxfwd"))
+def test_legacy_context_attention_fwd_golden(name):
+    import gpu_util
+    from mi355_attn.kernels.legacy import chunked_prefill_paged_decode, context_attention_fwd
+
+    meta, t = golden_io.load(name)
+    d = gpu_util.to_dev(t)
+    one = torch.ones(1, dtype=torch.float32, device=gpu_util.DEV)
+    out = torch.zeros_like(d["q"])
+    context_attention_fwd(d["q"], d["k_new"], d["v_new"], out, "auto", d["k_cache_v0"], d["v_cache_v0"], d["block_table"], d["cu_seqlens_q"],
+                          d["seqused_k"], max(meta["query_lens"]), one, one, sliding_window=meta["window"] or None)
+    torch.cuda.synchronize()
+    atol, rtol = golden_io.tolerance(t["q"].dtype)
+    torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol)   # decode rows stay zero, as in the reference
+    # chunked_prefill_paged_decode = the same prefill rows + the decode rows from the cache. The cache
+    # must then hold the new tokens too: write them with our cache op into a flash-layout copy.
+    kf, vf = orc.v0_to_flash(t["k_cache_v0"], t["v_cache_v0"])
+    cu = t["cu_seqlens_q"].tolist()
+    slots = []
+    for i, (ql, cl) in enumerate(zip(meta["query_lens"], meta["ctx_lens"])):
+        for j in range(cl, cl + ql):
+            slots.append(int(t["block_table"][i, j // 16]) * 16 + j % 16)
+    orc.reshape_and_cache_flash_oracle(t["k_new"], t["v_new"], kf, vf, torch.tensor(slots))
+    ref = orc.unified_attention_oracle(t["q"], kf, vf, t["cu_seqlens_q"], t["seqused_k"], t["block_table"], meta["scale"],
+                                       sliding_window=meta["window"])
+    x = t["k_cache_v0"].shape[4]
+    nb, page, hk, dd = kf.shape
+    k0 = kf.view(nb, page, hk, dd // x, x).permute(0, 2, 3, 1, 4).contiguous().to(gpu_util.DEV)
+    v0 = vf.permute(0, 2, 3, 1).contiguous().to(gpu_util.DEV)
+    out2 = torch.full_like(d["q"], float("nan"))
+    chunked_prefill_paged_decode(d["q"], d["k_new"], d["v_new"], out2, "auto", k0, v0, d["block_table"], d["cu_seqlens_q"], d["seqused_k"],
+                                 max(meta["query_lens"]), one, one, None, meta["window"] or None, meta["scale"])
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out2.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("kv_cache_dtype,dtype", [("auto", torch.bfloat16), ("auto", torch.float16), ("fp8", torch.bfloat16), ("fp8_e5m2", torch.float16)])
+def test_impl_forward_writes_cache_then_attends(kv_cache_dtype, dtype):
+    """What vLLM calls per layer: forward(layer, q, k, v, kv_cache, metadata, output)."""
+    import gpu_util
+    from mi355_attn.backend import attn
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page = 8, 2, 128, 16
+    query_lens, ctx_lens = [5, 1, 40, 1], [0, 44, 30, 299]
+    kv_lens = [a + b for a, b in zip(query_lens, ctx_lens)]
+    inp = orc.make_paged_inputs(31, query_lens, kv_lens, Hq, Hk, D, page, dtype)
+    T = sum(query_lens)
+    g = torch.Generator().manual_seed(32)
+    k_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype)
+    v_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype)
+    slots = []
+    for i, (ql, cl) in enumerate(zip(query_lens, ctx_lens)):
+        for j in range(cl, cl + ql):
+            slots.append(int(inp["block_table"][i, j // page]) * page + j % page)
+    pad = 3  # padded tokens at the end of the step (full-graph mode): slot -1
+    slot_mapping = torch.tensor(slots + [-1] * pad, dtype=torch.int64)
+    fp8 = kv_cache_dtype.startswith("fp8")
+    cache_dtype = {"auto": dtype, "fp8": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}[kv_cache_dtype]
+    k_scale, v_scale = (0.5, 0.25) if fp8 else (1.0, 1.0)
+    # reference state: context already in the cache (quantised for fp8), then the oracle's cache write
+    kc = torch.zeros(inp["k_cache"].shape, dtype=cache_dtype)
+    vc = torch.zeros_like(kc)
+    if fp8:
+        kc.copy_((inp["k_cache"].float() / k_scale).to(cache_dtype))
+        vc.copy_((inp["v_cache"].float() / v_scale).to(cache_dtype))
+    else:
+        kc.copy_(inp["k_cache"]); vc.copy_(inp["v_cache"])
+    kv_cache = torch.stack([kc, vc]).to(dev)
+    if fp8:
+        kv_cache = kv_cache.view(torch.uint8)           # vLLM hands fp8 caches over as uint8
+    orc.reshape_and_cache_flash_oracle(k_new, v_new, kc, vc, slot_mapping[:T], k_scale=k_scale, v_scale=v_scale)
+    ref = orc.unified_attention_oracle(inp["q"], kc, vc, inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"],
+                                       k_scale=k_scale, v_scale=v_scale)
+
+    impl = attn.MI355AttentionImpl(Hq, D, inp["scale"], Hk, None, None, kv_cache_dtype)
+    layer = types.SimpleNamespace(_k_scale=torch.tensor(k_scale, device=dev), _v_scale=torch.tensor(v_scale, device=dev),
+                                  _q_scale=torch.tensor(1.0, device=dev))
+    md = attn.MI355AttentionMetadata(
+        num_actual_tokens=T, max_query_len=max(query_lens), avg_query_len=T // 4, avg_seq_len=sum(kv_lens) // 4,
+        query_start_loc=inp["cu_seqlens_q"].to(dev), max_seq_len=max(kv_lens), seq_lens=inp["seqused_k"].to(dev),
+        block_table=inp["block_table"].to(dev), slot_mapping=slot_mapping.to(dev), use_cascade=False, common_prefix_len=0,
+        cu_prefix_query_lens=None, prefix_kv_lens=None, suffix_kv_lens=None)
+    q_pad = torch.zeros(T + pad, Hq, D, dtype=dtype, device=dev); q_pad[:T] = inp["q"].to(dev)
+    k_pad = torch.zeros(T + pad, Hk, D, dtype=dtype, device=dev); k_pad[:T] = k_new.to(dev)
+    v_pad = torch.zeros(T + pad, Hk, D, dtype=dtype, device=dev); v_pad[:T] = v_new.to(dev)
+    output = torch.full((T + pad, Hq * D), float("nan"), dtype=dtype, device=dev)
+    ret = impl.forward(layer, q_pad, k_pad, v_pad, kv_cache, md, output=output)
+    torch.cuda.synchronize()
+    assert ret is output
+    atol, rtol = golden_io.tolerance(dtype, cache_dtype if fp8 else None)
+    torch.testing.assert_close(output[:T].view(T, Hq, D).float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    assert torch.isnan(output[T:]).all()                                # padded rows untouched
+    got_k = kv_cache[0].view(cache_dtype) if fp8 else kv_cache[0]
+    assert torch.equal(got_k.cpu().view(torch.uint8), kc.view(torch.uint8))   # cache write is bit-exact (incl. fp8 quantisation)
+    got_v = kv_cache[1].view(cache_dtype) if fp8 else kv_cache[1]
+    assert torch.equal(got_v.cpu().view(torch.uint8), vc.view(torch.uint8))

@@ -1,0 +1,338 @@
+"""vLLM V1 attention backend on libmi355_attn.so.
+
+Mirrors the reference's TritonAttentionBackend / TritonAttentionImpl / TritonAttentionMetadataBuilder /
+TritonAttentionMetadata (LIB/backend/triton_attn.py:60-470): same static contract, same constructor
+and forward signatures, same error behaviour. forward() issues exactly two C-ABI calls on the current
+stream: the paged-cache write and the unified attention.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, ClassVar, Optional
+
+import torch
+
+from .. import _lib
+from ..kernels import reshape_and_cache_flash, unified_attention
+from ._vllm_shim import (
+    AttentionBackend,
+    AttentionImpl,
+    AttentionMetadataBuilder,
+    AttentionType,
+    CommonAttentionMetadata,
+    init_logger,
+    make_local_attention_virtual_batches,
+)
+
+logger = init_logger(__name__)
+_lib.load()  # fail at import, not at the first forward, if the HIP library is missing
+
+
+@dataclass
+class MI355AttentionMetadata:
+    """Per-step metadata (reference: TritonAttentionMetadata, triton_attn.py:60-103)."""
+
+    num_actual_tokens: int  # Number of tokens excluding padding.
+    max_query_len: int
+    avg_query_len: int
+    avg_seq_len: int
+    query_start_loc: torch.Tensor
+    max_seq_len: int
+    seq_lens: torch.Tensor
+    block_table: torch.Tensor
+    slot_mapping: torch.Tensor
+
+    # cascade attention is never used (use_cascade_attention -> False), kept for interface parity
+    use_cascade: bool
+    common_prefix_len: int
+    cu_prefix_query_lens: Optional[torch.Tensor]
+    prefix_kv_lens: Optional[torch.Tensor]
+    suffix_kv_lens: Optional[torch.Tensor]
+
+    scheduler_metadata: Optional[torch.Tensor] = None
+    prefix_scheduler_metadata: Optional[torch.Tensor] = None
+
+    @dataclass
+    class LocalAttentionMetadata:
+        local_query_start_loc: torch.Tensor
+        local_seqused_k: torch.Tensor
+        local_block_table: torch.Tensor
+        local_max_query_len: int
+        local_max_seq_len: int
+        local_avg_query_len: int
+        local_avg_seq_len: int
+        local_scheduler_metadata: Optional[torch.Tensor]
+
+    local_attn_metadata: Optional[LocalAttentionMetadata] = None
+
+
+class MI355AttentionMetadataBuilder(AttentionMetadataBuilder[MI355AttentionMetadata]):
+    """Host-side, once per scheduler step (reference: triton_attn.py:106-233)."""
+
+    full_cudagraph_supported: ClassVar[bool] = True
+
+    def __init__(self, runner, kv_cache_spec, block_table):
+        self.runner = runner
+        self.block_size = kv_cache_spec.block_size
+        self.kv_cache_spec = kv_cache_spec
+        self.block_table = block_table
+
+    def build_for_cudagraph_capture(self, common_attn_metadata: CommonAttentionMetadata) -> MI355AttentionMetadata:
+        attn_metadata = self.build(0, common_attn_metadata)
+        # capture with seq_lens = 1 so that the captured kernels do minimal work (triton_attn.py:124-127);
+        # the kernels clamp negative context lengths, so this is harmless for query_len > 1 rows
+        attn_metadata.seq_lens.fill_(1)
+        return attn_metadata
+
+    def build(self, common_prefix_len: int, common_attn_metadata: CommonAttentionMetadata) -> MI355AttentionMetadata:
+        num_reqs = common_attn_metadata.num_reqs
+        num_actual_tokens = common_attn_metadata.num_actual_tokens
+        max_query_len = common_attn_metadata.max_query_len
+
+        max_seq_len = int(self.runner.seq_lens_np[:num_reqs].max())
+        query_start_loc = common_attn_metadata.query_start_loc
+        seq_lens = common_attn_metadata.seq_lens
+        block_table = self.block_table
+        block_table_tensor = block_table.get_device_tensor()[:num_reqs]
+
+        avg_seq_len = int(self.runner.seq_lens_np[:num_reqs].mean())
+        avg_query_len = int(self.runner.query_start_loc_np[num_reqs] / num_reqs)
+
+        block_table.slot_mapping[:num_actual_tokens].copy_(block_table.slot_mapping_cpu[:num_actual_tokens], non_blocking=True)
+        # padding slots = -1: skipped by reshape_and_cache_flash (needed in full-graph mode, :149-151)
+        block_table.slot_mapping[num_actual_tokens:].fill_(-1)
+        slot_mapping = block_table.slot_mapping[:num_actual_tokens]
+
+        local_attn_metadata = None
+        if getattr(self.runner, "attention_chunk_size", None) is not None:
+            if make_local_attention_virtual_batches is None:
+                raise NotImplementedError("local (chunked) attention needs vLLM's make_local_attention_virtual_batches")
+            seqlens_q_local_np, virt_q_cu_seqlens_np, virt_k_seqlens_np, virt_block_table_tensor = make_local_attention_virtual_batches(
+                self.runner.attention_chunk_size,
+                self.runner.query_start_loc_np[: num_reqs + 1],
+                self.runner.seq_lens_np[:num_reqs],
+                block_table_tensor,
+                self.block_size,
+            )
+            n_virt = len(virt_k_seqlens_np)
+            local_attn_metadata = MI355AttentionMetadata.LocalAttentionMetadata(
+                local_query_start_loc=torch.from_numpy(virt_q_cu_seqlens_np).to(self.runner.device, non_blocking=True),
+                local_seqused_k=torch.from_numpy(virt_k_seqlens_np).to(self.runner.device, non_blocking=True),
+                local_block_table=virt_block_table_tensor,
+                local_max_query_len=int(seqlens_q_local_np.max()),
+                local_max_seq_len=int(virt_k_seqlens_np.max()),
+                local_avg_query_len=int(seqlens_q_local_np.sum() / max(n_virt, 1)),
+                local_avg_seq_len=int(virt_k_seqlens_np.sum() / max(n_virt, 1)),
+                local_scheduler_metadata=None,
+            )
+
+        use_cascade = common_prefix_len > 0
+        if use_cascade:
+            cu_prefix_query_lens = torch.tensor([0, num_actual_tokens], dtype=torch.int32, device=self.runner.device)
+            prefix_kv_lens = torch.tensor([common_prefix_len], dtype=torch.int32, device=self.runner.device)
+            suffix_kv_lens = torch.from_numpy(self.runner.seq_lens_np[:num_reqs] - common_prefix_len).to(self.runner.device)
+        else:
+            cu_prefix_query_lens = prefix_kv_lens = suffix_kv_lens = None
+
+        return MI355AttentionMetadata(
+            num_actual_tokens=num_actual_tokens,
+            max_query_len=max_query_len,
+            query_start_loc=query_start_loc,
+            max_seq_len=max_seq_len,
+            seq_lens=seq_lens,
+            block_table=block_table_tensor,
+            slot_mapping=slot_mapping,
+            use_cascade=use_cascade,
+            common_prefix_len=common_prefix_len,
+            cu_prefix_query_lens=cu_prefix_query_lens,
+            prefix_kv_lens=prefix_kv_lens,
+            suffix_kv_lens=suffix_kv_lens,
+            local_attn_metadata=local_attn_metadata,
+            prefix_scheduler_metadata=None,
+            avg_query_len=avg_query_len,
+            avg_seq_len=avg_seq_len,
+        )
+
+    def can_run_in_cudagraph(self, common_attn_metadata: CommonAttentionMetadata) -> bool:
+        return True  # static launch grids, caller-owned workspace, no host sync
+
+
+class MI355AttentionBackend(AttentionBackend):
+    """Static contract (reference: TritonAttentionBackend, triton_attn.py:236-285)."""
+
+    accept_output_buffer: bool = True
+
+    @classmethod
+    def get_supported_head_sizes(cls) -> list[int]:
+        return [32, 64, 96, 128, 160, 192, 224, 256]
+
+    @classmethod
+    def validate_head_size(cls, head_size: int) -> None:
+        supported_head_sizes = cls.get_supported_head_sizes()
+        if head_size not in supported_head_sizes:
+            attn_type = cls.__name__.removesuffix("Backend")
+            raise ValueError(
+                f"Head size {head_size} is not supported by {attn_type}. "
+                f"Supported head sizes are: {supported_head_sizes}. "
+                "Set VLLM_ATTENTION_BACKEND=FLEX_ATTENTION to use "
+                "FlexAttention backend which supports all head sizes."
+            )
+
+    @staticmethod
+    def get_name() -> str:
+        # the reference's name, so VLLM_ATTENTION_BACKEND=TRITON_ATTN_VLLM_V1 scripts keep working
+        return "TRITON_ATTN_VLLM_V1"
+
+    @staticmethod
+    def get_impl_cls() -> type["MI355AttentionImpl"]:
+        return MI355AttentionImpl
+
+    @staticmethod
+    def get_metadata_cls() -> type["MI355AttentionMetadata"]:
+        return MI355AttentionMetadata
+
+    @staticmethod
+    def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int, head_size: int) -> tuple[int, ...]:
+        if block_size % 16 != 0:
+            raise ValueError("Block size must be a multiple of 16.")
+        return (2, num_blocks, block_size, num_kv_heads, head_size)
+
+    @staticmethod
+    def use_cascade_attention(*args, **kwargs) -> bool:
+        return False
+
+    @staticmethod
+    def get_builder_cls() -> type["MI355AttentionMetadataBuilder"]:
+        return MI355AttentionMetadataBuilder
+
+
+class MI355AttentionImpl(AttentionImpl):
+    """Per-layer forward (reference: TritonAttentionImpl, triton_attn.py:288-470)."""
+
+    def __init__(
+        self,
+        num_heads: int,
+        head_size: int,
+        scale: float,
+        num_kv_heads: int,
+        alibi_slopes: Optional[list[float]],
+        sliding_window: Optional[int],
+        kv_cache_dtype: str,
+        blocksparse_params: Optional[dict[str, Any]] = None,
+        logits_soft_cap: Optional[float] = None,
+        attn_type: AttentionType = AttentionType.DECODER,
+        kv_sharing_target_layer_name: Optional[int] = None,
+        use_irope: bool = False,
+    ) -> None:
+        if blocksparse_params is not None:
+            raise ValueError("MI355Attention does not support block-sparse attention.")
+        self.num_heads = num_heads
+        self.head_size = head_size
+        self.scale = float(scale)
+        self.num_kv_heads = num_kv_heads
+        if alibi_slopes is not None:
+            alibi_slopes = torch.tensor(alibi_slopes, dtype=torch.float32)
+        self.alibi_slopes = alibi_slopes
+        self._alibi_dev: Optional[torch.Tensor] = None
+        if sliding_window is None:
+            self.sliding_window = (-1, -1)
+        else:
+            self.sliding_window = (sliding_window - 1, 0)
+        self.kv_cache_dtype = kv_cache_dtype
+        if logits_soft_cap is None:
+            logits_soft_cap = 0  # 0 means no soft cap
+        self.logits_soft_cap = logits_soft_cap
+        self.kv_sharing_target_layer_name = kv_sharing_target_layer_name
+        self.use_irope = use_irope
+        self.num_queries_per_kv = self.num_heads // self.num_kv_heads
+
+        MI355AttentionBackend.validate_head_size(head_size)
+
+        if attn_type != AttentionType.DECODER:
+            raise NotImplementedError(
+                "Encoder self-attention and encoder/decoder cross-attention are not implemented for MI355AttentionImpl"
+            )
+        # gfx950 speaks OCP fp8 (e4m3fn), unlike MI300's fnuz
+        self.fp8_dtype = torch.float8_e5m2 if kv_cache_dtype == "fp8_e5m2" else torch.float8_e4m3fn
+        logger.warning_once("Using mi355-attn attention PLUGIN V1 (hand-written gfx950 HIP kernels).")
+
+    def forward(
+        self,
+        layer: torch.nn.Module,
+        query: torch.Tensor,
+        key: torch.Tensor,
+        value: torch.Tensor,
+        kv_cache: torch.Tensor,
+        attn_metadata: MI355AttentionMetadata,
+        output: Optional[torch.Tensor] = None,
+        output_scale: Optional[torch.Tensor] = None,
+    ) -> torch.Tensor:
+        """query [T, Hq, D]; key/value [T, Hk, D]; kv_cache [2, num_blocks, block_size, Hk, D];
+        output [T, Hq, D] (or [T, Hq*D]) is written in place and returned."""
+        assert output is not None, "Output tensor must be provided."
+        if output_scale is not None:
+            raise NotImplementedError("fused output quantization is not yet supported for MI355AttentionImpl")
+        if attn_metadata is None:
+            return output  # profiling run
+        assert attn_metadata.use_cascade is False
+
+        num_actual_tokens = attn_metadata.num_actual_tokens
+        key_cache, value_cache = kv_cache.unbind(0)
+
+        if self.kv_sharing_target_layer_name is None:
+            reshape_and_cache_flash(key, value, key_cache, value_cache, attn_metadata.slot_mapping, self.kv_cache_dtype,
+                                    layer._k_scale, layer._v_scale)
+
+        if self.kv_cache_dtype.startswith("fp8"):
+            key_cache = key_cache.view(self.fp8_dtype)
+            value_cache = value_cache.view(self.fp8_dtype)
+            assert layer._q_scale == 1.0, "A non 1.0 q_scale is not currently supported."
+            # Q stays in its own dtype: K/V are dequantised in the kernel (the reference skips Q
+            # quantisation on ROCm as well, triton_attn.py:414-420)
+
+        use_local_attn = self.use_irope and attn_metadata.local_attn_metadata is not None
+        if use_local_attn:
+            lm = attn_metadata.local_attn_metadata
+            cu_seqlens_q, seqused_k = lm.local_query_start_loc, lm.local_seqused_k
+            max_seqlen_q, max_seqlen_k = lm.local_max_query_len, lm.local_max_seq_len
+            block_table = lm.local_block_table
+            avg_seqlen_q, avg_seqlen_k = lm.local_avg_query_len, lm.local_avg_seq_len
+        else:
+            cu_seqlens_q, seqused_k = attn_metadata.query_start_loc, attn_metadata.seq_lens
+            max_seqlen_q, max_seqlen_k = attn_metadata.max_query_len, attn_metadata.max_seq_len
+            block_table = attn_metadata.block_table
+            avg_seqlen_q, avg_seqlen_k = attn_metadata.avg_query_len, attn_metadata.avg_seq_len
+
+        if self.alibi_slopes is not None and (self._alibi_dev is None or self._alibi_dev.device != query.device):
+            self._alibi_dev = self.alibi_slopes.to(query.device)
+
+        q = query[:num_actual_tokens]
+        out = output[:num_actual_tokens]
+        if out.dim() == 2:
+            out = out.view(-1, self.num_heads, self.head_size)
+        if q.dim() == 2:
+            q = q.view(-1, self.num_heads, self.head_size)
+
+        unified_attention(
+            q=q,
+            k=key_cache,
+            v=value_cache,
+            out=out,
+            cu_seqlens_q=cu_seqlens_q,
+            max_seqlen_q=max_seqlen_q,
+            seqused_k=seqused_k,
+            max_seqlen_k=max_seqlen_k,
+            avg_seqlen_q=avg_seqlen_q,
+            avg_seqlen_k=avg_seqlen_k,
+            softmax_scale=self.scale,
+            causal=True,
+            alibi_slopes=self._alibi_dev,
+            window_size=self.sliding_window,
+            block_table=block_table,
+            softcap=self.logits_soft_cap,
+            q_descale=None,  # not supported
+            k_descale=layer._k_scale,  # the kernel reads element 0 (triton_unified_attention.py:438,:453)
+            v_descale=layer._v_scale,
+        )
+        return output

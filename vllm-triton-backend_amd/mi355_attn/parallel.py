@@ -1,0 +1,132 @@
+"""Multi-GPU partitioning of the attention hot path (one process per GPU).
+
+The path shards over independent units — (sequence, KV head) — with NO data-path collective
+(the reference's launch grid has exactly these axes and no cross-program traffic,
+LIB/kernels/triton_unified_attention.py:321-322,:567-569). Two partitionings:
+
+  * batch sharding (default): rank r owns a cost-balanced subset of the sequences, only those
+    sequences' KV pages (re-indexed into a compact local cache) and the matching slices of q/out;
+  * KV-head sharding (= what vLLM tensor parallelism hands the backend): rank r owns KV heads
+    [r*Hk/n, (r+1)*Hk/n) and their query heads; block table and lengths are replicated.
+
+The only collective is optional: gathering the per-rank outputs (torch.distributed all_gather over
+RCCL/xGMI with backend "nccl"; "gloo" in CPU tests) for verification or for a caller that wants the
+full tensor everywhere.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def attention_cost(query_len: int, kv_len: int) -> float:
+    """Relative cost of one sequence: q*ctx + q(q+1)/2 score entries."""
+    ctx = kv_len - query_len
+    return float(query_len * ctx + query_len * (query_len + 1) / 2)
+
+
+def assign_sequences(query_lens: Sequence[int], kv_lens: Sequence[int], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of sequences to ranks. Deterministic (ties by index),
+    identical on every rank, preserves the original order inside each rank."""
+    order = sorted(range(len(query_lens)), key=lambda i: (-attention_cost(query_lens[i], kv_lens[i]), i))
+    load = [0.0] * world_size
+    owned: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda x: (load[x], x))
+        owned[r].append(i)
+        load[r] += attention_cost(query_lens[i], kv_lens[i])
+    return [sorted(o) for o in owned]
+
+
+@dataclass
+class LocalBatch:
+    """What one rank needs to run its share with `unified_attention`."""
+
+    seq_ids: List[int]                # global sequence indices owned by this rank
+    token_index: torch.Tensor         # [T_local] global token index of every local query token
+    q: torch.Tensor                   # [T_local, Hq, D]
+    cu_seqlens_q: torch.Tensor        # [S_local + 1] int32
+    seqused_k: torch.Tensor           # [S_local] int32
+    block_table: torch.Tensor         # [S_local, max_pages] int32, indices into the LOCAL caches
+    k_cache: torch.Tensor             # [local_pages, page, Hk, D]
+    v_cache: torch.Tensor
+    max_seqlen_q: int
+    max_seqlen_k: int
+
+
+def shard_batch(rank: int, world_size: int, q, k_cache, v_cache, cu_seqlens_q, seqused_k, block_table) -> LocalBatch:
+    """Batch sharding: slice out rank `rank`'s sequences and compact their KV pages."""
+    cu = cu_seqlens_q.tolist()
+    kv = seqused_k.tolist()
+    qlens = [cu[i + 1] - cu[i] for i in range(len(kv))]
+    mine = assign_sequences(qlens, kv, world_size)[rank]
+    page = k_cache.shape[1]
+    tok, pages, local_bt = [], [], []
+    max_pages = 1
+    for i in mine:
+        tok.append(torch.arange(cu[i], cu[i + 1]))
+        n = (kv[i] + page - 1) // page
+        max_pages = max(max_pages, n)
+        local_bt.append((len(pages), n))
+        pages.extend(block_table[i, :n].tolist())
+    token_index = torch.cat(tok) if tok else torch.zeros(0, dtype=torch.long)
+    bt = torch.zeros(len(mine), max_pages, dtype=torch.int32)
+    for row, (start, n) in enumerate(local_bt):
+        bt[row, :n] = torch.arange(start, start + n, dtype=torch.int32)
+    page_idx = torch.tensor(pages, dtype=torch.long, device=k_cache.device)
+    lq = [qlens[i] for i in mine]
+    cu_local = torch.zeros(len(mine) + 1, dtype=torch.int32)
+    if mine:
+        cu_local[1:] = torch.cumsum(torch.tensor(lq, dtype=torch.int32), 0)
+    dev = q.device
+    return LocalBatch(
+        seq_ids=mine,
+        token_index=token_index,
+        q=q[token_index.to(dev)],
+        cu_seqlens_q=cu_local.to(dev),
+        seqused_k=torch.tensor([kv[i] for i in mine], dtype=torch.int32, device=dev),
+        block_table=bt.to(dev),
+        k_cache=k_cache[page_idx] if len(pages) else k_cache[:0],
+        v_cache=v_cache[page_idx] if len(pages) else v_cache[:0],
+        max_seqlen_q=max(lq) if lq else 0,
+        max_seqlen_k=max((kv[i] for i in mine), default=0),
+    )
+
+
+def shard_kv_heads(rank: int, world_size: int, q, k_cache, v_cache):
+    """KV-head sharding (tensor-parallel layout): returns this rank's views (q_r, k_cache_r, v_cache_r)
+    and the query-head slice it owns."""
+    Hq, Hk = q.shape[1], k_cache.shape[2]
+    if Hk % world_size != 0:
+        raise ValueError(f"num_kv_heads {Hk} is not divisible by world size {world_size}")
+    hk = Hk // world_size
+    g = Hq // Hk
+    ks = slice(rank * hk, (rank + 1) * hk)
+    qs = slice(rank * hk * g, (rank + 1) * hk * g)
+    return q[:, qs], k_cache[:, :, ks], v_cache[:, :, ks], qs
+
+
+def gather_outputs(local_out: torch.Tensor, local: LocalBatch, total_tokens: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Assemble the full [T, Hq, D] output on every rank from the batch-sharded pieces.
+    One all_gather of padded pieces + one of the token maps (RCCL over xGMI under backend "nccl")."""
+    world = dist.get_world_size(group)
+    counts = [torch.zeros(1, dtype=torch.int64, device=local_out.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([local_out.shape[0]], dtype=torch.int64, device=local_out.device), group=group)
+    counts = [int(c.item()) for c in counts]
+    t_max = max(max(counts), 1)
+    pad_out = torch.zeros((t_max,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device)
+    pad_out[: local_out.shape[0]] = local_out
+    pad_idx = torch.full((t_max,), -1, dtype=torch.int64, device=local_out.device)
+    pad_idx[: local_out.shape[0]] = local.token_index.to(local_out.device)
+    outs = [torch.empty_like(pad_out) for _ in range(world)]
+    idxs = [torch.empty_like(pad_idx) for _ in range(world)]
+    dist.all_gather(outs, pad_out, group=group)
+    dist.all_gather(idxs, pad_idx, group=group)
+    full = torch.zeros((total_tokens,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device)
+    for o, ix, n in zip(outs, idxs, counts):
+        full[ix[:n]] = o[:n]
+    return full
