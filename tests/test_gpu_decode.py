@@ -145,3 +145,63 @@ def test_decode_c3_full_size_properties():
     d3["v_cache"] = torch.full_like(d["v_cache"], 0.5)
     out3, _ = gpu_util.run_unified(d3, scale)
     torch.testing.assert_close(out3.float(), torch.full_like(out3, 0.5).float(), atol=4e-3, rtol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("hq,hk,d", [(32, 8, 128), (64, 8, 128), (8, 2, 64), (4, 1, 256)])
+def test_decode_fp8_kv_cache_on_the_mfma_path(dtype, kv_dtype, hq, hk, d):
+    """C5-style: fp8 KV cache, 16-bit queries, scalar k/v scales (LIB/kernels/triton_unified_attention.py:434-455)."""
+    kv_lens = [1, 15, 16, 17, 33, 700, 1023, 257]
+    inp = orc.make_paged_inputs(11, [1] * len(kv_lens), kv_lens, hq, hk, d, 16, dtype, kv_dtype=kv_dtype, kv_scale=0.5)
+    _check(inp, dtype, force=None, expect="decode_splitkv_fp8", kv_dtype=kv_dtype, kv_scale=0.5)
+
+
+def test_decode_fp8_page32_and_features():
+    kv_lens = [300, 17, 256, 1, 129]
+    inp = orc.make_paged_inputs(12, [1] * len(kv_lens), kv_lens, 8, 2, 128, 32, torch.float16, kv_dtype=torch.float8_e4m3fn, kv_scale=0.25)
+    alibi = torch.tensor([2.0 ** (-(i + 1)) for i in range(8)], dtype=torch.float32)
+    _check(inp, torch.float16, force=None, expect="decode", kv_dtype=torch.float8_e4m3fn, kv_scale=0.25)
+    _check(inp, torch.float16, force=None, window=50, softcap=25.0, alibi=alibi, expect="decode", kv_dtype=torch.float8_e4m3fn, kv_scale=0.25)
+
+
+@pytest.mark.parametrize("spike_key", [0, 5, 12, 21, 30, 37, 63, 100, 255])
+def test_decode_running_max_exchange_with_a_spiked_key(spike_key):
+    """One key scores ~+60 above the rest, placed so that it lands in each of the four lane groups
+    / both 16-key groups of a tile in turn: the running max must be exchanged across lane groups
+    (a wrong exchange overflows exp2 or loses the spike's weight)."""
+    import gpu_util
+
+    kv_len, Hq, Hk, D = 256, 8, 2, 128
+    inp = orc.make_paged_inputs(13, [1], [kv_len], Hq, Hk, D, 16, torch.bfloat16)
+    page, slot = int(inp["block_table"][0, spike_key // 16]), spike_key % 16
+    qn = inp["q"][0].float()                                       # [Hq, D]
+    for h in range(Hk):                                            # key = 6 * normalised mean query of its group
+        qm = qn[h * 4:(h + 1) * 4].mean(0)
+        inp["k_cache"][page, slot, h] = (qm / qm.norm() * 60.0).to(torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       1.0, mode="3d")
+    d = gpu_util.to_dev(inp)
+    for force in (None, 2):
+        out, kernel = gpu_util.run_unified(d, 1.0, force=force)
+        assert not torch.isnan(out).any() and not torch.isinf(out).any(), kernel
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2, msg=lambda m: f"[{kernel}] {m}")
+
+
+def test_mixed_batch_splits_into_prefill_and_decode_launches():
+    import gpu_util
+
+    query_lens = [1, 64, 1, 1, 200, 1, 33, 1]
+    kv_lens = [900, 64, 17, 2048, 333, 1, 100, 513]
+    inp = orc.make_paged_inputs(14, query_lens, kv_lens, 32, 8, 128, 16, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(d, inp["scale"])
+    assert kernel == "prefill_mfma+decode_splitkv"
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    # and the single-kernel 2D path gives the same answer
+    out2, kernel2 = gpu_util.run_unified(d, inp["scale"], force=2)
+    assert kernel2 == "prefill_mfma"
+    torch.testing.assert_close(out2.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--segments", type=int, nargs="*", default=[0])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--kvdtype", default="same", choices=["same", "fp8", "fp8_e5m2"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
@@ -32,8 +33,10 @@ def main():
     B, kv, page = args.batch, args.kv, args.page
     ppseq = (kv + page - 1) // page
     nb = int(B * ppseq * 1.25)
-    k = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(dt)
-    v = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+    kvdt = {"same": dt, "fp8": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}[args.kvdtype]
+    k = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(kvdt)
+    v = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(kvdt)
+    ksc = torch.ones(1, device=dev) if kvdt != dt else None
     q = (torch.rand(B, args.hq, args.d, device=dev) * 2 - 1).to(dt)
     bt = torch.randperm(nb, device=dev)[: B * ppseq].to(torch.int32).view(B, ppseq)
     cu = torch.arange(B + 1, dtype=torch.int32, device=dev)
@@ -41,7 +44,7 @@ def main():
     out = torch.empty_like(q)
     algo_bytes = B * kv * args.hk * args.d * 2 * k.element_size() + 2 * q.numel() * q.element_size() + bt.numel() * 4 + (2 * B + 1) * 4
     for seg in args.segments:
-        p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, 1, sl, kv, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, None, None, None, None,
+        p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, 1, sl, kv, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, None,
                                           num_segments=seg)
         for _ in range(3):
             ua_mod.launch(p, dev)

@@ -54,7 +54,7 @@ static int validate(const mi355_attn_params* p) {
 // AUTO policy. The reference picks 3D iff max_seqlen_q == 1 (:884). We do the same for the
 // split-KV decode kernel, send everything else the MFMA prefill kernel covers there, and the
 // remainder to the generic kernel.
-enum class Path { Generic, Decode, Prefill };
+enum class Path { Generic, Decode, Prefill, PrefillPlusDecode };
 
 static Path choose(const mi355_attn_params& p) {
   const int sel = p.kernel_select;
@@ -64,6 +64,10 @@ static Path choose(const mi355_attn_params& p) {
   if (sel == MI355_SELECT_3D) return dec_ok ? Path::Decode : Path::Generic;
   if (sel == MI355_SELECT_2D) return pre_ok ? Path::Prefill : Path::Generic;
   if (p.max_seqlen_q <= 1 && dec_ok) return Path::Decode;
+  // mixed batch: prefill rows on the MFMA Q-block kernel, query_len == 1 rows on the split-KV kernel
+  // (what the reference's legacy glue does with two kernels, chunked_prefill_paged_decode:28-117;
+  // its unified 2D kernel instead pads every decode row to a BLOCK_M-row Q block)
+  if (pre_ok && dec_ok && p.num_seqs > 1 && !p.skip_decodes && !p.only_decodes) return Path::PrefillPlusDecode;
   if (pre_ok) return Path::Prefill;
   if (dec_ok) return Path::Decode;
   return Path::Generic;
@@ -101,6 +105,15 @@ int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t 
     case Path::Prefill:
       rc = launch_prefill(*p, s);
       break;
+    case Path::PrefillPlusDecode: {
+      mi355_attn_params pp = *p, pd = *p;
+      pp.skip_decodes = 1;
+      pd.only_decodes = 1;
+      rc = launch_prefill(pp, s);
+      if (rc == MI355_OK) rc = launch_decode(pd, workspace, workspace_bytes, s);
+      if (rc == MI355_OK) set_kernel_name("prefill_mfma+decode_splitkv");
+      break;
+    }
     default:
       rc = launch_generic(*p, s);
       if (rc == MI355_OK) set_kernel_name("generic");

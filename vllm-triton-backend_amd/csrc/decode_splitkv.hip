@@ -7,10 +7,14 @@
 //
 // Work decomposition: one WAVE per (query token, KV head, KV split); no inter-wave communication,
 // no barriers. A wave walks its KV range in tiles of 32 keys (two 16-key groups; a group never
-// straddles a page because page_size % 16 == 0):
+// straddles a page because page_size is a power of two >= 16):
 //   * K and V of the NEXT tile are fetched HBM -> VGPR with row-shaped 16-byte loads (each load
-//     instruction covers whole 2*D-byte key rows, so every 128-byte line is fetched once) while the
-//     current tile is computed;
+//     instruction covers whole key rows, so every 128-byte line is fetched once) while the current
+//     tile is computed; the block-table entries of the tile after that are fetched through the
+//     scalar cache, so no dependent load sits in front of the stream;
+//   * an fp8 (e4m3fn / e5m2) cache is widened to the query's 16-bit type on the way into LDS
+//     (v_cvt_pk_f32_fp8 -> v_cvt_pk_{bf16,f16}_f32; exact, every fp8 value is representable) and the
+//     scalar k/v scales are folded into the softmax scale and the output normalisation;
 //   * rows are parked in wave-private LDS (row stride 2*D+32 bytes: conflict-free for both read
 //     kinds) and read back as MFMA operands: K with ds_read_b128, V with the transposing
 //     ds_read_b64_tr_b16;
@@ -24,6 +28,10 @@
 //     addressed to deliver exactly those keys.
 // Partials (m, l, un-normalised O) go to a caller-provided workspace and are merged by
 // reduce_splits_kernel; with a single split the wave normalises and stores the output itself.
+// In `only_decodes` mode the grid runs over SEQUENCES (one query token each), which is how a mixed
+// batch hands its decode rows to this kernel without paying for its prefill tokens.
+#include <algorithm>
+
 #include "common.h"
 
 namespace mi355 {
@@ -33,6 +41,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
@@ -41,11 +50,14 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 struct DecodeArgs {
   mi355_attn_params p;
-  float* ws_acc;   // [T*Hq*num_splits][D]   un-normalised partial outputs
-  float2* ws_ml;   // [T*Hq*num_splits]      (running max in log2 domain, partial sum)
+  float* ws_acc;   // [(token*Hq + hq)*num_splits + split][D]   un-normalised partial outputs
+  float2* ws_ml;   // same index: (running max in log2 domain, partial sum)
   int num_splits;
   int tiles_per_split;
   int group;       // G = Hq / Hk
+  int page_shift;  // log2(page_size)
+  int by_seq;      // 1: work items enumerate sequences (only_decodes), 0: query tokens
+  uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated on the host
 };
 
 template <typename T> struct mma;
@@ -53,20 +65,35 @@ template <> struct mma<bf16_t> {
   static __device__ __forceinline__ f32x4_t run(s16x8_t a, s16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
-  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return pack_bf16x2(lo, hi);
-  }
-  static __device__ __forceinline__ u32x2_t pack4(float a, float b, float c, float d) { return u32x2_t{pack2(a, b), pack2(c, d)}; }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
 };
 template <> struct mma<f16_t> {
   static __device__ __forceinline__ f32x4_t run(s16x8_t a, s16x8_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
-  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return pack_f16x2(lo, hi);
-  }
-  static __device__ __forceinline__ u32x2_t pack4(float a, float b, float c, float d) { return u32x2_t{pack2(a, b), pack2(c, d)}; }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
 };
+
+// 16 fp8 values (one 16-byte load) -> 16 values of the query's 16-bit type (two 16-byte LDS pieces)
+template <typename T, typename KVT>
+__device__ __forceinline__ void widen_fp8x16(u32x4_t in, u32x4_t& lo, u32x4_t& hi) {
+  uint32_t o[8];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    f32x2_t a, b;
+    if constexpr (__is_same(KVT, e4m3_t)) {
+      a = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], false);
+      b = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], true);
+    } else {
+      a = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], false);
+      b = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], true);
+    }
+    o[2 * w] = mma<T>::pack2(a[0], a[1]);
+    o[2 * w + 1] = mma<T>::pack2(b[0], b[1]);
+  }
+  lo = u32x4_t{o[0], o[1], o[2], o[3]};
+  hi = u32x4_t{o[4], o[5], o[6], o[7]};
+}
 
 // max / sum over the four lanes {g, g+16, g+32, g+48}
 __device__ __forceinline__ float max_over_lane_groups(float v) {
@@ -78,14 +105,50 @@ __device__ __forceinline__ float sum_over_lane_groups(float v) {
   return v + lane_xor16(v);
 }
 
-template <typename T, int D, int WAVES>
+// Shared by both kernels: which token a work unit is, and the key range it may see.
+struct RowInfo {
+  int token, seq, q_len, ctx_len, q_pos, n_keys, first_key;
+  bool valid;
+};
+__device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_seq, int unit) {
+  RowInfo r;
+  r.valid = false;
+  r.token = r.seq = r.q_len = r.ctx_len = r.q_pos = r.n_keys = r.first_key = 0;
+  if (by_seq) {
+    r.seq = unit;
+    if (unit >= p.num_seqs) return r;
+    r.token = p.cu_seqlens_q[unit];
+  } else {
+    r.token = unit;
+    if (unit >= p.num_tokens) return r;
+    r.seq = find_seq_by_token(p.cu_seqlens_q, p.num_seqs, unit);
+  }
+  const int q_start = p.cu_seqlens_q[r.seq];
+  r.q_len = p.cu_seqlens_q[r.seq + 1] - q_start;
+  if (by_seq && r.q_len != 1) return r;
+  if (p.skip_decodes && r.q_len == 1) return r;
+  if (p.only_decodes && r.q_len != 1) return r;
+  const int seq_len = p.seqused_k[r.seq];
+  r.ctx_len = seq_len - r.q_len;
+  r.q_pos = r.token - q_start;
+  r.n_keys = max(0, min(r.ctx_len + r.q_pos + 1, seq_len));   // causal
+  if (p.sliding_window > 0) r.first_key = max(0, r.ctx_len + r.q_pos - p.sliding_window + 1);  // keep j with q_abs - j < window
+  r.valid = true;
+  return r;
+}
+
+template <typename T, typename KVT, int D, int WAVES, bool FEAT>
 __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const DecodeArgs a) {
-  constexpr int PPR = D / 8;            // 16-byte pieces per key row
-  constexpr int NLD = PPR / 4;          // row-shaped loads per 16-key group per lane
-  constexpr int RS = D * 2 + 32;        // LDS row stride in bytes
-  constexpr int KSTEPS = D / 32;        // MFMA k-steps of Q.K^T
-  constexpr int DBLK = D / 16;          // 16-wide output blocks of P.V
-  constexpr int LDS_PER_WAVE = 48 * RS; // K: one 16-key group, V: two
+  constexpr bool FP8 = !__is_same(T, KVT);
+  constexpr int KVB = FP8 ? 1 : 2;                  // bytes per cache element
+  constexpr int PPR = D * KVB / 16;                 // 16-byte pieces per key row in HBM
+  constexpr int NLD = (16 * PPR) / 64;              // row-shaped loads per 16-key group per lane
+  constexpr int EPP = 16 / KVB;                     // elements per piece
+  constexpr int RS = D * 2 + 32;                    // LDS row stride in bytes (16-bit rows)
+  constexpr int KSTEPS = D / 32;                    // MFMA k-steps of Q.K^T
+  constexpr int DBLK = D / 16;                      // 16-wide output blocks of P.V
+  constexpr int LDS_PER_WAVE = 48 * RS;             // K: one 16-key group, V: two
+  static_assert(NLD >= 1, "head size too small for the row-shaped load");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mi355_attn_params& p = a.p;
@@ -94,27 +157,15 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   char* k_lds = smem + wave_in_wg * LDS_PER_WAVE;
   char* v_lds = k_lds + 16 * RS;
 
-  // ---- which (token, split, kv head) this wave owns (all wave-uniform) -------------------------
+  // ---- which (unit, split, kv head) this wave owns (all wave-uniform) ----------------------------
   const int Hk = p.num_kv_heads;
   const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave_in_wg);
   const int head = item % Hk;
   const int rest = item / Hk;
   const int split = rest % a.num_splits;
-  const int token = rest / a.num_splits;
-  if (token >= p.num_tokens) return;
-
-  const int seq = find_seq_by_token(p.cu_seqlens_q, p.num_seqs, token);
-  const int q_start = p.cu_seqlens_q[seq];
-  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
-  if (p.skip_decodes && q_len == 1) return;
-  if (p.only_decodes && q_len != 1) return;
-  const int seq_len = p.seqused_k[seq];
-  const int ctx_len = seq_len - q_len;
-  const int q_pos = token - q_start;
-  int n_keys = min(ctx_len + q_pos + 1, seq_len);   // causal
-  if (n_keys < 0) n_keys = 0;
-  int first_key = 0;                                // sliding window: keep j with q_abs - j < window
-  if (p.sliding_window > 0) first_key = max(0, ctx_len + q_pos - p.sliding_window + 1);
+  const RowInfo ri = row_info(p, a.by_seq, rest / a.num_splits);
+  if (!ri.valid) return;
+  const int token = ri.token, n_keys = ri.n_keys, first_key = ri.first_key, ctx_len = ri.ctx_len;
 
   const int G = a.group;
   const int g = lane & 15, grp = lane >> 4;
@@ -147,42 +198,62 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     }
   }
 
-  const float slope = (p.alibi_slopes && g_ok) ? p.alibi_slopes[hq] : 0.0f;
-  const float scale2 = p.scale * kLog2e;
-  const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
-  const uint16_t* kbase = (const uint16_t*)p.k_cache + (int64_t)head * p.k_stride_head;
-  const uint16_t* vbase = (const uint16_t*)p.v_cache + (int64_t)head * p.v_stride_head;
+  const float k_scale = (FP8 && p.k_scale) ? p.k_scale[0] : 1.0f;
+  const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
+  const float slope = (FEAT && p.alibi_slopes && g_ok) ? p.alibi_slopes[hq] : 0.0f;
+  const float scale_nat = p.scale * k_scale;     // fp8: K is used un-scaled, its scale moves here
+  const float scale2 = scale_nat * kLog2e;
+  const int32_t* bt = p.block_table + (int64_t)ri.seq * p.block_table_stride;
+  using kv_elem_t = typename KVT::storage;
+  const kv_elem_t* kbase = (const kv_elem_t*)p.k_cache + (int64_t)head * p.k_stride_head;
+  const kv_elem_t* vbase = (const kv_elem_t*)p.v_cache + (int64_t)head * p.v_stride_head;
   const int last_group = (n_keys - 1) >> 4;  // last 16-key group that holds a visible key
+  const int page_mask = p.page_size - 1;
 
   // per-lane constants of the row-shaped loads: piece idx = lane + 64*i -> (row = idx / PPR, piece = idx % PPR)
-  int ld_row[NLD], ld_off[NLD];
+  int ld_row[NLD], ld_piece[NLD];
+  uint32_t k_toff[NLD], v_toff[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int idx = lane + 64 * i;
     ld_row[i] = idx / PPR;
-    ld_off[i] = (idx % PPR) * 8;
+    ld_piece[i] = idx % PPR;
+    k_toff[i] = (uint32_t)(ld_row[i] * (int)a.k_slot_stride + ld_piece[i] * EPP);
+    v_toff[i] = (uint32_t)(ld_row[i] * (int)a.v_slot_stride + ld_piece[i] * EPP);
   }
 
-  auto group_ptrs = [&](int gi, const uint16_t*& kp, const uint16_t*& vp) {
-    gi = min(gi, last_group);  // never index the block table past the sequence's pages
-    const int key0 = gi << 4;
-    const int page = bt[key0 / p.page_size];
-    const int slot = key0 % p.page_size;
-    kp = kbase + (int64_t)page * p.k_stride_page + (int64_t)slot * p.k_stride_slot;
-    vp = vbase + (int64_t)page * p.v_stride_page + (int64_t)slot * p.v_stride_slot;
+  // block-table entries of the two groups of a tile, via the scalar cache (see scalar_load4)
+  int pg[2];
+  auto lookup_pages = [&](int tile) {
+    const int i0 = (min(tile * 2, last_group) << 4) >> a.page_shift;      // stay inside the sequence's pages
+    const int i1 = (min(tile * 2 + 1, last_group) << 4) >> a.page_shift;
+    int d0, d1;
+    scalar_load4(bt, i0, i1, i0, i1, pg[0], pg[1], d0, d1);
   };
-
   u32x4_t kreg[2][NLD], vreg[2][NLD];
-  auto issue_loads = [&](int tile) {
+  auto issue_loads = [&](int tile) {       // uses pg[], which must hold this tile's pages
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint16_t *kp, *vp;
-      group_ptrs(tile * 2 + h, kp, vp);
+      const int gi = min(tile * 2 + h, last_group);
+      const int slot0 = (gi << 4) & page_mask;
+      const kv_elem_t* kp = kbase + ((uint64_t)(uint32_t)pg[h] * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride);
+      const kv_elem_t* vp = vbase + ((uint64_t)(uint32_t)pg[h] * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        kreg[h][i] = *(const u32x4_t*)(kp + (int64_t)ld_row[i] * p.k_stride_slot + ld_off[i]);
-        vreg[h][i] = *(const u32x4_t*)(vp + (int64_t)ld_row[i] * p.v_stride_slot + ld_off[i]);
+        kreg[h][i] = *(const u32x4_t*)(kp + k_toff[i]);
+        vreg[h][i] = *(const u32x4_t*)(vp + v_toff[i]);
       }
+    }
+  };
+  // one loaded 16-byte piece -> LDS row of the 16-bit type
+  auto park = [&](char* base, int row, int piece, u32x4_t v) {
+    if constexpr (FP8) {
+      u32x4_t lo, hi;
+      widen_fp8x16<T, KVT>(v, lo, hi);
+      *(u32x4_t*)(base + row * RS + piece * 32) = lo;
+      *(u32x4_t*)(base + row * RS + piece * 32 + 16) = hi;
+    } else {
+      *(u32x4_t*)(base + row * RS + piece * 16) = v;
     }
   };
 
@@ -191,7 +262,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
   for (int b = 0; b < DBLK; ++b) o_acc[b] = f32x4_t{0, 0, 0, 0};
 
+  lookup_pages(t0);
   issue_loads(t0);
+  if (t0 + 1 < t1) lookup_pages(t0 + 1);
+#pragma unroll
+  for (int c = 0; c < KSTEPS; ++c) asm volatile("" : "+v"(qf[c]));   // retire the Q loads before the loop (see prefill kernel)
 
   for (int tile = t0; tile < t1; ++tile) {
     // ---- park the current tile's rows in LDS, then refill the registers with the next tile ------
@@ -208,16 +283,19 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
         u32x4_t v = vreg[h][i];
         // rows past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
         if (tail && (tile * kTileKeys + h * 16 + ld_row[i] >= n_keys)) v = u32x4_t{0, 0, 0, 0};
-        *(u32x4_t*)(v_lds + (h * 16 + ld_row[i]) * RS + ld_off[i] * 2) = v;
+        park(v_lds, h * 16 + ld_row[i], ld_piece[i], v);
       }
-    if (tile + 1 < t1) issue_loads(tile + 1);
+    if (tile + 1 < t1) {
+      issue_loads(tile + 1);
+      if (tile + 2 < t1) lookup_pages(tile + 2);
+    }
 
     // ---- S^T = K . Q^T, one 16-key group at a time through the K buffer --------------------------
     f32x4_t s[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) *(u32x4_t*)(k_lds + ld_row[i] * RS + ld_off[i] * 2) = kcur[h][i];
+      for (int i = 0; i < NLD; ++i) park(k_lds, ld_row[i], ld_piece[i], kcur[h][i]);
       f32x4_t acc = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < KSTEPS; ++c) {
@@ -233,16 +311,22 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sv[h * 4 + r] = s[h][r];
-    const bool plain = !(p.softcap > 0.0f) && !p.alibi_slopes;
-    const bool need_mask = tail || (tile * kTileKeys < first_key);
+    const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
+    const bool need_mask = tail || (FEAT && tile * kTileKeys < first_key);
     if (plain && !need_mask) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) sv[j] *= scale2;
+    } else if (!FEAT) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int key = tile * kTileKeys + (j >> 2) * 16 + grp * 4 + (j & 3);
+        sv[j] = key < n_keys ? sv[j] * scale2 : -INFINITY;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int key = tile * kTileKeys + (j >> 2) * 16 + grp * 4 + (j & 3);
-        float x = sv[j] * p.scale;
+        float x = sv[j] * scale_nat;
         if (p.softcap > 0.0f) x = softcap_fn(x, p.softcap);
         if (key >= n_keys || key < first_key) x = -INFINITY;
         if (p.alibi_slopes) x += slope * (float)(key - ctx_len);
@@ -264,11 +348,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     m_run = m_new;
     // P^T fragment (B operand): k-slot j -> key 4*grp + (j&3) of group (j>>2); rounded to the KV
     // dtype before P.V like the reference (:508)
-    const u32x2_t plo = mma<T>::pack4(pv[0], pv[1], pv[2], pv[3]);
-    const u32x2_t phi = mma<T>::pack4(pv[4], pv[5], pv[6], pv[7]);
-    const s16x8_t pf = __builtin_bit_cast(s16x8_t, u32x4_t{plo[0], plo[1], phi[0], phi[1]});
+    const s16x8_t pf = __builtin_bit_cast(s16x8_t, u32x4_t{mma<T>::pack2(pv[0], pv[1]), mma<T>::pack2(pv[2], pv[3]),
+                                                           mma<T>::pack2(pv[4], pv[5]), mma<T>::pack2(pv[6], pv[7])});
 
     // ---- O^T += V^T . P^T -----------------------------------------------------------------------
+    const bool rescale = !__all(alpha == 1.0f);
 #pragma unroll
     for (int b = 0; b < DBLK; ++b) {
       // transposed read: lane 4q+pp of group grp addresses row 4*grp+q, columns 16b+4pp..+3 and
@@ -278,8 +362,10 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va));
       const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + 16 * RS));
       const s16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (rescale) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o_acc[b][r] *= alpha;
+        for (int r = 0; r < 4; ++r) o_acc[b][r] *= alpha;
+      }
       o_acc[b] = mma<T>::run(vf, pf, o_acc[b]);
     }
   }
@@ -288,12 +374,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const float l_tot = sum_over_lane_groups(l_run);
   if (!g_ok) return;
   if (direct) {
-    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    const float inv = l_tot > 0.0f ? v_scale / l_tot : 0.0f;
     const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
       *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
-          mma<T>::pack4(o_acc[b][0] * inv, o_acc[b][1] * inv, o_acc[b][2] * inv, o_acc[b][3] * inv);
+          u32x2_t{mma<T>::pack2(o_acc[b][0] * inv, o_acc[b][1] * inv), mma<T>::pack2(o_acc[b][2] * inv, o_acc[b][3] * inv)};
   } else {
     const int64_t slot = ((int64_t)token * p.num_q_heads + hq) * a.num_splits + split;
     float* dst = a.ws_acc + slot * D;
@@ -303,83 +389,92 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   }
 }
 
-// Merge of the split partials (reference: reduce_segments, :757-836). One wave per (token, query
-// head); lane d-strided over the head dimension.
-template <typename T, int D>
+// Merge of the split partials (reference: reduce_segments, :757-836). One wave per (unit, query
+// head): the 64 lanes split as (split-parity, 16-byte column chunk) so that the partial rows are
+// read as full-width 16-byte loads, several splits at a time.
+template <typename T, bool FP8, int D>
 __global__ __launch_bounds__(64) void reduce_splits_kernel(const DecodeArgs a) {
   const mi355_attn_params& p = a.p;
-  const int token = blockIdx.x, hq = blockIdx.y, lane = threadIdx.x;
-  const int seq = find_seq_by_token(p.cu_seqlens_q, p.num_seqs, token);
-  const int q_start = p.cu_seqlens_q[seq];
-  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
-  if (p.skip_decodes && q_len == 1) return;
-  if (p.only_decodes && q_len != 1) return;
-  const int seq_len = p.seqused_k[seq];
-  const int ctx_len = seq_len - q_len;
-  const int q_pos = token - q_start;
-  int n_keys = min(ctx_len + q_pos + 1, seq_len);
-  if (n_keys < 0) n_keys = 0;
-  int first_key = 0;
-  if (p.sliding_window > 0) first_key = max(0, ctx_len + q_pos - p.sliding_window + 1);
-  const int tile_lo = first_key / kTileKeys;
-  const int tile_hi = (n_keys + kTileKeys - 1) / kTileKeys;
+  const int hq = blockIdx.y, lane = threadIdx.x;
+  const RowInfo ri = row_info(p, a.by_seq, blockIdx.x);
+  if (!ri.valid) return;
+  const int tile_lo = ri.first_key / kTileKeys;
+  const int tile_hi = (ri.n_keys + kTileKeys - 1) / kTileKeys;
   const int n_tiles = max(0, tile_hi - tile_lo);
   const int active = min(a.num_splits, (n_tiles + a.tiles_per_split - 1) / a.tiles_per_split);
+  const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
 
-  const int64_t slot0 = ((int64_t)token * p.num_q_heads + hq) * a.num_splits;
+  constexpr int CH = D / 4;               // 16-byte chunks per row (16, 32 or 64)
+  constexpr int LPS = CH < 64 ? CH : 64;  // lanes per split row
+  constexpr int SPW = 64 / LPS;           // split rows handled per pass
+  constexpr int CPL = CH / LPS;           // chunks per lane
+  const int sub = lane / LPS, col = lane % LPS;
+
+  const int64_t slot0 = ((int64_t)ri.token * p.num_q_heads + hq) * a.num_splits;
   float m_all = -INFINITY;
   for (int s = 0; s < active; ++s) m_all = fmaxf(m_all, a.ws_ml[slot0 + s].x);
-  float l_all = 0.0f;
-  constexpr int PER = (D + 63) / 64;
-  float acc[PER];
+  float l_part = 0.0f;
+  f32x4_t acc[CPL];
 #pragma unroll
-  for (int i = 0; i < PER; ++i) acc[i] = 0.0f;
-  for (int s = 0; s < active; ++s) {
+  for (int c = 0; c < CPL; ++c) acc[c] = f32x4_t{0, 0, 0, 0};
+  for (int s = sub; s < active; s += SPW) {
     const float2 ml = a.ws_ml[slot0 + s];
     const float w = __builtin_amdgcn_exp2f(ml.x - m_all);
-    l_all += ml.y * w;
-    const float* src = a.ws_acc + (slot0 + s) * D;
+    l_part += ml.y * w;
+    const f32x4_t* src = (const f32x4_t*)(a.ws_acc + (slot0 + s) * D);
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int d = lane + 64 * i;
-      if (d < D) acc[i] += src[d] * w;
-    }
+    for (int c = 0; c < CPL; ++c) acc[c] += src[col + c * LPS] * w;
   }
-  const float inv = l_all > 0.0f ? 1.0f / l_all : 0.0f;  // "0 if the overall sum is 0" (:828)
-  const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
+  // fold the SPW partial sums (lanes col, col+LPS, ...)
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int d = lane + 64 * i;
-    if (d < D) elem<T>::store(p.out, o + d, acc[i] * inv);
+  for (int o = LPS; o < 64; o <<= 1) {
+    l_part += __shfl_xor(l_part, o, 64);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c][e] += __shfl_xor(acc[c][e], o, 64);
   }
+  if (sub != 0) return;
+  const float inv = l_part > 0.0f ? v_scale / l_part : 0.0f;  // "0 if the overall sum is 0" (:828)
+  uint16_t* op = (uint16_t*)p.out + (int64_t)ri.token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+    *(u32x2_t*)(op + 4 * (col + c * LPS)) =
+        u32x2_t{mma<T>::pack2(acc[c][0] * inv, acc[c][1] * inv), mma<T>::pack2(acc[c][2] * inv, acc[c][3] * inv)};
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
+static bool is_fp8_dtype(int d) { return d == MI355_FP8_E4M3 || d == MI355_FP8_E5M2; }
 
 bool decode_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
-  if (p.kv_dtype != p.q_dtype) return false;
+  if (p.kv_dtype != p.q_dtype && !is_fp8_dtype(p.kv_dtype)) return false;
   if (!(p.head_size == 64 || p.head_size == 128 || p.head_size == 256)) return false;
   if (p.k_new || p.v_new) return false;
-  if (p.page_size % 16 != 0) return false;
+  if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
   const int G = p.num_q_heads / p.num_kv_heads;
   if (G > 16) return false;
   if (!aligned16(p.q) || !aligned16(p.k_cache) || !aligned16(p.v_cache)) return false;
   if (((uintptr_t)p.out & 7) != 0) return false;
-  const int64_t strides[] = {p.q_stride_token, p.q_stride_head, p.k_stride_page, p.k_stride_slot, p.k_stride_head,
-                             p.v_stride_page, p.v_stride_slot, p.v_stride_head};
-  for (int64_t s : strides) if (s % 8 != 0) return false;
+  const int64_t kv_align = is_fp8_dtype(p.kv_dtype) ? 16 : 8;   // elements per 16 bytes
+  const int64_t kv_strides[] = {p.k_stride_page, p.k_stride_slot, p.k_stride_head, p.v_stride_page, p.v_stride_slot, p.v_stride_head};
+  for (int64_t s : kv_strides) if (s % kv_align != 0 || s < 0) return false;
+  if (p.q_stride_token % 8 != 0 || p.q_stride_head % 8 != 0) return false;
   if (p.out_stride_token % 4 != 0 || p.out_stride_head % 4 != 0) return false;
+  if (p.k_stride_slot >= (1 << 24) || p.v_stride_slot >= (1 << 24)) return false;      // 32-bit in-page offsets
+  if (p.k_stride_page >= (1LL << 31) || p.v_stride_page >= (1LL << 31)) return false;
   return true;
 }
 
 struct SplitPlan { int num_splits, tiles_per_split; };
 
-// Capture-stable split policy: depends only on host-known sizes (T, Hk, max_seqlen_k).
+static long decode_units(const mi355_attn_params& p) { return p.only_decodes ? p.num_seqs : p.num_tokens; }
+
+// Capture-stable split policy: depends only on host-known sizes (units, Hk, max_seqlen_k).
 static SplitPlan plan_splits(const mi355_attn_params& p) {
   const int max_tiles = (p.max_seqlen_k + kTileKeys - 1) / kTileKeys;
   if (max_tiles <= 1) return {1, 1};
@@ -387,34 +482,41 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
   if (p.num_segments > 0) {
     want = p.num_segments;
   } else {
-    const long base = (long)p.num_tokens * p.num_kv_heads;  // waves with one split each
-    const long target = 256L * 8 * 2;                       // ~2 waves per resident slot (8 waves/CU)
+    const long base = std::max(1L, decode_units(p) * p.num_kv_heads);  // waves with one split each
+    const long target = 256L * 8 * 2;                                   // ~2 waves per resident slot (8 waves/CU)
     want = (int)((target + base - 1) / base);
-    // keep each split at least 4 tiles (128 keys) long
-    want = min(want, max(1, max_tiles / 4));
+    want = std::min(want, std::max(1, max_tiles / 4));                  // keep each split >= 4 tiles (128 keys)
   }
-  want = max(1, min(want, min(max_tiles, 64)));
+  want = std::max(1, std::min(want, std::min(max_tiles, 64)));
   const int tps = (max_tiles + want - 1) / want;
   return {(max_tiles + tps - 1) / tps, tps};
 }
 
 size_t decode_workspace_bytes(const mi355_attn_params& p) {
   if (!decode_supported(p)) return 0;
-  const SplitPlan sp = plan_splits(p);
-  if (sp.num_splits == 1) return 0;
-  const size_t slots = (size_t)p.num_tokens * p.num_q_heads * sp.num_splits;
+  // a mixed batch may send only its decode rows here: size for the larger of the two uses
+  mi355_attn_params alt = p;
+  alt.only_decodes = p.only_decodes ? 0 : 1;
+  const int splits = std::max(plan_splits(p).num_splits, plan_splits(alt).num_splits);
+  if (splits == 1) return 0;
+  const size_t slots = (size_t)p.num_tokens * p.num_q_heads * splits;
   return slots * p.head_size * sizeof(float) + slots * sizeof(float2);
 }
 
-template <typename T, int D>
+template <typename T, typename KVT, int D, bool FEAT>
 static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   constexpr int WAVES = 4;
+  constexpr bool FP8 = !__is_same(T, KVT);
   DecodeArgs a;
   a.p = p;
   const SplitPlan sp = plan_splits(p);
   a.num_splits = sp.num_splits;
   a.tiles_per_split = sp.tiles_per_split;
   a.group = p.num_q_heads / p.num_kv_heads;
+  a.page_shift = __builtin_ctz((unsigned)p.page_size);
+  a.by_seq = p.only_decodes ? 1 : 0;
+  a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
+  a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   a.ws_acc = nullptr;
   a.ws_ml = nullptr;
   if (sp.num_splits > 1) {
@@ -427,29 +529,45 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     a.ws_acc = (float*)ws;
     a.ws_ml = (float2*)((char*)ws + slots * D * sizeof(float));
   }
-  const long items = (long)p.num_tokens * sp.num_splits * p.num_kv_heads;
+  const long units = decode_units(p);
+  if (units == 0) return MI355_OK;
+  const long items = units * sp.num_splits * p.num_kv_heads;
   const int grid = (int)((items + WAVES - 1) / WAVES);
   const size_t lds = (size_t)WAVES * 48 * (D * 2 + 32);
-  hipLaunchKernelGGL((decode_splitkv_kernel<T, D, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+  hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
   if (rc != MI355_OK) return rc;
   if (sp.num_splits > 1) {
-    hipLaunchKernelGGL((reduce_splits_kernel<T, D>), dim3(p.num_tokens, p.num_q_heads), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D>), dim3((unsigned)units, p.num_q_heads), dim3(64), 0, stream, a);
     rc = check_hip(hipGetLastError(), "reduce_splits_kernel launch");
   }
-  if (rc == MI355_OK) set_kernel_name(sp.num_splits > 1 ? "decode_splitkv" : "decode_single");
+  if (rc == MI355_OK)
+    set_kernel_name(sp.num_splits > 1 ? (FP8 ? "decode_splitkv_fp8" : "decode_splitkv") : (FP8 ? "decode_single_fp8" : "decode_single"));
   return rc;
 }
 
-template <typename T>
+template <typename T, typename KVT, int D>
+static int launch_decode_f(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+  return feat ? launch_decode_t<T, KVT, D, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false>(p, ws, ws_bytes, stream);
+}
+
+template <typename T, typename KVT>
 static int launch_decode_d(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   switch (p.head_size) {
-    case 64: return launch_decode_t<T, 64>(p, ws, ws_bytes, stream);
-    case 128: return launch_decode_t<T, 128>(p, ws, ws_bytes, stream);
-    case 256: return launch_decode_t<T, 256>(p, ws, ws_bytes, stream);
+    case 64: return launch_decode_f<T, KVT, 64>(p, ws, ws_bytes, stream);
+    case 128: return launch_decode_f<T, KVT, 128>(p, ws, ws_bytes, stream);
+    case 256: return launch_decode_f<T, KVT, 256>(p, ws, ws_bytes, stream);
   }
   set_error("decode: head_size %d not built", p.head_size);
   return MI355_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+static int launch_decode_kv(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (p.kv_dtype == MI355_FP8_E4M3) return launch_decode_d<T, e4m3_t>(p, ws, ws_bytes, stream);
+  if (p.kv_dtype == MI355_FP8_E5M2) return launch_decode_d<T, e5m2_t>(p, ws, ws_bytes, stream);
+  return launch_decode_d<T, T>(p, ws, ws_bytes, stream);
 }
 
 int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -457,8 +575,8 @@ int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStre
     set_error("decode kernel does not support this configuration");
     return MI355_ERR_UNSUPPORTED;
   }
-  if (p.q_dtype == MI355_BF16) return launch_decode_d<bf16_t>(p, ws, ws_bytes, stream);
-  return launch_decode_d<f16_t>(p, ws, ws_bytes, stream);
+  if (p.q_dtype == MI355_BF16) return launch_decode_kv<bf16_t>(p, ws, ws_bytes, stream);
+  return launch_decode_kv<f16_t>(p, ws, ws_bytes, stream);
 }
 
 }  // namespace mi355
