@@ -24,6 +24,8 @@
 //     only masks).
 // Launch grid mirrors the reference's static upper bound (T / BLOCK_Q + S Q-blocks, :886-889,
 // :935-943), heaviest (latest) Q blocks first.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mi355 {
@@ -387,6 +389,310 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
     }
 }
 
+// =============================================================================================
+// prefill_dma_kernel: the D = 128, no-soft-cap/ALiBi/window fast path.
+//
+// Same decomposition and MFMA orientation as prefill_mfma_kernel, plus three changes that cut the
+// per-tile instruction count (the kernel is issue-bound well before it is MFMA-bound):
+//   * K/V tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no
+//     ds_write pass). The DMA writes 1 KiB contiguously per wave-instruction, so rows cannot be
+//     padded; bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index instead,
+//     applied on the per-lane SOURCE address and again on the read address:
+//       K (ds_read_b128 rows):        chunk ^= row & 15
+//       V (ds_read_b64_tr_b16 reads): chunk ^= ((row & 3) << 2) | ((row >> 2) & 3)
+//     Rows past the sequence are redirected to the sequence's last row (finite data, masked P).
+//   * the query is pre-scaled by scale*log2(e) once, and the running max enters through the MFMA
+//     accumulator: S^T starts from C = -m_ref, so P = exp2(acc) is ONE instruction per score.
+//     m_ref is only moved when some row's tile max exceeds it by more than kDeferThr (log2 units);
+//     the softmax is shift-invariant, so results are unchanged up to rounding (P <= 2^kDeferThr).
+//   * read addresses are per-lane constants (the swizzle is folded in once), the tile loop is
+//     unrolled by two so the LDS stage is an immediate offset.
+// =============================================================================================
+constexpr float kDeferThr = 8.0f;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a) {
+  constexpr int D = 128;
+  constexpr int ROWB = D * 2;                 // 256-byte rows, 16 chunks of 16 B
+  constexpr int KBUF = kTileN * ROWB, STAGE = 2 * KBUF;   // K tile then V tile
+  constexpr int KSTEPS = D / 16, DBLK = D / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages
+  const mi355_attn_params& p = a.p;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = a.group, BQ = a.block_q;
+
+  const int head = (int)(blockIdx.x % p.num_kv_heads);
+  const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);
+  const int seq = find_seq_by_qblock(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
+  if (seq < 0) return;
+  const int q_start = p.cu_seqlens_q[seq];
+  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
+  const int qb_local = qblock - (q_start / BQ + seq);
+  if (qb_local * BQ >= q_len) return;
+  if (p.skip_decodes && q_len == 1) return;
+  if (p.only_decodes && q_len != 1) return;
+  const int seq_len = p.seqused_k[seq];
+  const int ctx_len = seq_len - q_len;
+  const int tok0 = qb_local * BQ;
+
+  const int qr = lane & 31, half = lane >> 5;
+  const int m_row = wave * 32 + qr;
+  const int tok_local = tok0 + m_row / G;
+  const int hq = head * G + m_row % G;
+  const bool row_ok = (m_row < BQ * G) && (tok_local < q_len);
+  const int q_abs = ctx_len + tok_local;
+  const int lim = row_ok ? min(q_abs, seq_len - 1) : -1;   // last visible key of this row
+
+  const int w_tok_lo = tok0 + (wave * 32) / G;
+  const int w_tok_hi = min(min(tok0 + (wave * 32 + 31) / G, tok0 + BQ - 1), q_len - 1);
+  const int wg_tok_hi = min(tok0 + BQ - 1, q_len - 1);
+  const int n_keys_wg = max(0, min(ctx_len + wg_tok_hi + 1, seq_len));
+  const int wave_keys = min(ctx_len + w_tok_hi + 1, seq_len);
+  const bool wave_has_rows = w_tok_lo <= w_tok_hi;
+  const int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
+
+  // ---- Q fragments, pre-scaled into the log2 domain ---------------------------------------------
+  const float scale2 = p.scale * kLog2eP;
+  ps16x8_t qf[KSTEPS];
+  {
+    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)(q_start + tok_local) * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      pu32x4_t v = {0, 0, 0, 0};
+      if (row_ok) v = *(const pu32x4_t*)(qp + 16 * ks);
+      pu32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo, hi;
+        if constexpr (__is_same(T, bf16_t)) {
+          lo = bf16_to_f32((uint16_t)(v[e] & 0xffff)); hi = bf16_to_f32((uint16_t)(v[e] >> 16));
+        } else {
+          lo = f16_to_f32((uint16_t)(v[e] & 0xffff)); hi = f16_to_f32((uint16_t)(v[e] >> 16));
+        }
+        w[e] = pmma<T>::pack2(lo * scale2, hi * scale2);
+      }
+      qf[ks] = __builtin_bit_cast(ps16x8_t, w);
+    }
+  }
+
+  // ---- DMA staging constants ----------------------------------------------------------------------
+  // lane handles LDS chunk (row = (tid>>4) + 16 i, c = tid & 15) of both tiles; 16-key group i <-> load i
+  const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
+  const char* kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
+  const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
+  const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
+  const int page_mask = p.page_size - 1;
+  const int rowin = tid >> 4, ch = tid & 15;
+  const int fk = rowin & 15;
+  const int fv = ((rowin & 3) << 2) | ((rowin >> 2) & 3);
+  uint32_t k_voff = (uint32_t)(rowin * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
+  uint32_t v_voff = (uint32_t)(rowin * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
+  const uint32_t lds_wave = (uint32_t)(wave * 64 * 16);        // + i*4096 (+KBUF for V) + stage
+
+  int pg_next[4];
+  auto lookup_pages = [&](int tile) {
+    int idx[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) idx[g4] = (min(tile * 4 + g4, last_group) << 4) >> a.page_shift;
+    scalar_load4(bt, idx[0], idx[1], idx[2], idx[3], pg_next[0], pg_next[1], pg_next[2], pg_next[3]);
+  };
+  auto issue_dma = [&](int tile, char* stage) {   // uses pg_next (this tile's pages)
+    const uint32_t kv = k_voff, vv = v_voff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gi = min(tile * 4 + i, last_group);
+      const int key0 = gi << 4;
+      const int slot0 = key0 & page_mask;
+      uint32_t kvo = kv, vvo = vv;
+      if (key0 + 16 > seq_len) {          // wave-uniform: the sequence ends inside this group -> rows past it
+                                          // fetch its last row instead (never stale cache contents)
+        const int r = min(rowin, max(seq_len - 1 - key0, 0));
+        kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
+        vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
+      }
+      const char* kp = kbase + ((uint64_t)(uint32_t)pg_next[i] * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride) * 2;
+      const char* vp = vbase + ((uint64_t)(uint32_t)pg_next[i] * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride) * 2;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + kvo),
+                                       (__attribute__((address_space(3))) void*)(stage + lds_wave + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + vvo),
+                                       (__attribute__((address_space(3))) void*)(stage + KBUF + lds_wave + i * 4096), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane LDS read addresses (swizzle folded in) ---------------------------------------------
+  // K fragment ks of 32-key block kb: row 32kb + qr, logical chunk 2ks + half
+  uint32_t k_rd[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = (uint32_t)(qr * ROWB + (((2 * ks + half) ^ (qr & 15)) << 4));
+  // V transposed read of k-step sk (16 keys), output block b: row 16sk + 4half + q4 (+8), logical
+  // byte column 64b + 32g1 + 8pp  ->  chunk 4b + 2g1 + (pp>>1), sub-offset 8(pp&1)
+  const int gq1 = (lane >> 4) & 1, li = lane & 15, q4 = li >> 2, pp = li & 3;
+  uint32_t v_rd0[DBLK], v_rd1[DBLK];
+#pragma unroll
+  for (int b = 0; b < DBLK; ++b) {
+    const int lc = 4 * b + 2 * gq1 + (pp >> 1);
+    const int r0 = 4 * half + q4, r1 = r0 + 8;
+    const int f0 = ((r0 & 3) << 2) | ((r0 >> 2) & 3), f1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3);
+    v_rd0[b] = (uint32_t)(KBUF + r0 * ROWB + ((lc ^ f0) << 4) + 8 * (pp & 1));
+    v_rd1[b] = (uint32_t)(KBUF + r1 * ROWB + ((lc ^ f1) << 4) + 8 * (pp & 1));
+  }
+
+  float m_ref = 0.0f, l_run = 0.0f;
+  bool started = !row_ok;               // padding rows never see a key: do not let them force the slow path
+  pf32x16_t cinit;                      // -m_ref in every register: the C operand that starts S^T
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = 0.0f;
+  pf32x16_t o_acc[DBLK];
+#pragma unroll
+  for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
+
+  if (tile_hi > 0) {
+    lookup_pages(0);
+    issue_dma(0, smem);
+    if (tile_hi > 1) lookup_pages(1);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  __syncthreads();
+
+  auto compute_tile = [&](int tile, const char* stage) {
+    const int key_base = tile * kTileN;
+    // ---- S^T - m_ref = K . Q'^T + cinit --------------------------------------------------------------
+    pf32x16_t s_acc[2];
+    pu32x4_t kf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const pu32x4_t*)(stage + k_rd[ks]);
+    __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      s_acc[0] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], ks == 0 ? cinit : s_acc[0]);
+      kf[ks] = *(const pu32x4_t*)(stage + 32 * ROWB + k_rd[ks]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      s_acc[1] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], ks == 0 ? cinit : s_acc[1]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    // ---- softmax -------------------------------------------------------------------------------------
+    const bool need_mask = (key_base + kTileN - 1 > ctx_len + w_tok_lo) || (key_base + kTileN > seq_len);
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+          s_acc[kb][r] = key <= lim ? s_acc[kb][r] : -INFINITY;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
+    mx = fmaxf(mx, lane_xor32(mx));                       // the other half-wave holds the other 32 keys
+    float alpha = 1.0f;
+    const bool calm = started && mx <= kDeferThr;         // this row keeps its reference max
+    if (!__all(calm)) {
+      // move the reference of the rows that need it: first visible key, or max grew past the threshold
+      const float upd = (!calm && mx > -INFINITY) ? mx : 0.0f;
+      started = started || (mx > -INFINITY);
+      m_ref += upd;
+      alpha = __builtin_amdgcn_exp2f(-upd);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kb][r] -= upd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[r] = -m_ref;
+      l_run *= alpha;
+#pragma unroll
+      for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
+    }
+    float psum = 0.0f;
+    ps16x8_t pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float e[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        e[r] = __builtin_amdgcn_exp2f(s_acc[kb][r]);
+        psum += e[r];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const pu32x4_t w = {pmma<T>::pack2(e[8 * s + 0], e[8 * s + 1]), pmma<T>::pack2(e[8 * s + 2], e[8 * s + 3]),
+                            pmma<T>::pack2(e[8 * s + 4], e[8 * s + 5]), pmma<T>::pack2(e[8 * s + 6], e[8 * s + 7])};
+        pf[2 * kb + s] = __builtin_bit_cast(ps16x8_t, w);
+      }
+    }
+    l_run += psum;
+    // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
+    ps16x4_t vt[2][8];
+    auto read_v_block = [&](int b, ps16x4_t (&dst)[8]) {
+#pragma unroll
+      for (int sk = 0; sk < 4; ++sk) {
+        dst[2 * sk] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd0[b]));
+        dst[2 * sk + 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd1[b]));
+      }
+    };
+    read_v_block(0, vt[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b) {
+      if (b + 1 < DBLK) read_v_block(b + 1, vt[(b + 1) & 1]);
+#pragma unroll
+      for (int sk = 0; sk < 4; ++sk) {
+        const ps16x4_t v0 = vt[b & 1][2 * sk], v1 = vt[b & 1][2 * sk + 1];
+        const ps16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o_acc[b] = pmma<T>::run(vf, pf[sk], o_acc[b]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (b + 1 < DBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    }
+  };
+
+  // tile loop, two tiles per trip so that the LDS stage is a compile-time offset
+  for (int tile = 0; tile < tile_hi; tile += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = tile + u;
+      if (t < tile_hi) {
+        char* cur = smem + u * STAGE;
+        char* nxt = smem + (u ^ 1) * STAGE;
+        if (t + 1 < tile_hi) {
+          issue_dma(t + 1, nxt);
+          if (t + 2 < tile_hi) lookup_pages(t + 2);
+        }
+        if (wave_has_rows && t * kTileN < wave_keys) compute_tile(t, cur);
+        __syncthreads();     // DMA of tile t+1 has landed (vmcnt(0) is part of it) and stage `cur` is free
+      }
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------
+  l_run += lane_xor32(l_run);
+  if (!row_ok) return;
+  const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+  uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
+#pragma unroll
+  for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
+                          pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+      *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -437,6 +743,30 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   return rc;
 }
 
+template <typename T>
+static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
+  PrefillArgs a;
+  a.p = p;
+  a.group = p.num_q_heads / p.num_kv_heads;
+  a.block_q = kBlockM / a.group;
+  a.page_shift = __builtin_ctz((unsigned)p.page_size);
+  a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
+  a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
+  const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
+  constexpr size_t lds = 2 * 2 * (size_t)kTileN * 256;   // two stages of K + V tiles, unpadded
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                              "hipFuncSetAttribute(prefill_dma)");
+    if (rc0 != MI355_OK) return rc0;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((prefill_dma_kernel<T>), dim3(qblocks * p.num_kv_heads), dim3(256), lds, stream, a);
+  const int rc = check_hip(hipGetLastError(), "prefill_dma_kernel launch");
+  if (rc == MI355_OK) set_kernel_name("prefill_mfma");
+  return rc;
+}
+
 int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   if (!prefill_supported(p)) {
     set_error("prefill kernel does not support this configuration");
@@ -444,6 +774,8 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   }
   const bool bf = p.q_dtype == MI355_BF16;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+  static const bool force_v1 = getenv("MI355_PREFILL_V1") != nullptr;   // A/B switch for measurements
+  if (!feat && p.head_size == 128 && !force_v1) return bf ? launch_prefill_dma<bf16_t>(p, stream) : launch_prefill_dma<f16_t>(p, stream);
 #define MI355_PREFILL_CASE(DD)                                                                            \
   case DD:                                                                                                \
     if (feat) return bf ? launch_prefill_t<bf16_t, DD, true>(p, stream) : launch_prefill_t<f16_t, DD, true>(p, stream); \
