@@ -410,6 +410,23 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
 // =============================================================================================
 constexpr float kDeferThr = 8.0f;
 
+// Diagnostic build only (-DMI355_PROFILE_PHASES, tools/phase_profile.py): per-wave cycle sums of the
+// tile loop's phases, added into a caller-provided buffer whose address travels in reserved0/1.
+// No stamp executes in the product build.
+#ifdef MI355_PROFILE_PHASES
+#define MI355_STAMP(idx)                                                                   \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    unsigned long long t_now;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    prof_sum[idx] += t_now - prof_last;                                                    \
+    prof_last = t_now;                                                                     \
+  } while (0)
+#else
+#define MI355_STAMP(idx) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a) {
   constexpr int D = 128;
@@ -499,22 +516,36 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
     for (int g4 = 0; g4 < 4; ++g4) idx[g4] = (min(tile * 4 + g4, last_group) << 4) >> a.page_shift;
     scalar_load4(bt, idx[0], idx[1], idx[2], idx[3], pg_next[0], pg_next[1], pg_next[2], pg_next[3]);
   };
+  const bool same_layout = a.k_page_stride == a.v_page_stride && a.k_slot_stride == a.v_slot_stride;  // K/V = two views of one cache
+  const bool page16 = a.page_shift == 4;
+  const uint32_t k_page_bytes = a.k_page_stride * 2, v_page_bytes = a.v_page_stride * 2;
   auto issue_dma = [&](int tile, char* stage) {   // uses pg_next (this tile's pages)
-    const uint32_t kv = k_voff, vv = v_voff;
+    if (tile * 4 + 3 <= last_group && tile * kTileN + kTileN <= seq_len && same_layout && page16) {
+      // common case, minimal scalar work: group = page, one 64-bit offset per page shared by K and V
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint64_t off = (uint64_t)(uint32_t)pg_next[i] * k_page_bytes;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + off + k_voff),
+                                         (__attribute__((address_space(3))) void*)(stage + lds_wave + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + off + v_voff),
+                                         (__attribute__((address_space(3))) void*)(stage + KBUF + lds_wave + i * 4096), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int gi = min(tile * 4 + i, last_group);
       const int key0 = gi << 4;
       const int slot0 = key0 & page_mask;
-      uint32_t kvo = kv, vvo = vv;
+      uint32_t kvo = k_voff, vvo = v_voff;
       if (key0 + 16 > seq_len) {          // wave-uniform: the sequence ends inside this group -> rows past it
                                           // fetch its last row instead (never stale cache contents)
         const int r = min(rowin, max(seq_len - 1 - key0, 0));
         kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
         vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
       }
-      const char* kp = kbase + ((uint64_t)(uint32_t)pg_next[i] * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride) * 2;
-      const char* vp = vbase + ((uint64_t)(uint32_t)pg_next[i] * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride) * 2;
+      const char* kp = kbase + ((uint64_t)(uint32_t)pg_next[i] * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2);
+      const char* vp = vbase + ((uint64_t)(uint32_t)pg_next[i] * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + kvo),
                                        (__attribute__((address_space(3))) void*)(stage + lds_wave + i * 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + vvo),
@@ -559,6 +590,10 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
   __syncthreads();
+#ifdef MI355_PROFILE_PHASES
+  unsigned long long prof_sum[6] = {0, 0, 0, 0, 0, 0}, prof_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
+#endif
 
   auto compute_tile = [&](int tile, const char* stage) {
     const int key_base = tile * kTileN;
@@ -580,6 +615,10 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
       s_acc[1] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], ks == 0 ? cinit : s_acc[1]);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
+#ifdef MI355_PROFILE_PHASES
+    asm volatile("" :: "v"(s_acc[1][0]));   // the stamp below waits for the QK chains, not just their issue
+#endif
+    MI355_STAMP(1);
     // ---- softmax -------------------------------------------------------------------------------------
     const bool need_mask = (key_base + kTileN - 1 > ctx_len + w_tok_lo) || (key_base + kTileN > seq_len);
     if (need_mask) {
@@ -635,29 +674,34 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
       }
     }
     l_run += psum;
+    MI355_STAMP(2);
     // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
-    ps16x4_t vt[2][8];
-    auto read_v_block = [&](int b, ps16x4_t (&dst)[8]) {
+    // fragments are assembled at read time (both halves written straight into one 4-VGPR operand)
+    ps16x8_t vfr[2][4];
+    auto read_v_block = [&](int b, ps16x8_t (&dst)[4]) {
 #pragma unroll
       for (int sk = 0; sk < 4; ++sk) {
-        dst[2 * sk] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd0[b]));
-        dst[2 * sk + 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd1[b]));
+        const ps16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd0[b]));
+        const ps16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd1[b]));
+        dst[sk] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
     };
-    read_v_block(0, vt[0]);
+    read_v_block(0, vfr[0]);
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
     for (int b = 0; b < DBLK; ++b) {
-      if (b + 1 < DBLK) read_v_block(b + 1, vt[(b + 1) & 1]);
+      if (b + 1 < DBLK) read_v_block(b + 1, vfr[(b + 1) & 1]);
 #pragma unroll
       for (int sk = 0; sk < 4; ++sk) {
-        const ps16x4_t v0 = vt[b & 1][2 * sk], v1 = vt[b & 1][2 * sk + 1];
-        const ps16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o_acc[b] = pmma<T>::run(vf, pf[sk], o_acc[b]);
+        o_acc[b] = pmma<T>::run(vfr[b & 1][sk], pf[sk], o_acc[b]);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (b + 1 < DBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
     }
+#ifdef MI355_PROFILE_PHASES
+    asm volatile("" :: "v"(o_acc[DBLK - 1][0]));
+#endif
+    MI355_STAMP(3);
   };
 
   // tile loop, two tiles per trip so that the LDS stage is a compile-time offset
@@ -672,13 +716,28 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
           issue_dma(t + 1, nxt);
           if (t + 2 < tile_hi) lookup_pages(t + 2);
         }
+        MI355_STAMP(0);
         if (wave_has_rows && t * kTileN < wave_keys) compute_tile(t, cur);
+#ifdef MI355_PROFILE_PHASES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MI355_STAMP(4);
+#endif
         __syncthreads();     // DMA of tile t+1 has landed (vmcnt(0) is part of it) and stage `cur` is free
+        MI355_STAMP(5);
       }
     }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
+#ifdef MI355_PROFILE_PHASES
+  {
+    unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
+    if (dbg && lane == 0) {
+      for (int i = 0; i < 6; ++i) atomicAdd(dbg + i, prof_sum[i]);
+      atomicAdd(dbg + 6, 1ull);
+    }
+  }
+#endif
   l_run += lane_xor32(l_run);
   if (!row_ok) return;
   const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
