@@ -223,6 +223,8 @@ int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStre
 
 bool prefill_supported(const mi355_attn_params& p);
 int launch_prefill(const mi355_attn_params& p, hipStream_t stream);
+bool prefill_w64_applicable(const mi355_attn_params& p);   // beyond prefill_supported()
+int launch_prefill_w64(const mi355_attn_params& p, hipStream_t stream);
 
 inline int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return MI355_OK;

@@ -833,8 +833,11 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   }
   const bool bf = p.q_dtype == MI355_BF16;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
-  static const bool force_v1 = getenv("MI355_PREFILL_V1") != nullptr;   // A/B switch for measurements
-  if (!feat && p.head_size == 128 && !force_v1) return bf ? launch_prefill_dma<bf16_t>(p, stream) : launch_prefill_dma<f16_t>(p, stream);
+  // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), v2 (LDS-DMA, 32 rows/wave); default = 64 rows/wave
+  static const char* variant = getenv("MI355_PREFILL");
+  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', v2 = variant && variant[0] == 'v' && variant[1] == '2';
+  if (!v1 && !v2 && prefill_w64_applicable(p)) return launch_prefill_w64(p, stream);
+  if (!feat && p.head_size == 128 && !v1) return bf ? launch_prefill_dma<bf16_t>(p, stream) : launch_prefill_dma<f16_t>(p, stream);
 #define MI355_PREFILL_CASE(DD)                                                                            \
   case DD:                                                                                                \
     if (feat) return bf ? launch_prefill_t<bf16_t, DD, true>(p, stream) : launch_prefill_t<f16_t, DD, true>(p, stream); \
