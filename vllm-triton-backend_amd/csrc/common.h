@@ -203,6 +203,24 @@ __device__ __forceinline__ void scalar_load4(const int32_t* base, int i0, int i1
       : "memory");
 }
 
+// One LDS-DMA piece: every lane fetches 16 bytes from its own global address and the wave's 1 KiB
+// lands contiguously at LDS byte address `lds_dst` (wave-uniform) + lane*16.
+// Issued through inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) orders every later
+// LDS read behind the DMA with an s_waitcnt vmcnt(0), i.e. the wave sits out the whole HBM/L2 round
+// trip before it may touch the OTHER stage, and the prefetch overlaps nothing. With the asm form the
+// compiler does not know a load is in flight; the caller retires it with glds_wait_all() before the
+// barrier that publishes the stage (cdna_hip_programming.md 5.7 item 1, M0 recipe).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // x * tanh(s / x) (reference: apply_softcap, triton_unified_attention.py:24-29, restated with tanhf
 // so that |s/x| > 88 does not overflow)
 __device__ __forceinline__ float softcap_fn(float s, float cap) { return cap * tanhf(s / cap); }

@@ -509,48 +509,43 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
   uint32_t v_voff = (uint32_t)(rowin * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
   const uint32_t lds_wave = (uint32_t)(wave * 64 * 16);        // + i*4096 (+KBUF for V) + stage
 
-  int pg_next[4];
-  auto lookup_pages = [&](int tile) {
-    int idx[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) idx[g4] = (min(tile * 4 + g4, last_group) << 4) >> a.page_shift;
-    scalar_load4(bt, idx[0], idx[1], idx[2], idx[3], pg_next[0], pg_next[1], pg_next[2], pg_next[3]);
-  };
-  const bool same_layout = a.k_page_stride == a.v_page_stride && a.k_slot_stride == a.v_slot_stride;  // K/V = two views of one cache
-  const bool page16 = a.page_shift == 4;
+  // block-table entries, 64 at a time in a VGPR (lane l = entry chunk*64 + l), one chunk ahead;
+  // picked with v_readlane: no scalar-cache round trip inside the loop
+  const int last_entry = (last_group << 4) >> a.page_shift;
+  int bt_chunk = 0;
+  int bt_cur = bt[min(lane, last_entry)];
+  int bt_nxt = bt[min(64 + lane, last_entry)];
   const uint32_t k_page_bytes = a.k_page_stride * 2, v_page_bytes = a.v_page_stride * 2;
-  auto issue_dma = [&](int tile, char* stage) {   // uses pg_next (this tile's pages)
-    if (tile * 4 + 3 <= last_group && tile * kTileN + kTileN <= seq_len && same_layout && page16) {
-      // common case, minimal scalar work: group = page, one 64-bit offset per page shared by K and V
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint64_t off = (uint64_t)(uint32_t)pg_next[i] * k_page_bytes;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + off + k_voff),
-                                         (__attribute__((address_space(3))) void*)(stage + lds_wave + i * 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + off + v_voff),
-                                         (__attribute__((address_space(3))) void*)(stage + KBUF + lds_wave + i * 4096), 16, 0, 0);
-      }
-      return;
+  auto dma_begin = [&](int tile) {          // call once per tile before its pieces
+    const int e0 = (min(tile * 4, last_group) << 4) >> a.page_shift;
+    if ((e0 >> 6) != bt_chunk) {            // wave-uniform; entries only ever move forward
+      bt_chunk = e0 >> 6;
+      bt_cur = bt_nxt;
+      bt_nxt = bt[min((bt_chunk + 1) * 64 + lane, last_entry)];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gi = min(tile * 4 + i, last_group);
-      const int key0 = gi << 4;
-      const int slot0 = key0 & page_mask;
-      uint32_t kvo = k_voff, vvo = v_voff;
-      if (key0 + 16 > seq_len) {          // wave-uniform: the sequence ends inside this group -> rows past it
+  };
+  // piece i of a tile = 16-key group i: one K and one V LDS-DMA per lane (1 KiB each per wave)
+  auto dma_piece = [&](int tile, char* stage, int i) {
+    const int gi = min(tile * 4 + i, last_group);
+    const int key0 = gi << 4;
+    const int slot0 = key0 & page_mask;
+    const int page = __builtin_amdgcn_readlane(bt_cur, (key0 >> a.page_shift) & 63);
+    uint32_t kvo = k_voff, vvo = v_voff;
+    if (key0 + 16 > seq_len) {            // wave-uniform: the sequence ends inside this group -> rows past it
                                           // fetch its last row instead (never stale cache contents)
-        const int r = min(rowin, max(seq_len - 1 - key0, 0));
-        kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
-        vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
-      }
-      const char* kp = kbase + ((uint64_t)(uint32_t)pg_next[i] * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2);
-      const char* vp = vbase + ((uint64_t)(uint32_t)pg_next[i] * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + kvo),
-                                       (__attribute__((address_space(3))) void*)(stage + lds_wave + i * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + vvo),
-                                       (__attribute__((address_space(3))) void*)(stage + KBUF + lds_wave + i * 4096), 16, 0, 0);
+      const int r = min(rowin, max(seq_len - 1 - key0, 0));
+      kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
+      vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
     }
+    const char* kp = kbase + ((uint64_t)(uint32_t)page * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2);
+    const char* vp = vbase + ((uint64_t)(uint32_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2);
+    glds16(kp + kvo, lds_addr(stage) + lds_wave + i * 4096);
+    glds16(vp + vvo, lds_addr(stage) + KBUF + lds_wave + i * 4096);
+  };
+  auto issue_dma = [&](int tile, char* stage) {
+    dma_begin(tile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(tile, stage, i);
   };
 
   // ---- per-lane LDS read addresses (swizzle folded in) ---------------------------------------------
@@ -582,11 +577,8 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
 
-  if (tile_hi > 0) {
-    lookup_pages(0);
-    issue_dma(0, smem);
-    if (tile_hi > 1) lookup_pages(1);
-  }
+  if (tile_hi > 0) issue_dma(0, smem);
+  glds_wait_all();
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
   __syncthreads();
@@ -595,10 +587,17 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
 #endif
 
-  auto compute_tile = [&](int tile, const char* stage) {
+  // `prefetch`: issue the NEXT tile's LDS-DMA pieces from inside the Q.K^T MFMA stream (an LDS-DMA
+  // instruction costs the issuing wave ~100+ cycles when issued in a burst, far less between MFMAs)
+  auto compute_tile = [&](int tile, const char* stage, char* next_stage, bool prefetch) {
     const int key_base = tile * kTileN;
+    if (prefetch) dma_begin(tile + 1);
     // ---- S^T - m_ref = K . Q'^T + cinit --------------------------------------------------------------
     pf32x16_t s_acc[2];
+#ifdef MI355_ABLATE_QK
+    s_acc[0] = cinit; s_acc[1] = cinit;
+    asm volatile("" : "+v"(s_acc[0]), "+v"(s_acc[1]));
+#else
     pu32x4_t kf[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const pu32x4_t*)(stage + k_rd[ks]);
@@ -609,17 +608,30 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
       kf[ks] = *(const pu32x4_t*)(stage + 32 * ROWB + k_rd[ks]);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#ifndef MI355_ABLATE_DMA
+      if (prefetch && (ks & 1)) {
+        dma_piece(tile + 1, next_stage, ks >> 1);
+      }
+#endif
     }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       s_acc[1] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], ks == 0 ? cinit : s_acc[1]);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
+#endif
 #ifdef MI355_PROFILE_PHASES
     asm volatile("" :: "v"(s_acc[1][0]));   // the stamp below waits for the QK chains, not just their issue
 #endif
     MI355_STAMP(1);
     // ---- softmax -------------------------------------------------------------------------------------
+#ifdef MI355_ABLATE_SOFTMAX
+    ps16x8_t pf[4];
+    asm volatile("" :: "v"(s_acc[0]), "v"(s_acc[1]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pu32x4_t w = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(w)); pf[i] = __builtin_bit_cast(ps16x8_t, w); }
+    l_run += 1.0f;
+#else
     const bool need_mask = (key_base + kTileN - 1 > ctx_len + w_tok_lo) || (key_base + kTileN > seq_len);
     if (need_mask) {
 #pragma unroll
@@ -674,8 +686,12 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
       }
     }
     l_run += psum;
+#endif
     MI355_STAMP(2);
     // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
+#ifdef MI355_ABLATE_PV
+    asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
+#else
     // fragments are assembled at read time (both halves written straight into one 4-VGPR operand)
     ps16x8_t vfr[2][4];
     auto read_v_block = [&](int b, ps16x8_t (&dst)[4]) {
@@ -698,6 +714,7 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
         if (b + 1 < DBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
     }
+#endif
 #ifdef MI355_PROFILE_PHASES
     asm volatile("" :: "v"(o_acc[DBLK - 1][0]));
 #endif
@@ -712,17 +729,23 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
       if (t < tile_hi) {
         char* cur = smem + u * STAGE;
         char* nxt = smem + (u ^ 1) * STAGE;
-        if (t + 1 < tile_hi) {
-          issue_dma(t + 1, nxt);
-          if (t + 2 < tile_hi) lookup_pages(t + 2);
-        }
+        const bool more = t + 1 < tile_hi;
         MI355_STAMP(0);
-        if (wave_has_rows && t * kTileN < wave_keys) compute_tile(t, cur);
+        if (wave_has_rows && t * kTileN < wave_keys) {
+          compute_tile(t, cur, nxt, more);
+        } else {
+#ifndef MI355_ABLATE_DMA
+          if (more) issue_dma(t + 1, nxt);   // this wave has no rows left for the tile but still stages its share
+#endif
+        }
 #ifdef MI355_PROFILE_PHASES
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MI355_STAMP(4);
 #endif
-        __syncthreads();     // DMA of tile t+1 has landed (vmcnt(0) is part of it) and stage `cur` is free
+        glds_wait_all();     // this wave's pieces of tile t+1 have landed ...
+#ifndef MI355_ABLATE_BARRIER
+        __syncthreads();     // ... and so have everyone else's; stage `cur` is free
+#endif
         MI355_STAMP(5);
       }
     }
@@ -833,10 +856,10 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   }
   const bool bf = p.q_dtype == MI355_BF16;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
-  // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), v2 (LDS-DMA, 32 rows/wave); default = 64 rows/wave
+  // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), w64 (64 rows/wave, one wave per SIMD); default = LDS-DMA, 32 rows/wave
   static const char* variant = getenv("MI355_PREFILL");
-  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', v2 = variant && variant[0] == 'v' && variant[1] == '2';
-  if (!v1 && !v2 && prefill_w64_applicable(p)) return launch_prefill_w64(p, stream);
+  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', w64 = variant && variant[0] == 'w';
+  if (w64 && prefill_w64_applicable(p)) return launch_prefill_w64(p, stream);
   if (!feat && p.head_size == 128 && !v1) return bf ? launch_prefill_dma<bf16_t>(p, stream) : launch_prefill_dma<f16_t>(p, stream);
 #define MI355_PREFILL_CASE(DD)                                                                            \
   case DD:                                                                                                \

@@ -217,10 +217,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prefill_w64_kernel(const W64Arg
       }
       const char* kp = kbase + ((uint64_t)(uint32_t)page * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2);
       const char* vp = vbase + ((uint64_t)(uint32_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + kvo),
-                                       (__attribute__((address_space(3))) void*)(stage + lds_wave + i * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + vvo),
-                                       (__attribute__((address_space(3))) void*)(stage + KBUF + lds_wave + i * 4096), 16, 0, 0);
+      glds16(kp + kvo, lds_addr(stage) + lds_wave + i * 4096);
+      glds16(vp + vvo, lds_addr(stage) + KBUF + lds_wave + i * 4096);
     }
   };
 
@@ -256,12 +254,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prefill_w64_kernel(const W64Arg
   }
 
   if (tile_hi > 0) issue_dma(0, smem);
+  glds_wait_all();
   __syncthreads();
 
   auto compute_tile = [&](int tile, const char* stage) {
     const int key_base = tile * kW64Tile;
     // ---- S^T - m_ref = K . Q'^T + cinit, both sub-blocks per K fragment ---------------------------------
     wf32x16_t s_acc[2][2];   // [sub-block][32-key block]
+#ifdef MI355_ABLATE_QK
+    s_acc[0][0] = cinit[0]; s_acc[0][1] = cinit[0]; s_acc[1][0] = cinit[1]; s_acc[1][1] = cinit[1];
+#else
     wu32x4_t kf[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const wu32x4_t*)(stage + k_rd[ks]);
@@ -286,12 +288,22 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prefill_w64_kernel(const W64Arg
         amma<T>::acc_s(s_acc[1][1], kf[ks], qf[1][ks]);
       }
     }
+#endif
     mfma_settle_v(s_acc[0][0], s_acc[0][1], s_acc[1][0], s_acc[1][1]);
-    // ---- softmax, per sub-block -------------------------------------------------------------------------
-    const bool need_mask = (key_base + kW64Tile - 1 > ctx_len + w_tok_lo) || (key_base + kW64Tile > seq_len);
-    ws16x8_t pf[2][4];
+    // ---- all 16 transposed V fragments of the tile are requested now and kept in registers: they
+    //      land while the VALU does sub-block A's softmax, feed P.V of A and are reused for B ------------
+    ws16x8_t vfr[16];   // [4*b + sk]
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
+    for (int j = 0; j < 16; ++j) {
+      const int b = j >> 2, sk = j & 3;
+      const ws16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4_t*)(stage + sk * 16 * ROWB + v_rd0[b]));
+      const ws16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4_t*)(stage + sk * 16 * ROWB + v_rd1[b]));
+      vfr[j] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    // ---- softmax ----------------------------------------------------------------------------------------
+    const bool need_mask = (key_base + kW64Tile - 1 > ctx_len + w_tok_lo) || (key_base + kW64Tile > seq_len);
+    // mask, running-max check and (rarely) the move of the reference max for one sub-block
+    auto settle_rows = [&](int sb) {
       if (need_mask) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -326,36 +338,57 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prefill_w64_kernel(const W64Arg
 #pragma unroll
           for (int r = 0; r < 16; ++r) o_acc[sb][b][r] *= alpha;
       }
-      float psum = 0.0f;
+    };
+    // P dword j of a sub-block = exp2 of S registers (kb = j>>3, r = 2(j&7), r+1), bf16-packed
+    uint32_t pw[2][16];
+    float psum[2] = {0.0f, 0.0f};
+    auto exp_step = [&](int sb, int j) {
+      const int kb = j >> 3, r = 2 * (j & 7);
+#ifdef MI355_ABLATE_SOFTMAX
+      asm volatile("" :: "v"(s_acc[sb][kb][r]), "v"(s_acc[sb][kb][r + 1]));
+      pw[sb][j] = 0x3c003c00u;
+#else
+      const float e0 = __builtin_amdgcn_exp2f(s_acc[sb][kb][r]), e1 = __builtin_amdgcn_exp2f(s_acc[sb][kb][r + 1]);
+      psum[sb] += e0 + e1;
+      pw[sb][j] = wmma<T>::pack2(e0, e1);
+#endif
+    };
+    auto pfrag = [&](int sb, int sk) {   // B operand of k-step sk (16 keys) of P.V
+      return __builtin_bit_cast(ws16x8_t, wu32x4_t{pw[sb][4 * sk], pw[sb][4 * sk + 1], pw[sb][4 * sk + 2], pw[sb][4 * sk + 3]});
+    };
+
+    // phase 2: sub-block A's softmax (VALU alone; the V reads above land underneath)
+    settle_rows(0);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        float e[16];
+    for (int j = 0; j < 16; ++j) exp_step(0, j);
+    l_run[0] += psum[0];
+    ws16x8_t pfa[4] = {pfrag(0, 0), pfrag(0, 1), pfrag(0, 2), pfrag(0, 3)};
+    // sub-block B: mask / max check now, its exponentials ride in the MFMA gaps of phase 3
+    settle_rows(1);
+    valu_to_mfma_pad(pfa[0], pfa[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 3: O_A^T += V^T . P_A^T (16 MFMAs) with B's 32 exp2 + sums + packs between them
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          e[r] = __builtin_amdgcn_exp2f(s_acc[sb][kb][r]);
-          psum += e[r];
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const wu32x4_t w = {wmma<T>::pack2(e[8 * s + 0], e[8 * s + 1]), wmma<T>::pack2(e[8 * s + 2], e[8 * s + 3]),
-                              wmma<T>::pack2(e[8 * s + 4], e[8 * s + 5]), wmma<T>::pack2(e[8 * s + 6], e[8 * s + 7])};
-          pf[sb][2 * kb + s] = __builtin_bit_cast(ws16x8_t, w);
-        }
-      }
-      l_run[sb] += psum;
+    for (int j = 0; j < 16; ++j) {
+#ifndef MI355_ABLATE_PV
+      amma<T>::acc_o(o_acc[0][j >> 2], vfr[j], pfa[j & 3]);
+#else
+      asm volatile("" :: "v"(vfr[j]), "v"(pfa[j & 3]));
+#endif
+      exp_step(1, j);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- O^T += V^T . P^T, both sub-blocks per V fragment ------------------------------------------------
-    valu_to_mfma_pad(pf[0][3], pf[1][3]);
+    l_run[1] += psum[1];
+    ws16x8_t pfb[4] = {pfrag(1, 0), pfrag(1, 1), pfrag(1, 2), pfrag(1, 3)};
+    valu_to_mfma_pad(pfb[0], pfb[3]);
+    // phase 4: O_B^T += V^T . P_B^T from the same V fragments
 #pragma unroll
-    for (int b = 0; b < DBLK; ++b) {
-#pragma unroll
-      for (int sk = 0; sk < 4; ++sk) {
-        const ws16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4_t*)(stage + sk * 16 * ROWB + v_rd0[b]));
-        const ws16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4_t*)(stage + sk * 16 * ROWB + v_rd1[b]));
-        const ws16x8_t vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-        amma<T>::acc_o(o_acc[0][b], vf, pf[0][sk]);
-        amma<T>::acc_o(o_acc[1][b], vf, pf[1][sk]);
-      }
+    for (int j = 0; j < 16; ++j) {
+#ifndef MI355_ABLATE_PV
+      amma<T>::acc_o(o_acc[1][j >> 2], vfr[j], pfb[j & 3]);
+#else
+      asm volatile("" :: "v"(vfr[j]), "v"(pfb[j & 3]));
+#endif
     }
   };
 
@@ -367,9 +400,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prefill_w64_kernel(const W64Arg
       if (t < tile_hi) {
         char* cur = smem + u * STAGE;
         char* nxt = smem + (u ^ 1) * STAGE;
+#ifndef MI355_ABLATE_DMA
         if (t + 1 < tile_hi) issue_dma(t + 1, nxt);
+#endif
         if (wave_has_rows && t * kW64Tile < wave_keys) compute_tile(t, cur);
-        __syncthreads();     // DMA of tile t+1 has landed (vmcnt(0) is part of it) and stage `cur` is free
+        glds_wait_all();     // this wave's pieces of tile t+1 have landed ...
+#ifndef MI355_ABLATE_BARRIER
+        __syncthreads();     // ... and so have everyone else's; stage `cur` is free
+#endif
       }
     }
   }
