@@ -122,6 +122,22 @@ def cpu_baseline(w, out_gpu):
             "max_abs_diff_vs_gpu": err}
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/collect_traffic.py ->
+    profiles/r01/traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of the guide);
+    None when no profile of that kernel is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        for name, rec in json.load(open(path)).items():
+            if name.startswith(kernel_prefix):
+                return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,13 +199,13 @@ def main():
             "config": {"workload": "C2 prefill: Llama-3-8B shape Hq32/Hk8/D128, 1 seq x 4096 tokens per GPU, causal, paged KV (16-token pages)",
                        "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
             "roofline": {"bound": "mfma", "achieved": round(pf_ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(pf_ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "kernel": pf["kernel"],
+                         "frac": round(pf_ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": measured_traffic("prefill_dma_kernel"), "kernel": pf["kernel"],
                          "kernel_us": round(pf["per_launch"] * 1e6, 2), "algorithmic_flops_per_launch": pf["w"]["flops"]},
             "decode": {"metric": "KV GB/s (paged decode)", "value": round(dc_val, 1), "unit": "GB/s", "ms_per_step": round(dc["wall"] / K * 1e3, 4),
                        "config": {"workload": "C3 decode: Hq32/Hk8/D128, batch 64 x kv_len 8192 per GPU, bf16, 16-token pages",
                                   "global_batch": 64 * n_gpus, "kernel": dc["kernel"]},
                        "roofline": {"bound": "hbm", "achieved": round(dc_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(dc_ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dc["kernel"],
+                                    "frac": round(dc_ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic("decode_splitkv_kernel"), "kernel": dc["kernel"],
                                     "kernel_us": round(dc["per_launch"] * 1e6, 2), "algorithmic_bytes_per_launch": dc["w"]["bytes"]}},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
