@@ -149,7 +149,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product")
     device = torch.device("cuda", local_rank)
