@@ -140,6 +140,9 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
 template <typename T, typename KVT, int D, int WAVES, bool FEAT>
 __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const DecodeArgs a) {
   constexpr bool FP8 = !__is_same(T, KVT);
+  // tiles in flight HBM -> VGPR per wave: an fp8 tile is half the bytes of a 16-bit one, so two of
+  // them are kept in flight to put the same number of bytes on the wire per CU
+  constexpr int PF = (FP8 && D <= 128) ? 2 : 1;
   constexpr int KVB = FP8 ? 1 : 2;                  // bytes per cache element
   constexpr int PPR = D * KVB / 16;                 // 16-byte pieces per key row in HBM
   constexpr int NLD = (16 * PPR) / 64;              // row-shaped loads per 16-key group per lane
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     int d0, d1;
     scalar_load4(bt, i0, i1, i0, i1, pg[0], pg[1], d0, d1);
   };
-  u32x4_t kreg[2][NLD], vreg[2][NLD];
-  auto issue_loads = [&](int tile) {       // uses pg[], which must hold this tile's pages
+  u32x4_t kreg[PF][2][NLD], vreg[PF][2][NLD];
+  auto issue_loads = [&](int tile, u32x4_t (&KR)[2][NLD], u32x4_t (&VR)[2][NLD]) {   // uses pg[] = this tile's pages
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int gi = min(tile * 2 + h, last_group);
@@ -240,8 +243,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       const kv_elem_t* vp = vbase + ((uint64_t)(uint32_t)pg[h] * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        kreg[h][i] = *(const u32x4_t*)(kp + k_toff[i]);
-        vreg[h][i] = *(const u32x4_t*)(vp + v_toff[i]);
+        KR[h][i] = *(const u32x4_t*)(kp + k_toff[i]);
+        VR[h][i] = *(const u32x4_t*)(vp + v_toff[i]);
       }
     }
   };
@@ -263,31 +266,35 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   for (int b = 0; b < DBLK; ++b) o_acc[b] = f32x4_t{0, 0, 0, 0};
 
   lookup_pages(t0);
-  issue_loads(t0);
-  if (t0 + 1 < t1) lookup_pages(t0 + 1);
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (t0 + u < t1) {
+      issue_loads(t0 + u, kreg[u], vreg[u]);
+      if (t0 + u + 1 < t1) lookup_pages(t0 + u + 1);
+    }
 #pragma unroll
   for (int c = 0; c < KSTEPS; ++c) asm volatile("" : "+v"(qf[c]));   // retire the Q loads before the loop (see prefill kernel)
 
-  for (int tile = t0; tile < t1; ++tile) {
-    // ---- park the current tile's rows in LDS, then refill the registers with the next tile ------
+  auto tile_body = [&](int tile, u32x4_t (&KR)[2][NLD], u32x4_t (&VR)[2][NLD]) {
+    // ---- park the current tile's rows in LDS, then refill the registers with a later tile --------
     u32x4_t kcur[2][NLD];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) kcur[h][i] = kreg[h][i];
+      for (int i = 0; i < NLD; ++i) kcur[h][i] = KR[h][i];
     const bool tail = (tile * kTileKeys + kTileKeys > n_keys);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        u32x4_t v = vreg[h][i];
+        u32x4_t v = VR[h][i];
         // rows past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
         if (tail && (tile * kTileKeys + h * 16 + ld_row[i] >= n_keys)) v = u32x4_t{0, 0, 0, 0};
         park(v_lds, h * 16 + ld_row[i], ld_piece[i], v);
       }
-    if (tile + 1 < t1) {
-      issue_loads(tile + 1);
-      if (tile + 2 < t1) lookup_pages(tile + 2);
+    if (tile + PF < t1) {
+      issue_loads(tile + PF, KR, VR);
+      if (tile + PF + 1 < t1) lookup_pages(tile + PF + 1);
     }
 
     // ---- S^T = K . Q^T, one 16-key group at a time through the K buffer --------------------------
@@ -368,6 +375,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       }
       o_acc[b] = mma<T>::run(vf, pf, o_acc[b]);
     }
+  };
+
+  for (int tile = t0; tile < t1; tile += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (tile + u < t1) tile_body(tile + u, kreg[u], vreg[u]);
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
