@@ -180,6 +180,10 @@ MI355_API const char* mi355_last_kernel(void);
  * Bytes of scratch mi355_unified_attention needs for these parameters (host-side arithmetic only;
  * depends on sizes and upper bounds, never on device data, so it is capture-stable).
  * Replaces the three per-call torch.empty scratch tensors at triton_unified_attention.py:950-971.
+ * The workspace must be ZERO-FILLED ONCE by its owner after allocation: its first 256 KiB hold the
+ * arrival counters of the in-kernel split merge, which every call leaves at zero again (a call
+ * that was aborted mid-kernel does not: zero-fill again after a device error). One workspace
+ * serves one stream at a time.
  */
 MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
 

@@ -95,8 +95,10 @@ def test_workspace_bytes_is_host_arithmetic(lib):
     p.v_stride_page, p.v_stride_slot, p.v_stride_head, p.v_stride_d = 16384, 1024, 128, 1
     p.block_table_stride = 512
     n = h.mi355_attn_workspace_bytes(C.byref(p))
-    assert n > 0 and n % (64 * 32 * (128 + 2) * 4) == 0
-    splits = n // (64 * 32 * (128 + 2) * 4)
+    counters = 256 << 10                                      # fixed head region: arrival counters of the in-kernel merge
+    slot = (128 + 32) * 4                                     # partial output + (m, l), padded to a 128-byte multiple
+    assert n > counters and (n - counters) % (64 * 32 * slot) == 0
+    splits = (n - counters) // (64 * 32 * slot)
     assert 1 < splits <= 64
     p.max_seqlen_k = 16
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0          # single tile: no split, no scratch

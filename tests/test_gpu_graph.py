@@ -1,0 +1,62 @@
+"""-m gpu: the ops are HIP-graph capturable (no allocation, no sync, static launch grids): capture
+one decode step and one mixed step, then replay with new data in the same buffers."""
+
+import pytest
+import torch
+
+from oracle import paged_attention_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("query_lens,kv_lens", [([1] * 6, [300, 17, 2048, 1, 129, 700]), ([1, 40, 1, 129], [90, 70, 513, 400])])
+def test_unified_attention_and_cache_write_under_graph_capture(query_lens, kv_lens):
+    import gpu_util
+    from mi355_attn.kernels import reshape_and_cache_flash, unified_attention
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page = 16, 4, 128, 16
+    inp = orc.make_paged_inputs(41, query_lens, kv_lens, Hq, Hk, D, page, torch.bfloat16)
+    d = gpu_util.to_dev(inp)
+    T = sum(query_lens)
+    # the new tokens' K/V are written into the cache inside the graph, like a vLLM step does
+    slots = []
+    for i, (ql, kl) in enumerate(zip(query_lens, kv_lens)):
+        for j in range(kl - ql, kl):
+            slots.append(int(inp["block_table"][i, j // page]) * page + j % page)
+    slot_mapping = torch.tensor(slots, dtype=torch.int64, device=dev)
+    k_new = torch.zeros(T, Hk, D, dtype=torch.bfloat16, device=dev)
+    v_new = torch.zeros_like(k_new)
+    out = torch.zeros_like(d["q"])
+
+    def step():
+        reshape_and_cache_flash(k_new, v_new, d["k_cache"], d["v_cache"], slot_mapping, "auto", None, None)
+        unified_attention(q=d["q"], k=d["k_cache"], v=d["v_cache"], out=out, cu_seqlens_q=d["cu_seqlens_q"], max_seqlen_q=max(query_lens),
+                          seqused_k=d["seqused_k"], max_seqlen_k=max(kv_lens), avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=inp["scale"],
+                          causal=True, window_size=(-1, -1), block_table=d["block_table"], softcap=0, q_descale=None, k_descale=None,
+                          v_descale=None)
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()                       # warm-up outside the capture: sizes the workspace, sets kernel attributes
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        step()
+    # replay twice with fresh data written into the SAME buffers
+    for seed in (1, 2):
+        g = torch.Generator().manual_seed(seed)
+        q2 = (torch.rand(T, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+        kn = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+        vn = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+        d["q"].copy_(q2.to(dev)); k_new.copy_(kn.to(dev)); v_new.copy_(vn.to(dev))
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        kc, vc = d["k_cache"].cpu(), d["v_cache"].cpu()
+        ref = orc.unified_attention_oracle(q2, kc, vc, inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"])
+        assert not torch.isnan(out).any()
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+        # the cache really holds the tokens written inside the graph
+        flat_k = kc.view(-1, Hk, D)
+        assert torch.equal(flat_k[torch.tensor(slots)].view(torch.int16), kn.view(torch.int16))

@@ -203,6 +203,24 @@ __device__ __forceinline__ void scalar_load4(const int32_t* base, int i0, int i1
       : "memory");
 }
 
+// One word at `w` and two words of `base` in the same scalar round trip (all wave-uniform).
+__device__ __forceinline__ void scalar_load_word_and_pair(const int32_t* w, const int32_t* base, int i0, int i1, int& rw, int& r0, int& r1) {
+  const int o0 = __builtin_amdgcn_readfirstlane(i0 * 4), o1 = __builtin_amdgcn_readfirstlane(i1 * 4);
+  const uint64_t b = (uint64_t)base, ww = (uint64_t)w;
+  // readfirstlane returns int: take each half through uint32_t or the low half sign-extends into the high one
+  const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint32_t wlo = __builtin_amdgcn_readfirstlane((uint32_t)ww), whi = __builtin_amdgcn_readfirstlane((uint32_t)(ww >> 32));
+  const uint64_t bu = ((uint64_t)bhi << 32) | blo, wu = ((uint64_t)whi << 32) | wlo;
+  asm volatile(
+      "s_load_dword %0, %3, 0x0\n\t"
+      "s_load_dword %1, %4, %5\n\t"
+      "s_load_dword %2, %4, %6\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(rw), "=&s"(r0), "=&s"(r1)
+      : "s"(wu), "s"(bu), "s"(o0), "s"(o1)
+      : "memory");
+}
+
 // One LDS-DMA piece: every lane fetches 16 bytes from its own global address and the wave's 1 KiB
 // lands contiguously at LDS byte address `lds_dst` (wave-uniform) + lane*16.
 // Issued through inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) orders every later

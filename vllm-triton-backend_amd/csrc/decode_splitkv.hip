@@ -31,6 +31,7 @@
 // In `only_decodes` mode the grid runs over SEQUENCES (one query token each), which is how a mixed
 // batch hands its decode rows to this kernel without paying for its prefill tokens.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -46,17 +47,25 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 constexpr int kTileKeys = 32;
+constexpr int kMaxSplits = 64;
+constexpr int kSlotPad = 32;   // floats appended to a D-float partial (m, l, padding to a 128-byte multiple)
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct DecodeArgs {
   mi355_attn_params p;
-  float* ws_acc;   // [(token*Hq + hq)*num_splits + split][D]   un-normalised partial outputs
-  float2* ws_ml;   // same index: (running max in log2 domain, partial sum)
+  // split-KV scratch: slot (token*Hq + hq)*num_splits + split = kSlotPad+D floats: un-normalised
+  // partial output [0,D), running max in the log2 domain [D], partial sum [D+1]; slots are multiples
+  // of 128 bytes so that no cache line is shared between the partials of different merge groups
+  float* ws_slots;
+  int* ws_cnt;     // [units*Hk] arrival counters of the in-kernel merge; zero on entry, zero on exit
+  uint32_t ws_slot_bytes_total;
+  int fused_merge; // 1: the last-arriving split of a (unit, KV head) merges in the kernel, no second launch
   int num_splits;
   int tiles_per_split;
   int group;       // G = Hq / Hk
   int page_shift;  // log2(page_size)
   int by_seq;      // 1: work items enumerate sequences (only_decodes), 0: query tokens
+  int unit_is_seq; // 1: every sequence has exactly one query token (max_seqlen_q == 1), so unit == token == sequence
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated on the host
 };
 
@@ -166,14 +175,53 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const int head = item % Hk;
   const int rest = item / Hk;
   const int split = rest % a.num_splits;
-  const RowInfo ri = row_info(p, a.by_seq, rest / a.num_splits);
-  if (!ri.valid) return;
-  const int token = ri.token, n_keys = ri.n_keys, first_key = ri.first_key, ctx_len = ri.ctx_len;
-
+  const int unit = rest / a.num_splits;
   const int G = a.group;
   const int g = lane & 15, grp = lane >> 4;
   const bool g_ok = g < G;
   const int hq = head * G + g;
+
+  // ---- Q fragments: B operand of S^T = K.Q^T: lane (g, grp) holds Q[g][32c + 8grp .. +7] --------
+  s16x8_t qf[KSTEPS];
+  auto load_q = [&](int tok) {   // issued as early as the token is known: rides the same round trip as the lookups
+    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)tok * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * grp;
+#pragma unroll
+    for (int c = 0; c < KSTEPS; ++c) {
+      u32x4_t v = {0, 0, 0, 0};
+      if (g_ok) v = *(const u32x4_t*)(qp + 32 * c);
+      qf[c] = __builtin_bit_cast(s16x8_t, v);
+    }
+  };
+
+  // Every dependent memory round trip ahead of the first K/V load costs a wave ~2 us on an idle chip
+  // and several times that when the chip is streaming, with none of its bytes in flight meanwhile.
+  // A pure decode batch (unit == token == sequence) therefore takes ONE scalar round trip for the
+  // sequence length AND the first tile's two block-table entries (looked up before the length is
+  // known, inside the row's first cdiv(max_seqlen_k, page) entries); the general path searches
+  // cu_seqlens_q first.
+  RowInfo ri;
+  int pg_first[2] = {0, 0};
+  const bool fast_head = !FEAT && a.unit_is_seq;
+  if (fast_head) {
+    if (unit >= p.num_seqs || p.skip_decodes) return;
+    load_q(unit);
+    const int t0s = split * a.tiles_per_split;
+    const int last_blk = ((p.max_seqlen_k + p.page_size - 1) >> a.page_shift) - 1;
+    int seq_len;
+    scalar_load_word_and_pair(p.seqused_k + unit, p.block_table + (int64_t)unit * p.block_table_stride,
+                              min((t0s * 2 * 16) >> a.page_shift, last_blk), min(((t0s * 2 + 1) * 16) >> a.page_shift, last_blk),
+                              seq_len, pg_first[0], pg_first[1]);
+    ri.token = ri.seq = unit;
+    ri.q_len = 1; ri.q_pos = 0; ri.first_key = 0;
+    ri.ctx_len = seq_len - 1;
+    ri.n_keys = max(0, seq_len);
+    ri.valid = true;
+  } else {
+    ri = row_info(p, a.by_seq, unit);
+    if (!ri.valid) return;
+    load_q(ri.token);
+  }
+  const int token = ri.token, n_keys = ri.n_keys, first_key = ri.first_key, ctx_len = ri.ctx_len;
 
   const int tile_lo = first_key / kTileKeys;
   const int tile_hi = (n_keys + kTileKeys - 1) / kTileKeys;
@@ -181,24 +229,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const int t1 = min(t0 + a.tiles_per_split, tile_hi);
   const bool direct = a.num_splits == 1;
   if (t0 >= t1) {
-    if (direct && g_ok) {  // no visible key at all: the reference returns acc/L = 0/1 = 0
+    if (split == 0 && g_ok) {  // no visible key at all (no split has a tile): the reference returns acc/L = 0/1 = 0
       const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
 #pragma unroll
       for (int b = 0; b < DBLK; ++b) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) = u32x2_t{0, 0};
     }
     return;
-  }
-
-  // ---- Q fragments: B operand of S^T = K.Q^T: lane (g, grp) holds Q[g][32c + 8grp .. +7] --------
-  s16x8_t qf[KSTEPS];
-  {
-    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)token * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * grp;
-#pragma unroll
-    for (int c = 0; c < KSTEPS; ++c) {
-      u32x4_t v = {0, 0, 0, 0};
-      if (g_ok) v = *(const u32x4_t*)(qp + 32 * c);
-      qf[c] = __builtin_bit_cast(s16x8_t, v);
-    }
   }
 
   const float k_scale = (FP8 && p.k_scale) ? p.k_scale[0] : 1.0f;
@@ -265,7 +301,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
   for (int b = 0; b < DBLK; ++b) o_acc[b] = f32x4_t{0, 0, 0, 0};
 
-  lookup_pages(t0);
+  if (fast_head) {   // looked up with the sequence length; a second group past the sequence re-reads the first
+    pg[0] = pg_first[0];
+    pg[1] = (t0 * 2 + 1 > last_group) ? pg_first[0] : pg_first[1];
+  } else {
+    lookup_pages(t0);
+  }
 #pragma unroll
   for (int u = 0; u < PF; ++u)
     if (t0 + u < t1) {
@@ -385,30 +426,121 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 
   // ---- epilogue ----------------------------------------------------------------------------------
   const float l_tot = sum_over_lane_groups(l_run);
-  if (!g_ok) return;
   if (direct) {
+    if (!g_ok) return;
     const float inv = l_tot > 0.0f ? v_scale / l_tot : 0.0f;
     const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
       *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
           u32x2_t{mma<T>::pack2(o_acc[b][0] * inv, o_acc[b][1] * inv), mma<T>::pack2(o_acc[b][2] * inv, o_acc[b][3] * inv)};
-  } else {
-    const int64_t slot = ((int64_t)token * p.num_q_heads + hq) * a.num_splits + split;
-    float* dst = a.ws_acc + slot * D;
-#pragma unroll
-    for (int b = 0; b < DBLK; ++b) *(f32x4_t*)(dst + 16 * b + 4 * grp) = o_acc[b];
-    if (grp == 0) a.ws_ml[slot] = make_float2(m_run, l_tot);
+    return;
   }
+  // Partial -> workspace with WRITE-THROUGH (sc1) 16-byte stores: they are visible to every CU once
+  // this wave's vmcnt has drained, without a release fence (cdna_hip_programming.md, Guideline 16 R1).
+  constexpr int SLOT = D + kSlotPad;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ws_slots, 0, (int)a.ws_slot_bytes_total, 0x00020000);
+  const uint32_t slot_g0 = (uint32_t)(((uint32_t)token * p.num_q_heads + head * G) * a.num_splits);   // slot of (g = 0, split 0)
+  if (g_ok) {
+    const uint32_t so = ((slot_g0 + g * a.num_splits + split) * SLOT) * 4u;
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o_acc[b]), rsrc, so + (16 * b + 4 * grp) * 4, 0, 16);
+    if (grp == 0)
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(uint32_t, m_run), __builtin_bit_cast(uint32_t, l_tot)}, rsrc, so + D * 4, 0, 16);
+  }
+  if (!a.fused_merge) return;
+
+  // ---- in-kernel merge by the last-arriving split of this (unit, KV head) (reference: reduce_segments, :757-836)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains before it signals
+  const int n_tiles = max(0, tile_hi - tile_lo);
+  const int active = min(a.num_splits, (n_tiles + a.tiles_per_split - 1) / a.tiles_per_split);
+  int* cnt = a.ws_cnt + ((a.by_seq ? ri.seq : token) * Hk + head);
+  int ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != active - 1) return;
+  // All `active` partials are in memory; every load of them below is an sc1 load (bypasses this CU's
+  // L1, which may hold lines of an earlier launch). The compute layout leaves lanes g >= G idle, so
+  // the merge folds them in: lane (gm, sub, grp) walks splits sub, sub + NS, ... of head gm with all
+  // of a split's loads in flight at once, and the NS partial merges meet through xor shuffles.
+  // (m, l are two 4-byte loads: hipcc 7.2 narrows a raw_buffer_load_b64 whose halves are used apart
+  // to ONE dword and hands the same register out for both.)
+  const int Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // G rounded up to a power of two
+  const int NS = 16 / Gp;
+  const int gm = g & (Gp - 1), sub = g / Gp;
+  const bool gm_ok = gm < G;
+  float m_acc = -INFINITY, l_acc = 0.0f;
+  f32x4_t acc[DBLK];
+#pragma unroll
+  for (int b = 0; b < DBLK; ++b) acc[b] = f32x4_t{0, 0, 0, 0};
+  auto fold = [&](float m_in, float l_in, const f32x4_t (&v_in)[DBLK]) {
+    const float m_new = fmaxf(m_acc, m_in);
+    const float wa = m_acc == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m_acc - m_new);
+    const float wb = m_in == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m_in - m_new);
+    l_acc = l_acc * wa + l_in * wb;
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b) acc[b] = acc[b] * wa + v_in[b] * wb;
+    m_acc = m_new;
+  };
+  if (gm_ok) {
+    // U splits' loads are issued before the first is consumed: each is a ~1-2 us L2-miss round trip,
+    // so the serial chain is ceil(active / (NS*U)) trips. A split past `active` is given an offset
+    // beyond the descriptor's range (the load returns 0) and the weight of an empty partial.
+    constexpr int U = D >= 128 ? 2 : 4;
+    const uint32_t s0 = ((slot_g0 + gm * a.num_splits) * SLOT) * 4u;
+    for (int base = sub; base < active; base += NS * U) {
+      float m_in[U], l_in[U];
+      f32x4_t v_in[U][DBLK];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int sidx = base + u * NS;
+        const uint32_t so = sidx < active ? s0 + (uint32_t)sidx * (SLOT * 4u) : 0x80000000u;
+        m_in[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, so + D * 4, 0, 16));
+        l_in[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, so + D * 4 + 4, 0, 16));
+#pragma unroll
+        for (int b = 0; b < DBLK; ++b)
+          v_in[u][b] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (16 * b + 4 * grp) * 4, 0, 16));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) fold(base + u * NS < active ? m_in[u] : -INFINITY, l_in[u], v_in[u]);
+    }
+  }
+  for (int off = Gp; off < 16; off <<= 1) {
+    const float m_in = __shfl_xor(m_acc, off), l_in = __shfl_xor(l_acc, off);
+    f32x4_t v_in[DBLK];
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v_in[b][r] = __shfl_xor(acc[b][r], off);
+    fold(m_in, l_in, v_in);
+  }
+  if (gm_ok && sub == 0) {
+    const float inv = l_acc > 0.0f ? v_scale / l_acc : 0.0f;              // "0 if the overall sum is 0" (:828)
+    const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)(head * G + gm) * p.out_stride_head;
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b)
+      *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
+          u32x2_t{mma<T>::pack2(acc[b][0] * inv, acc[b][1] * inv), mma<T>::pack2(acc[b][2] * inv, acc[b][3] * inv)};
+  }
+  if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counter zero for the next call
 }
 
-// Merge of the split partials (reference: reduce_segments, :757-836). One wave per (unit, query
-// head): the 64 lanes split as (split-parity, 16-byte column chunk) so that the partial rows are
-// read as full-width 16-byte loads, several splits at a time.
+// Merge of the split partials in a launch of its own (reference: reduce_segments, :757-836), used
+// when a (unit, KV head) has more splits than the in-kernel merge reads in one round trip. One
+// 256-thread workgroup per (unit, query head): thread (r, col) owns the 16-byte column chunk `col`
+// of split rows r, r + R, ...; all of a thread's loads are issued before the first is consumed, so
+// the kernel is ONE memory round trip however many splits there are, then an LDS fold of R rows.
 template <typename T, bool FP8, int D>
-__global__ __launch_bounds__(64) void reduce_splits_kernel(const DecodeArgs a) {
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) {
+  constexpr int LPS = D / 4;               // lanes per split row (16, 32 or 64)
+  constexpr int R = 256 / LPS;             // split rows per pass
+  constexpr int NI = kMaxSplits / R;       // passes
+  constexpr int SLOT = D + kSlotPad;
+  __shared__ __attribute__((aligned(16))) float red[R][D + 4];   // folded columns, then (m, l)
+
   const mi355_attn_params& p = a.p;
-  const int hq = blockIdx.y, lane = threadIdx.x;
+  const int hq = blockIdx.y, tid = threadIdx.x;
   const RowInfo ri = row_info(p, a.by_seq, blockIdx.x);
   if (!ri.valid) return;
   const int tile_lo = ri.first_key / kTileKeys;
@@ -416,44 +548,52 @@ __global__ __launch_bounds__(64) void reduce_splits_kernel(const DecodeArgs a) {
   const int n_tiles = max(0, tile_hi - tile_lo);
   const int active = min(a.num_splits, (n_tiles + a.tiles_per_split - 1) / a.tiles_per_split);
   const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
+  const int r = tid / LPS, col = tid % LPS;
 
-  constexpr int CH = D / 4;               // 16-byte chunks per row (16, 32 or 64)
-  constexpr int LPS = CH < 64 ? CH : 64;  // lanes per split row
-  constexpr int SPW = 64 / LPS;           // split rows handled per pass
-  constexpr int CPL = CH / LPS;           // chunks per lane
-  const int sub = lane / LPS, col = lane % LPS;
-
-  const int64_t slot0 = ((int64_t)ri.token * p.num_q_heads + hq) * a.num_splits;
+  const float* slot0 = a.ws_slots + ((int64_t)ri.token * p.num_q_heads + hq) * a.num_splits * SLOT;
+  float m_in[NI], l_in[NI];
+  f32x4_t v_in[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int s = r + i * R;
+    const float* slot = slot0 + (s < active ? s : 0) * SLOT;   // a row past `active` re-reads row 0 with weight 0
+    m_in[i] = slot[D];
+    l_in[i] = slot[D + 1];
+    v_in[i] = ((const f32x4_t*)slot)[col];
+  }
+  float m_loc = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (r + i * R >= active) m_in[i] = -INFINITY;
+    m_loc = fmaxf(m_loc, m_in[i]);
+  }
+  float l_loc = 0.0f;
+  f32x4_t acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float w = m_in[i] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m_in[i] - m_loc);
+    l_loc += l_in[i] * w;
+    acc += v_in[i] * w;
+  }
+  *(f32x4_t*)&red[r][4 * col] = acc;
+  if (col == 0) { red[r][D] = m_loc; red[r][D + 1] = l_loc; }
+  __syncthreads();
+  if (r != 0) return;
   float m_all = -INFINITY;
-  for (int s = 0; s < active; ++s) m_all = fmaxf(m_all, a.ws_ml[slot0 + s].x);
-  float l_part = 0.0f;
-  f32x4_t acc[CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = f32x4_t{0, 0, 0, 0};
-  for (int s = sub; s < active; s += SPW) {
-    const float2 ml = a.ws_ml[slot0 + s];
-    const float w = __builtin_amdgcn_exp2f(ml.x - m_all);
-    l_part += ml.y * w;
-    const f32x4_t* src = (const f32x4_t*)(a.ws_acc + (slot0 + s) * D);
+  for (int rr = 0; rr < R; ++rr) m_all = fmaxf(m_all, red[rr][D]);
+  float l_all = 0.0f;
+  acc = f32x4_t{0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) acc[c] += src[col + c * LPS] * w;
+  for (int rr = 0; rr < R; ++rr) {
+    const float m_r = red[rr][D];
+    const float w = m_r == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m_r - m_all);
+    l_all += red[rr][D + 1] * w;
+    acc += *(const f32x4_t*)&red[rr][4 * col] * w;
   }
-  // fold the SPW partial sums (lanes col, col+LPS, ...)
-#pragma unroll
-  for (int o = LPS; o < 64; o <<= 1) {
-    l_part += __shfl_xor(l_part, o, 64);
-#pragma unroll
-    for (int c = 0; c < CPL; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[c][e] += __shfl_xor(acc[c][e], o, 64);
-  }
-  if (sub != 0) return;
-  const float inv = l_part > 0.0f ? v_scale / l_part : 0.0f;  // "0 if the overall sum is 0" (:828)
+  const float inv = l_all > 0.0f ? v_scale / l_all : 0.0f;  // "0 if the overall sum is 0" (:828)
   uint16_t* op = (uint16_t*)p.out + (int64_t)ri.token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
-#pragma unroll
-  for (int c = 0; c < CPL; ++c)
-    *(u32x2_t*)(op + 4 * (col + c * LPS)) =
-        u32x2_t{mma<T>::pack2(acc[c][0] * inv, acc[c][1] * inv), mma<T>::pack2(acc[c][2] * inv, acc[c][3] * inv)};
+  *(u32x2_t*)(op + 4 * col) = u32x2_t{mma<T>::pack2(acc[0] * inv, acc[1] * inv), mma<T>::pack2(acc[2] * inv, acc[3] * inv)};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -500,9 +640,19 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
     want = (int)((target + base - 1) / base);
     want = std::min(want, std::max(1, max_tiles / 4));                  // keep each split >= 4 tiles (128 keys)
   }
-  want = std::max(1, std::min(want, std::min(max_tiles, 64)));
+  want = std::max(1, std::min(want, std::min(max_tiles, kMaxSplits)));
   const int tps = (max_tiles + want - 1) / want;
   return {(max_tiles + tps - 1) / tps, tps};
+}
+
+// Arrival counters of the in-kernel merge: a FIXED region at the head of the workspace, one int per
+// (query token | sequence, KV head). Fixed so that the counters of one call never land on bytes an
+// earlier call used for partials: the caller zero-fills the workspace once and every call leaves
+// the counters at zero. A batch with more (unit, KV head) pairs than fit merges in a second launch.
+constexpr size_t kCounterRegionBytes = 256 << 10;
+static size_t counters_bytes(const mi355_attn_params&) { return kCounterRegionBytes; }
+static bool counters_fit(const mi355_attn_params& p) {
+  return (size_t)std::max(p.num_tokens, p.num_seqs) * p.num_kv_heads * sizeof(int) <= kCounterRegionBytes;
 }
 
 size_t decode_workspace_bytes(const mi355_attn_params& p) {
@@ -513,7 +663,7 @@ size_t decode_workspace_bytes(const mi355_attn_params& p) {
   const int splits = std::max(plan_splits(p).num_splits, plan_splits(alt).num_splits);
   if (splits == 1) return 0;
   const size_t slots = (size_t)p.num_tokens * p.num_q_heads * splits;
-  return slots * p.head_size * sizeof(float) + slots * sizeof(float2);
+  return counters_bytes(p) + slots * (p.head_size + kSlotPad) * sizeof(float);
 }
 
 template <typename T, typename KVT, int D, bool FEAT>
@@ -528,19 +678,35 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.group = p.num_q_heads / p.num_kv_heads;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
   a.by_seq = p.only_decodes ? 1 : 0;
+  a.unit_is_seq = (!p.only_decodes && p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) ? 1 : 0;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
-  a.ws_acc = nullptr;
-  a.ws_ml = nullptr;
+  a.ws_slots = nullptr;
+  a.ws_cnt = nullptr;
+  a.ws_slot_bytes_total = 0;
+  a.fused_merge = 0;
   if (sp.num_splits > 1) {
     const size_t slots = (size_t)p.num_tokens * p.num_q_heads * sp.num_splits;
-    const size_t need = slots * D * sizeof(float) + slots * sizeof(float2);
+    const size_t slot_bytes = slots * (D + kSlotPad) * sizeof(float);
+    const size_t need = counters_bytes(p) + slot_bytes;
     if (!ws || ws_bytes < need) {
       set_error("decode needs a %zu-byte workspace, got %zu", need, ws_bytes);
       return MI355_ERR_WORKSPACE;
     }
-    a.ws_acc = (float*)ws;
-    a.ws_ml = (float2*)((char*)ws + slots * D * sizeof(float));
+    if (slot_bytes >= (1ull << 31)) {
+      set_error("split-KV scratch of %zu bytes exceeds the 2 GiB buffer-descriptor range; pass fewer segments", slot_bytes);
+      return MI355_ERR_UNSUPPORTED;
+    }
+    a.ws_cnt = (int*)ws;
+    a.ws_slots = (float*)((char*)ws + counters_bytes(p));
+    a.ws_slot_bytes_total = (uint32_t)slot_bytes;
+    static const bool two_launch = getenv("MI355_DECODE_MERGE_KERNEL") != nullptr;   // A/B switch: separate merge launch
+    // in-kernel merge only where the last arriver reads its partials in ONE round trip (NS lanes x U
+    // loads in flight, see the kernel's epilogue); more splits than that merge faster in a launch of
+    // their own, which is one round trip at any split count
+    const int G = a.group, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));
+    const int one_trip = (16 / Gp) * (D >= 128 ? 2 : 4);
+    a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip) ? 0 : 1;
   }
   const long units = decode_units(p);
   if (units == 0) return MI355_OK;
@@ -550,8 +716,8 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
   if (rc != MI355_OK) return rc;
-  if (sp.num_splits > 1) {
-    hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D>), dim3((unsigned)units, p.num_q_heads), dim3(64), 0, stream, a);
+  if (sp.num_splits > 1 && !a.fused_merge) {
+    hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D>), dim3((unsigned)units, p.num_q_heads), dim3(256), 0, stream, a);
     rc = check_hip(hipGetLastError(), "reduce_splits_kernel launch");
   }
   if (rc == MI355_OK)

@@ -216,6 +216,8 @@ def workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
                 "mi355_attn workspace must be allocated before graph capture: run one eager call of "
                 "the largest shape first"
             )
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        # zero-filled once: the head of the workspace holds the split-merge arrival counters, which
+        # every call leaves at zero again (include/mi355_attn.h, mi355_attn_workspace_bytes)
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
