@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kvdtype", default="same", choices=["same", "fp8", "fp8_e5m2"])
+    ap.add_argument("--flush", default="write", choices=["write", "read", "none"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
@@ -49,10 +50,16 @@ def main():
         for _ in range(3):
             ua_mod.launch(p, dev)
         torch.cuda.synchronize()
-        flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        # Cold caches between launches. "write" is what triton.testing.do_bench does (zero a buffer)
+        # and leaves L2 + the 256 MB MALL full of DIRTY lines, whose write-back then competes with the
+        # timed kernel's reads for HBM; "read" sweeps a 1 GiB buffer instead (clean lines, same eviction).
+        flush = torch.zeros((1 << 30) if args.flush == "read" else (512 << 20), dtype=torch.uint8, device=dev)
         ts = []
         for _ in range(args.iters):
-            flush.zero_()
+            if args.flush == "write":
+                flush.zero_()
+            elif args.flush == "read":
+                flush.view(torch.int64).sum()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             ua_mod.launch(p, dev)

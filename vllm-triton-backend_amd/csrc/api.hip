@@ -67,7 +67,9 @@ static Path choose(const mi355_attn_params& p) {
   // mixed batch: prefill rows on the MFMA Q-block kernel, query_len == 1 rows on the split-KV kernel
   // (what the reference's legacy glue does with two kernels, chunked_prefill_paged_decode:28-117;
   // its unified 2D kernel instead pads every decode row to a BLOCK_M-row Q block)
-  if (pre_ok && dec_ok && p.num_seqs > 1 && !p.skip_decodes && !p.only_decodes) return Path::PrefillPlusDecode;
+  // (a batch whose sequences all carry max_seqlen_q tokens has no such row: host-known, no device read)
+  const bool uniform_prefill = (int64_t)p.num_seqs * p.max_seqlen_q == p.num_tokens;
+  if (pre_ok && dec_ok && p.num_seqs > 1 && !uniform_prefill && !p.skip_decodes && !p.only_decodes) return Path::PrefillPlusDecode;
   if (pre_ok) return Path::Prefill;
   if (dec_ok) return Path::Decode;
   return Path::Generic;
@@ -87,9 +89,17 @@ const char* mi355_last_kernel(void) { return g_kernel; }
 
 size_t mi355_attn_workspace_bytes(const mi355_attn_params* p) {
   if (!p || p->num_tokens <= 0 || p->num_seqs <= 0) return 0;
-  // sized for the split-KV path whenever that path could be taken, so that the answer does not
-  // depend on the dispatch decision
-  return decode_workspace_bytes(*p);
+  // follows the dispatch decision, which depends on host-known sizes only
+  if (validate(p) != MI355_OK) return 0;
+  switch (choose(*p)) {
+    case Path::Decode: return decode_workspace_bytes(*p);
+    case Path::PrefillPlusDecode: {
+      mi355_attn_params pd = *p;
+      pd.only_decodes = 1;
+      return decode_workspace_bytes(pd);
+    }
+    default: return 0;
+  }
 }
 
 int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,

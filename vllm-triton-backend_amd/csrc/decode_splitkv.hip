@@ -440,7 +440,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   // this wave's vmcnt has drained, without a release fence (cdna_hip_programming.md, Guideline 16 R1).
   constexpr int SLOT = D + kSlotPad;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ws_slots, 0, (int)a.ws_slot_bytes_total, 0x00020000);
-  const uint32_t slot_g0 = (uint32_t)(((uint32_t)token * p.num_q_heads + head * G) * a.num_splits);   // slot of (g = 0, split 0)
+  // slot rows are indexed by work unit: the query token, or the sequence when only decode rows are served
+  const uint32_t slot_g0 = (uint32_t)(((uint32_t)unit * p.num_q_heads + head * G) * a.num_splits);   // slot of (g = 0, split 0)
   if (g_ok) {
     const uint32_t so = ((slot_g0 + g * a.num_splits + split) * SLOT) * 4u;
 #pragma unroll
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains before it signals
   const int n_tiles = max(0, tile_hi - tile_lo);
   const int active = min(a.num_splits, (n_tiles + a.tiles_per_split - 1) / a.tiles_per_split);
-  int* cnt = a.ws_cnt + ((a.by_seq ? ri.seq : token) * Hk + head);
+  int* cnt = a.ws_cnt + (unit * Hk + head);
   int ticket = 0;
   if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
   const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
   const int r = tid / LPS, col = tid % LPS;
 
-  const float* slot0 = a.ws_slots + ((int64_t)ri.token * p.num_q_heads + hq) * a.num_splits * SLOT;
+  const float* slot0 = a.ws_slots + ((int64_t)blockIdx.x * p.num_q_heads + hq) * a.num_splits * SLOT;   // row = work unit
   float m_in[NI], l_in[NI];
   f32x4_t v_in[NI];
 #pragma unroll
@@ -652,17 +653,14 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
 constexpr size_t kCounterRegionBytes = 256 << 10;
 static size_t counters_bytes(const mi355_attn_params&) { return kCounterRegionBytes; }
 static bool counters_fit(const mi355_attn_params& p) {
-  return (size_t)std::max(p.num_tokens, p.num_seqs) * p.num_kv_heads * sizeof(int) <= kCounterRegionBytes;
+  return (size_t)decode_units(p) * p.num_kv_heads * sizeof(int) <= kCounterRegionBytes;
 }
 
 size_t decode_workspace_bytes(const mi355_attn_params& p) {
   if (!decode_supported(p)) return 0;
-  // a mixed batch may send only its decode rows here: size for the larger of the two uses
-  mi355_attn_params alt = p;
-  alt.only_decodes = p.only_decodes ? 0 : 1;
-  const int splits = std::max(plan_splits(p).num_splits, plan_splits(alt).num_splits);
+  const int splits = plan_splits(p).num_splits;
   if (splits == 1) return 0;
-  const size_t slots = (size_t)p.num_tokens * p.num_q_heads * splits;
+  const size_t slots = (size_t)decode_units(p) * p.num_q_heads * splits;
   return counters_bytes(p) + slots * (p.head_size + kSlotPad) * sizeof(float);
 }
 
@@ -686,7 +684,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.ws_slot_bytes_total = 0;
   a.fused_merge = 0;
   if (sp.num_splits > 1) {
-    const size_t slots = (size_t)p.num_tokens * p.num_q_heads * sp.num_splits;
+    const size_t slots = (size_t)decode_units(p) * p.num_q_heads * sp.num_splits;
     const size_t slot_bytes = slots * (D + kSlotPad) * sizeof(float);
     const size_t need = counters_bytes(p) + slot_bytes;
     if (!ws || ws_bytes < need) {
