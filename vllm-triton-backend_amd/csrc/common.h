@@ -234,6 +234,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+// The 4-byte form: lane l's dword lands at `lds_dst` + 4*l (256 bytes per wave-instruction).
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;

@@ -427,12 +427,31 @@ constexpr float kDeferThr = 8.0f;
 #define MI355_STAMP(idx) do { } while (0)
 #endif
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a) {
+// Diagnostic build only (-DMI355_PROFILE_WG, tools/wg_profile.py): life of a workgroup in s_memtime ticks.
+#ifdef MI355_PROFILE_WG
+#define MI355_WG_STAMP(var)                                                                \
+  unsigned long long var;                                                                  \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define MI355_WG_STAMP(var) do { } while (0)
+#endif
+
+// NW waves of 32 rows share the staged K/V tiles (Q block = 32*NW rows), NST stages of 32 KiB.
+//   NW 4, NST 2: two workgroups per CU, each staging its own tiles (64 KiB of LDS-DMA per CU per tile round)
+//   NW 8, NST 3: one workgroup per CU, HALF the LDS-DMA bytes per MFMA and a two-tile-deep prefetch.
+// The kernel's floor is the per-CU global->LDS fill rate (~25 GB/s per CU, MI355X_MICROARCH.md
+// ldsdma-fill), not the matrix pipes: tools/phase_profile.py shows the waves waiting on their DMA.
+template <typename T, int NW, int NST>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(const PrefillArgs a) {
   constexpr int D = 128;
   constexpr int ROWB = D * 2;                 // 256-byte rows, 16 chunks of 16 B
   constexpr int KBUF = kTileN * ROWB, STAGE = 2 * KBUF;   // K tile then V tile
   constexpr int KSTEPS = D / 16, DBLK = D / 32;
+  constexpr int RP = 4 * NW;                  // key rows one LDS-DMA piece covers (all waves, 4 rows each)
+  constexpr int NP = kTileN / RP;             // pieces per tile: each is one K and one V instruction per wave
+  constexpr int PD = NST - 1;                 // prefetch distance in tiles
+  constexpr int IPT = 2 * NP;                 // LDS-DMA instructions per tile per wave
+  static_assert(NP >= 1 && KSTEPS % NP == 0, "piece interleave");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages
   const mi355_attn_params& p = a.p;
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.group, BQ = a.block_q;
+  MI355_WG_STAMP(wg_t0);
 
   const int head = (int)(blockIdx.x % p.num_kv_heads);
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);
@@ -502,50 +522,74 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
   const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
   const int page_mask = p.page_size - 1;
-  const int rowin = tid >> 4, ch = tid & 15;
-  const int fk = rowin & 15;
-  const int fv = ((rowin & 3) << 2) | ((rowin >> 2) & 3);
-  uint32_t k_voff = (uint32_t)(rowin * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
-  uint32_t v_voff = (uint32_t)(rowin * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
-  const uint32_t lds_wave = (uint32_t)(wave * 64 * 16);        // + i*4096 (+KBUF for V) + stage
+  const int rowin = tid >> 4, ch = tid & 15;      // row within a piece (0 .. RP-1), 16-byte chunk
+  const int rig = rowin & 15;                     // row within its 16-key group
+  const int grp_in_piece = __builtin_amdgcn_readfirstlane(rowin >> 4);   // wave-uniform: a wave's 4 rows share a group
+  const int fk = rig;
+  const int fv = ((rig & 3) << 2) | ((rig >> 2) & 3);
+  uint32_t k_voff = (uint32_t)(rig * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
+  uint32_t v_voff = (uint32_t)(rig * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
+  const uint32_t lds_wave = (uint32_t)(wave * 64 * 16);        // + i*RP*ROWB (+KBUF for V) + stage
 
-  // block-table entries, 64 at a time in a VGPR (lane l = entry chunk*64 + l), one chunk ahead;
-  // picked with v_readlane: no scalar-cache round trip inside the loop
   const int last_entry = (last_group << 4) >> a.page_shift;
-  int bt_chunk = 0;
-  int bt_cur = bt[min(lane, last_entry)];
-  int bt_nxt = bt[min(64 + lane, last_entry)];
   const uint32_t k_page_bytes = a.k_page_stride * 2, v_page_bytes = a.v_page_stride * 2;
+  // Block-table entries of this workgroup's keys.
+  //   NST == 2: 64 at a time in a VGPR (lane l = entry chunk*64 + l), one chunk ahead, picked with
+  //             v_readlane: no scalar-cache round trip inside the loop.
+  //   NST >= 3: the whole prefix is staged once in LDS behind the tile stages by LDS-DMA. A VGPR chunk
+  //             is a compiler-visible load carried round the loop: hipcc waits for it with vmcnt(0) at
+  //             every copy, which would also drain the tile that is meant to stay in flight.
+  constexpr bool BT_IN_LDS = NST >= 3;
+  const int* bt_lds = (const int*)(smem + NST * STAGE);
+  int bt_chunk = 0, bt_cur = 0, bt_nxt = 0;
+  if constexpr (BT_IN_LDS) {
+    for (int c = wave; c * 64 <= last_entry; c += NW) glds4(bt + min(c * 64 + lane, last_entry), lds_addr(bt_lds) + c * 256);
+    glds_wait_all();     // the first tiles' addresses come out of this table
+    __syncthreads();
+  } else {
+    bt_cur = bt[min(lane, last_entry)];
+    bt_nxt = bt[min(64 + lane, last_entry)];
+  }
   auto dma_begin = [&](int tile) {          // call once per tile before its pieces
-    const int e0 = (min(tile * 4, last_group) << 4) >> a.page_shift;
-    if ((e0 >> 6) != bt_chunk) {            // wave-uniform; entries only ever move forward
-      bt_chunk = e0 >> 6;
-      bt_cur = bt_nxt;
-      bt_nxt = bt[min((bt_chunk + 1) * 64 + lane, last_entry)];
+    if constexpr (!BT_IN_LDS) {
+      const int e0 = (min(tile * 4, last_group) << 4) >> a.page_shift;
+      if ((e0 >> 6) != bt_chunk) {            // wave-uniform; entries only ever move forward
+        bt_chunk = e0 >> 6;
+        bt_cur = bt_nxt;
+        bt_nxt = bt[min((bt_chunk + 1) * 64 + lane, last_entry)];
+      }
     }
   };
-  // piece i of a tile = 16-key group i: one K and one V LDS-DMA per lane (1 KiB each per wave)
+  // piece i of a tile = key rows RP*i .. RP*i+RP-1: one K and one V LDS-DMA per lane (1 KiB each per wave)
   auto dma_piece = [&](int tile, char* stage, int i) {
-    const int gi = min(tile * 4 + i, last_group);
+    const int gi = min(tile * 4 + i * (RP / 16) + grp_in_piece, last_group);
     const int key0 = gi << 4;
     const int slot0 = key0 & page_mask;
-    const int page = __builtin_amdgcn_readlane(bt_cur, (key0 >> a.page_shift) & 63);
+    int page;
+    if constexpr (BT_IN_LDS) page = __builtin_amdgcn_readfirstlane(bt_lds[key0 >> a.page_shift]);
+    else page = __builtin_amdgcn_readlane(bt_cur, (key0 >> a.page_shift) & 63);
     uint32_t kvo = k_voff, vvo = v_voff;
     if (key0 + 16 > seq_len) {            // wave-uniform: the sequence ends inside this group -> rows past it
                                           // fetch its last row instead (never stale cache contents)
-      const int r = min(rowin, max(seq_len - 1 - key0, 0));
+      const int r = min(rig, max(seq_len - 1 - key0, 0));
       kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
       vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
     }
     const char* kp = kbase + ((uint64_t)(uint32_t)page * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2);
     const char* vp = vbase + ((uint64_t)(uint32_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2);
-    glds16(kp + kvo, lds_addr(stage) + lds_wave + i * 4096);
-    glds16(vp + vvo, lds_addr(stage) + KBUF + lds_wave + i * 4096);
+    glds16(kp + kvo, lds_addr(stage) + lds_wave + i * (RP * ROWB));
+    glds16(vp + vvo, lds_addr(stage) + KBUF + lds_wave + i * (RP * ROWB));
   };
   auto issue_dma = [&](int tile, char* stage) {
     dma_begin(tile);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(tile, stage, i);
+    for (int i = 0; i < NP; ++i) dma_piece(tile, stage, i);
+  };
+  // wait until this wave's pieces of tile t+1 have landed: `newer` tiles (t+2 ..) may stay in flight
+  auto wait_next_tile = [&](int newer) {
+    if (PD >= 3 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * IPT) : "memory");
+    else if (PD >= 2 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(IPT) : "memory");
+    else glds_wait_all();
   };
 
   // ---- per-lane LDS read addresses (swizzle folded in) ---------------------------------------------
@@ -577,11 +621,14 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
 
-  if (tile_hi > 0) issue_dma(0, smem);
-  glds_wait_all();
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  for (int t = 0; t < PD; ++t)
+    if (t < tile_hi) issue_dma(t, smem + t * STAGE);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));   // also retires the Q loads (older than the DMA)
+  wait_next_tile(max(0, min(PD - 1, tile_hi - 1)));                        // tile 0 has landed
   __syncthreads();
+  MI355_WG_STAMP(wg_t1);
 #ifdef MI355_PROFILE_PHASES
   unsigned long long prof_sum[6] = {0, 0, 0, 0, 0, 0}, prof_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
@@ -589,9 +636,9 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
 
   // `prefetch`: issue the NEXT tile's LDS-DMA pieces from inside the Q.K^T MFMA stream (an LDS-DMA
   // instruction costs the issuing wave ~100+ cycles when issued in a burst, far less between MFMAs)
-  auto compute_tile = [&](int tile, const char* stage, char* next_stage, bool prefetch) {
+  auto compute_tile = [&](int tile, const char* stage, char* next_stage, bool prefetch) {   // next_stage: where tile+PD goes
     const int key_base = tile * kTileN;
-    if (prefetch) dma_begin(tile + 1);
+    if (prefetch) dma_begin(tile + PD);
     // ---- S^T - m_ref = K . Q'^T + cinit --------------------------------------------------------------
     pf32x16_t s_acc[2];
 #ifdef MI355_ABLATE_QK
@@ -609,8 +656,8 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #ifndef MI355_ABLATE_DMA
-      if (prefetch && (ks & 1)) {
-        dma_piece(tile + 1, next_stage, ks >> 1);
+      if (prefetch && (ks % (KSTEPS / NP)) == 1) {
+        dma_piece(tile + PD, next_stage, ks / (KSTEPS / NP));
       }
 #endif
     }
@@ -721,28 +768,28 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
     MI355_STAMP(3);
   };
 
-  // tile loop, two tiles per trip so that the LDS stage is a compile-time offset
-  for (int tile = 0; tile < tile_hi; tile += 2) {
+  // tile loop, NST tiles per trip so that the LDS stage is a compile-time offset
+  for (int tile = 0; tile < tile_hi; tile += NST) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NST; ++u) {
       const int t = tile + u;
       if (t < tile_hi) {
         char* cur = smem + u * STAGE;
-        char* nxt = smem + (u ^ 1) * STAGE;
-        const bool more = t + 1 < tile_hi;
+        char* nxt = smem + ((u + PD) % NST) * STAGE;   // stage of tile t+PD = the one tile t-1 left
+        const bool more = t + PD < tile_hi;
         MI355_STAMP(0);
         if (wave_has_rows && t * kTileN < wave_keys) {
           compute_tile(t, cur, nxt, more);
         } else {
 #ifndef MI355_ABLATE_DMA
-          if (more) issue_dma(t + 1, nxt);   // this wave has no rows left for the tile but still stages its share
+          if (more) issue_dma(t + PD, nxt);   // this wave has no rows left for the tile but still stages its share
 #endif
         }
 #ifdef MI355_PROFILE_PHASES
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_next_tile(max(0, min(t + PD, tile_hi - 1) - (t + 1)));
         MI355_STAMP(4);
 #endif
-        glds_wait_all();     // this wave's pieces of tile t+1 have landed ...
+        wait_next_tile(max(0, min(t + PD, tile_hi - 1) - (t + 1)));     // this wave's pieces of tile t+1 have landed ...
 #ifndef MI355_ABLATE_BARRIER
         __syncthreads();     // ... and so have everyone else's; stage `cur` is free
 #endif
@@ -752,6 +799,7 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
+  MI355_WG_STAMP(wg_t2);
 #ifdef MI355_PROFILE_PHASES
   {
     unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
@@ -762,17 +810,34 @@ __global__ __launch_bounds__(256, 2) void prefill_dma_kernel(const PrefillArgs a
   }
 #endif
   l_run += lane_xor32(l_run);
-  if (!row_ok) return;
-  const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
-  uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
+  if (row_ok) {
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
 #pragma unroll
-  for (int b = 0; b < DBLK; ++b)
+    for (int b = 0; b < DBLK; ++b)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
-                          pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
-      *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+      for (int c = 0; c < 4; ++c) {
+        const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
+                            pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+        *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+      }
+  }
+#ifdef MI355_PROFILE_WG
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MI355_WG_STAMP(wg_t3);
+    unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
+    if (dbg && tid == 0) {
+      atomicAdd(dbg + 8, wg_t1 - wg_t0);     // prologue: entry -> first tile staged
+      atomicAdd(dbg + 9, wg_t2 - wg_t1);     // tile loop
+      atomicAdd(dbg + 10, wg_t3 - wg_t2);    // epilogue incl. store drain
+      atomicAdd(dbg + 11, (unsigned long long)tile_hi);
+      atomicAdd(dbg + 12, 1ull);
+      atomicMin(dbg + 13, wg_t0);
+      atomicMax(dbg + 14, wg_t3);
     }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -825,25 +890,34 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   return rc;
 }
 
-template <typename T>
+// LDS bytes of the staged block-table prefix (8-wave kernel): one int per page of the longest sequence, in 256-byte rows
+constexpr size_t kBtLdsMaxBytes = 60 << 10;
+static size_t prefill_bt_lds_bytes(const mi355_attn_params& p) {
+  const size_t entries = ((size_t)std::max(p.max_seqlen_k, 1) + p.page_size - 1) / p.page_size;
+  return ((entries + 63) / 64) * 256;
+}
+
+template <typename T, int NW, int NST>
 static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   PrefillArgs a;
   a.p = p;
   a.group = p.num_q_heads / p.num_kv_heads;
-  a.block_q = kBlockM / a.group;
+  a.block_q = (NW * 32) / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
-  constexpr size_t lds = 2 * 2 * (size_t)kTileN * 256;   // two stages of K + V tiles, unpadded
+  size_t lds = (size_t)NST * 2 * kTileN * 256;   // NST stages of K + V tiles, unpadded
+  if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix
   static bool attr_set = false;
   if (!attr_set) {
-    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_dma_kernel<T, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)((size_t)NST * 2 * kTileN * 256 + (NST >= 3 ? kBtLdsMaxBytes : 0))),
                               "hipFuncSetAttribute(prefill_dma)");
     if (rc0 != MI355_OK) return rc0;
     attr_set = true;
   }
-  hipLaunchKernelGGL((prefill_dma_kernel<T>), dim3(qblocks * p.num_kv_heads), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST>), dim3(qblocks * p.num_kv_heads), dim3(NW * 64), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_dma_kernel launch");
   if (rc == MI355_OK) set_kernel_name("prefill_mfma");
   return rc;
@@ -860,7 +934,19 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   static const char* variant = getenv("MI355_PREFILL");
   const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', w64 = variant && variant[0] == 'w';
   if (w64 && prefill_w64_applicable(p)) return launch_prefill_w64(p, stream);
-  if (!feat && p.head_size == 128 && !v1) return bf ? launch_prefill_dma<bf16_t>(p, stream) : launch_prefill_dma<f16_t>(p, stream);
+  if (!feat && p.head_size == 128 && !v1) {
+    // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
+    // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped
+    // prologue (measured: +6..15 % at 1 x 4096, +3 % at 16 x 4096, +5 % at 1 x 16384; -8..-20 % at <= 2048
+    // keys); otherwise 4 waves / 128-row Q blocks / 2 stages, two workgroups per CU.
+    // MI355_PREFILL=d4 | d8 pins one of the two for measurements.
+    const long wgs8 = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 256 + p.num_seqs) * p.num_kv_heads;
+    bool wide = wgs8 >= 2 * 256 && p.max_seqlen_k >= 4096;
+    if (variant && variant[0] == 'd') wide = variant[1] == '8';
+    if (wide && prefill_bt_lds_bytes(p) <= kBtLdsMaxBytes)
+      return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream) : launch_prefill_dma<f16_t, 8, 3>(p, stream);
+    return bf ? launch_prefill_dma<bf16_t, 4, 2>(p, stream) : launch_prefill_dma<f16_t, 4, 2>(p, stream);
+  }
 #define MI355_PREFILL_CASE(DD)                                                                            \
   case DD:                                                                                                \
     if (feat) return bf ? launch_prefill_t<bf16_t, DD, true>(p, stream) : launch_prefill_t<f16_t, DD, true>(p, stream); \
