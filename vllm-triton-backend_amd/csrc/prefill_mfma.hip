@@ -441,6 +441,10 @@ constexpr float kDeferThr = 8.0f;
 //   NW 8, NST 3: one workgroup per CU, HALF the LDS-DMA bytes per MFMA and a two-tile-deep prefetch.
 // The kernel's floor is the per-CU global->LDS fill rate (~25 GB/s per CU, MI355X_MICROARCH.md
 // ldsdma-fill), not the matrix pipes: tools/phase_profile.py shows the waves waiting on their DMA.
+// (A ping-pong variant - waves NW/2.. lagging half a tile so that one group's softmax sits beside the
+// other's MFMAs, 4 stages - was built and measured 4 % SLOWER than the plain 8-wave kernel: the chip is
+// at its 1.4 kW package power limit under this kernel (tools/clock_watch.py), so re-ordering the same
+// work buys nothing; only doing less work per FLOP does. It is not kept.)
 template <typename T, int NW, int NST>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(const PrefillArgs a) {
   constexpr int D = 128;
@@ -636,11 +640,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
 
   // `prefetch`: issue the NEXT tile's LDS-DMA pieces from inside the Q.K^T MFMA stream (an LDS-DMA
   // instruction costs the issuing wave ~100+ cycles when issued in a burst, far less between MFMAs)
-  auto compute_tile = [&](int tile, const char* stage, char* next_stage, bool prefetch) {   // next_stage: where tile+PD goes
-    const int key_base = tile * kTileN;
+  pf32x16_t s_acc[2];      // S^T of the tile in flight: lives from qk_phase to sm_phase (across a barrier for the lagging wave group)
+  ps16x8_t pf[4];          // P^T of that tile as MFMA B operands: from sm_phase to pv_phase
+  auto qk_phase = [&](int tile, const char* stage, char* next_stage, bool prefetch) {   // next_stage: where tile+PD goes
     if (prefetch) dma_begin(tile + PD);
     // ---- S^T - m_ref = K . Q'^T + cinit --------------------------------------------------------------
-    pf32x16_t s_acc[2];
 #ifdef MI355_ABLATE_QK
     s_acc[0] = cinit; s_acc[1] = cinit;
     asm volatile("" : "+v"(s_acc[0]), "+v"(s_acc[1]));
@@ -671,9 +675,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     asm volatile("" :: "v"(s_acc[1][0]));   // the stamp below waits for the QK chains, not just their issue
 #endif
     MI355_STAMP(1);
+  };
+  auto sm_phase = [&](int tile) {
+    const int key_base = tile * kTileN;
     // ---- softmax -------------------------------------------------------------------------------------
 #ifdef MI355_ABLATE_SOFTMAX
-    ps16x8_t pf[4];
     asm volatile("" :: "v"(s_acc[0]), "v"(s_acc[1]));
 #pragma unroll
     for (int i = 0; i < 4; ++i) { pu32x4_t w = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(w)); pf[i] = __builtin_bit_cast(ps16x8_t, w); }
@@ -716,7 +722,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
         for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
     }
     float psum = 0.0f;
-    ps16x8_t pf[4];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float e[16];
@@ -735,6 +740,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     l_run += psum;
 #endif
     MI355_STAMP(2);
+  };
+  auto pv_phase = [&](const char* stage) {
     // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
 #ifdef MI355_ABLATE_PV
     asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
@@ -766,6 +773,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     asm volatile("" :: "v"(o_acc[DBLK - 1][0]));
 #endif
     MI355_STAMP(3);
+  };
+  auto compute_tile = [&](int tile, const char* stage, char* next_stage, bool prefetch) {
+    qk_phase(tile, stage, next_stage, prefetch);
+    sm_phase(tile);
+    pv_phase(stage);
   };
 
   // tile loop, NST tiles per trip so that the LDS stage is a compile-time offset
@@ -891,7 +903,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
 }
 
 // LDS bytes of the staged block-table prefix (8-wave kernel): one int per page of the longest sequence, in 256-byte rows
-constexpr size_t kBtLdsMaxBytes = 60 << 10;
+static constexpr size_t bt_lds_max_bytes(int nst) { return (size_t)(160 - 4 - 32 * nst) << 10; }   // what the stages leave of 160 KiB
 static size_t prefill_bt_lds_bytes(const mi355_attn_params& p) {
   const size_t entries = ((size_t)std::max(p.max_seqlen_k, 1) + p.page_size - 1) / p.page_size;
   return ((entries + 63) / 64) * 256;
@@ -908,11 +920,11 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
   size_t lds = (size_t)NST * 2 * kTileN * 256;   // NST stages of K + V tiles, unpadded
-  if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix
+  if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix (the caller checked that it fits)
   static bool attr_set = false;
   if (!attr_set) {
     const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_dma_kernel<T, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)((size_t)NST * 2 * kTileN * 256 + (NST >= 3 ? kBtLdsMaxBytes : 0))),
+                                                  (int)((size_t)NST * 2 * kTileN * 256 + (NST >= 3 ? bt_lds_max_bytes(NST) : 0))),
                               "hipFuncSetAttribute(prefill_dma)");
     if (rc0 != MI355_OK) return rc0;
     attr_set = true;
@@ -943,7 +955,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
     const long wgs8 = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 256 + p.num_seqs) * p.num_kv_heads;
     bool wide = wgs8 >= 2 * 256 && p.max_seqlen_k >= 4096;
     if (variant && variant[0] == 'd') wide = variant[1] == '8';
-    if (wide && prefill_bt_lds_bytes(p) <= kBtLdsMaxBytes)
+    if (wide && prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3))
       return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream) : launch_prefill_dma<f16_t, 8, 3>(p, stream);
     return bf ? launch_prefill_dma<bf16_t, 4, 2>(p, stream) : launch_prefill_dma<f16_t, 4, 2>(p, stream);
   }
