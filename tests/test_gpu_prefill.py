@@ -11,17 +11,18 @@ from oracle import paged_attention_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _check(inp, dtype, *, force=None, window=0, softcap=0.0, alibi=None, expect="prefill"):
+def _check(inp, dtype, *, force=None, window=0, softcap=0.0, alibi=None, expect="prefill", kv_dtype=None, kv_scale=None):
     import gpu_util
 
     ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
-                                       inp["scale"], sliding_window=window, softcap=softcap, alibi_slopes=alibi, mode="2d", block_n=64)
+                                       inp["scale"], sliding_window=window, softcap=softcap, alibi_slopes=alibi,
+                                       k_scale=kv_scale or 1.0, v_scale=kv_scale or 1.0, mode="2d", block_n=64)
     d = gpu_util.to_dev(inp)
     if alibi is not None:
         d["alibi_slopes"] = alibi.to(gpu_util.DEV)
-    out, kernel = gpu_util.run_unified(d, inp["scale"], window=window, softcap=softcap, force=force)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], window=window, softcap=softcap, force=force, kv_scale=kv_scale)
     assert kernel.startswith(expect), kernel
-    atol, rtol = golden_io.tolerance(dtype)
+    atol, rtol = golden_io.tolerance(dtype, kv_dtype)
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
 
@@ -52,6 +53,50 @@ def test_prefill_features_window_softcap_alibi():
     _check(inp, torch.float16, softcap=30.0)
     _check(inp, torch.float16, alibi=alibi)
     _check(inp, torch.float16, window=64, softcap=20.0, alibi=alibi)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("hq,hk,d", [(8, 2, 128), (32, 8, 128), (8, 2, 64), (4, 4, 64)])
+def test_prefill_fp8_kv_cache_on_the_mfma_path(dtype, kv_dtype, hq, hk, d):
+    """fp8 KV cache under 16-bit queries: widened to the query type on the way into LDS, scalar k/v scales folded into the
+    softmax scale / output normalisation (LIB/kernels/triton_unified_attention.py:434-455). Mixed batch: the prefill rows
+    run on the MFMA kernel, the query_len == 1 rows on the split-KV kernel, both over the same fp8 cache."""
+    query_lens = [1, 5, 129, 1, 64, 200]
+    kv_lens = [9, 5, 129, 300, 257, 777]
+    inp = orc.make_paged_inputs(25, query_lens, kv_lens, hq, hk, d, 16, dtype, kv_dtype=kv_dtype, kv_scale=0.5)
+    _check(inp, dtype, expect="prefill_mfma", kv_dtype=kv_dtype, kv_scale=0.5)
+    _check(inp, dtype, force=2, expect="prefill_mfma_fp8", kv_dtype=kv_dtype, kv_scale=0.5)
+
+
+def test_prefill_fp8_kv_page32_and_features():
+    inp = orc.make_paged_inputs(26, [40, 1, 9, 130], [70, 45, 33, 400], 8, 2, 128, 32, torch.float16, kv_dtype=torch.float8_e4m3fn, kv_scale=0.25)
+    alibi = torch.tensor([2.0 ** (-(i + 1)) for i in range(8)], dtype=torch.float32)
+    _check(inp, torch.float16, force=2, expect="prefill_mfma_fp8_feat", window=50, softcap=25.0, alibi=alibi, kv_dtype=torch.float8_e4m3fn, kv_scale=0.25)
+    _check(inp, torch.float16, force=2, expect="prefill_mfma_fp8_feat", window=8, kv_dtype=torch.float8_e4m3fn, kv_scale=0.25)
+
+
+def test_prefill_fp8_kv_stale_nan_bytes_beyond_the_sequence_are_ignored():
+    """0x7f / 0xff are NaN in e4m3fn: unused slots and pages may hold them."""
+    import gpu_util
+
+    kv_lens = [33, 100, 70]
+    inp = orc.make_paged_inputs(27, [33, 7, 70], kv_lens, 8, 2, 128, 16, torch.bfloat16, kv_dtype=torch.float8_e4m3fn, kv_scale=0.5)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], k_scale=0.5, v_scale=0.5, mode="2d", block_n=64)
+    used = torch.zeros(inp["k_cache"].shape[:2], dtype=torch.bool)
+    for i, n in enumerate(kv_lens):
+        for j in range(n):
+            used[inp["block_table"][i, j // 16], j % 16] = True
+    for name in ("k_cache", "v_cache"):
+        raw = inp[name].view(torch.uint8)
+        raw[~used] = 0x7F
+    d = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], kv_scale=0.5, force=2)
+    assert kernel.startswith("prefill_mfma_fp8"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(torch.bfloat16, torch.float8_e4m3fn)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
 
 
 def test_prefill_2d_forced_on_decode_batch():

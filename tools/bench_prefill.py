@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--page", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--kvdtype", default="same", choices=["same", "fp8", "fp8_e5m2"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16
@@ -29,15 +30,17 @@ def main():
     B, L, page = args.batch, args.seq, args.page
     pps = (L + page - 1) // page
     nb = int(B * pps * 1.25)
-    k = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(dt)
-    v = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+    kvdt = {"same": dt, "fp8": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}[args.kvdtype]
+    k = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(kvdt)
+    v = (torch.rand(nb, page, args.hk, args.d, device=dev) * 2 - 1).to(kvdt)
+    ksc = torch.ones(1, device=dev) if kvdt != dt else None
     q = (torch.rand(B * L, args.hq, args.d, device=dev) * 2 - 1).to(dt)
     bt = torch.randperm(nb, device=dev)[: B * pps].to(torch.int32).view(B, pps)
     cu = (torch.arange(B + 1, dtype=torch.int32, device=dev) * L).to(torch.int32)
     sl = torch.full((B,), L, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
     flops = 4 * L * L * args.d * args.hq / 2 * B
-    p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, None, None, None, None)
+    p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, None)
     for _ in range(3):
         ua_mod.launch(p, dev)
     torch.cuda.synchronize()

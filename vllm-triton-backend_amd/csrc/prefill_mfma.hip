@@ -36,6 +36,7 @@ typedef __attribute__((ext_vector_type(4))) short ps16x4_t;
 typedef __attribute__((ext_vector_type(8))) short ps16x8_t;
 typedef __attribute__((ext_vector_type(16))) float pf32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int pu32x4_t;
+typedef __attribute__((ext_vector_type(2))) float pf32x2_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int pu32x2_t;
 
 constexpr int kBlockM = 128;   // Q-block rows per workgroup
@@ -78,12 +79,39 @@ __device__ __forceinline__ int find_seq_by_qblock(const int32_t* __restrict__ cu
   return left - 1;
 }
 
+// 16 fp8 values (one 16-byte load) -> 16 values of the query's 16-bit type (two 16-byte LDS pieces); exact
+template <typename T, typename KVT>
+__device__ __forceinline__ void widen_fp8_piece(pu32x4_t in, pu32x4_t& lo, pu32x4_t& hi) {
+  uint32_t o[8];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    pf32x2_t a, b;
+    if constexpr (__is_same(KVT, e4m3_t)) {
+      a = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], false);
+      b = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], true);
+    } else {
+      a = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], false);
+      b = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], true);
+    }
+    o[2 * w] = pmma<T>::pack2(a[0], a[1]);
+    o[2 * w + 1] = pmma<T>::pack2(b[0], b[1]);
+  }
+  lo = pu32x4_t{o[0], o[1], o[2], o[3]};
+  hi = pu32x4_t{o[4], o[5], o[6], o[7]};
+}
+
 // FEAT = soft-cap / ALiBi / sliding window compiled in; the plain instantiation only knows the
-// causal + sequence-length mask.
-template <typename T, int D, bool FEAT>
+// causal + sequence-length mask. KVT = T, or an fp8 type: the cache tile is widened to T on its way
+// from the staging registers into LDS (reference dequant `(fp8 -> f32) * scale -> Q dtype`, :434-455;
+// the scalar k scale is folded into the softmax scale, the v scale into the output normalisation).
+template <typename T, typename KVT, int D, bool FEAT>
 __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs a) {
-  constexpr int PPR = D / 8;                 // 16-byte pieces per key row
+  constexpr bool FP8 = !__is_same(T, KVT);
+  constexpr int KVB = FP8 ? 1 : 2;           // bytes per cache element
+  constexpr int EPP = 16 / KVB;              // elements per 16-byte piece
+  constexpr int PPR = D / EPP;               // 16-byte pieces per key row
   constexpr int NLD = PPR / 4;               // loads per thread per tile (64 keys * PPR pieces / 256 threads)
+  static_assert(NLD >= 1, "head size too small for the staging pattern");
   constexpr int RSK = D * 2 + 16;            // K row stride in LDS (bytes)
   constexpr int RSV = D * 2 + 64;            // V row stride in LDS (bytes)
   constexpr int KSTEPS = D / 16;             // k-steps of K.Q^T
@@ -148,15 +176,19 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
     }
   }
   const float slope = (FEAT && p.alibi_slopes && row_ok) ? p.alibi_slopes[hq] : 0.0f;
-  const float scale2 = p.scale * kLog2eP;
+  const float k_scale = (FP8 && p.k_scale) ? p.k_scale[0] : 1.0f;
+  const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
+  const float scale_nat = p.scale * k_scale;   // fp8: K is used un-scaled, its scale moves here
+  const float scale2 = scale_nat * kLog2eP;
   const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
 
   // ---- staging: thread t loads pieces t + 256*i of the 64 x PPR tile ------------------------------
   // Load round i of a wave touches exactly one 16-key group, so the page lookup is wave-uniform:
   // scalar loads + scalar address arithmetic, one tile ahead of the vector loads that use it.
   const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
-  const uint16_t* kbase = (const uint16_t*)p.k_cache + (int64_t)head * p.k_stride_head;
-  const uint16_t* vbase = (const uint16_t*)p.v_cache + (int64_t)head * p.v_stride_head;
+  using kv_elem_t = typename KVT::storage;
+  const kv_elem_t* kbase = (const kv_elem_t*)p.k_cache + (int64_t)head * p.k_stride_head;
+  const kv_elem_t* vbase = (const kv_elem_t*)p.v_cache + (int64_t)head * p.v_stride_head;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
   const int page_mask = p.page_size - 1;
   int st_key[NLD], st_off[NLD];             // key inside the tile / element offset inside the row
@@ -166,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
   for (int i = 0; i < NLD; ++i) {
     const int idx = tid + 256 * i;
     st_key[i] = idx / PPR;
-    st_off[i] = (idx % PPR) * 8;
+    st_off[i] = (idx % PPR) * EPP;
     st_grp[i] = __builtin_amdgcn_readfirstlane(st_key[i] >> 4);
     k_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.k_stride_slot + st_off[i]);
     v_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.v_stride_slot + st_off[i]);
@@ -192,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
       } else {                              // D=32: one group per wave
         page = wave == 0 ? pg_next[0] : wave == 1 ? pg_next[1] : wave == 2 ? pg_next[2] : pg_next[3];
       }
-      const uint16_t* kp = kbase + ((uint64_t)(uint32_t)page * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride);
-      const uint16_t* vp = vbase + ((uint64_t)(uint32_t)page * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
+      const kv_elem_t* kp = kbase + ((uint64_t)(uint32_t)page * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride);
+      const kv_elem_t* vp = vbase + ((uint64_t)(uint32_t)page * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
       kreg[i] = *(const pu32x4_t*)(kp + k_toff[i]);
       vreg[i] = *(const pu32x4_t*)(vp + v_toff[i]);
     }
@@ -204,8 +236,18 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
       pu32x4_t v = vreg[i];
       // slots past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
       if (tile * kTileN + st_key[i] >= seq_len) v = pu32x4_t{0, 0, 0, 0};
-      *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2) = kreg[i];
-      *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2) = v;
+      if constexpr (FP8) {
+        pu32x4_t lo, hi;
+        widen_fp8_piece<T, KVT>(kreg[i], lo, hi);
+        *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2) = lo;
+        *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2 + 16) = hi;
+        widen_fp8_piece<T, KVT>(v, lo, hi);
+        *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2) = lo;
+        *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2 + 16) = hi;
+      } else {
+        *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2) = kreg[i];
+        *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2) = v;
+      }
     }
   };
 
@@ -302,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float x = s_acc[kb][r] * p.scale;
+            float x = s_acc[kb][r] * scale_nat;
             if (p.softcap > 0.0f) x = softcap_fn(x, p.softcap);
             bool ok = row_ok && key <= q_abs && key < seq_len;
             if (p.sliding_window > 0) ok = ok && (q_abs - key) < p.sliding_window;
@@ -377,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
   // ---- epilogue: O = O^T / l, lane (qr, half) register r of block b <-> d = 32b + (r&3) + 8(r>>2) + 4half
   l_run += lane_xor32(l_run);
   if (!row_ok) return;
-  const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+  const float inv = l_run > 0.0f ? v_scale / l_run : 0.0f;
   uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
 #pragma unroll
   for (int b = 0; b < DBLK; ++b)
@@ -859,7 +901,8 @@ static bool paligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 bool prefill_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
-  if (p.kv_dtype != p.q_dtype) return false;
+  const bool fp8_kv = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
+  if (p.kv_dtype != p.q_dtype && !fp8_kv) return false;
   if (!(p.head_size == 64 || p.head_size == 128)) return false;
   if (p.k_new || p.v_new) return false;
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
@@ -871,14 +914,20 @@ bool prefill_supported(const mi355_attn_params& p) {
   if (G > kBlockM) return false;
   if (!paligned16(p.q) || !paligned16(p.k_cache) || !paligned16(p.v_cache)) return false;
   if (((uintptr_t)p.out & 7) != 0) return false;
-  const int64_t strides[] = {p.q_stride_token, p.q_stride_head, p.k_stride_page, p.k_stride_slot, p.k_stride_head,
-                             p.v_stride_page, p.v_stride_slot, p.v_stride_head};
-  for (int64_t s : strides) if (s % 8 != 0) return false;
+  if (p.q_stride_token % 8 != 0 || p.q_stride_head % 8 != 0) return false;
+  const int64_t kv_align = fp8_kv ? 16 : 8;   // elements per 16 bytes
+  const int64_t kv_strides[] = {p.k_stride_page, p.k_stride_slot, p.k_stride_head, p.v_stride_page, p.v_stride_slot, p.v_stride_head};
+  for (int64_t s : kv_strides) if (s % kv_align != 0) return false;
   if (p.out_stride_token % 4 != 0 || p.out_stride_head % 4 != 0) return false;
   return true;
 }
 
-template <typename T, int D, bool FEAT>
+// cache element type as a function of the query type
+template <typename T> using kv_same = T;
+template <typename T> using kv_e4m3 = e4m3_t;
+template <typename T> using kv_e5m2 = e5m2_t;
+
+template <typename T, typename KVT, int D, bool FEAT>
 static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   PrefillArgs a;
   a.p = p;
@@ -891,14 +940,14 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)kTileN * ((D * 2 + 16) + (D * 2 + 64));
   static bool attr_set = false;   // >64 KiB of dynamic LDS needs an opt-in, once per kernel
   if (!attr_set) {
-    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_mfma_kernel<T, D, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_mfma_kernel<T, KVT, D, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                               "hipFuncSetAttribute(prefill)");
     if (rc0 != MI355_OK) return rc0;
     attr_set = true;
   }
-  hipLaunchKernelGGL((prefill_mfma_kernel<T, D, FEAT>), dim3(qblocks * p.num_kv_heads), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((prefill_mfma_kernel<T, KVT, D, FEAT>), dim3(qblocks * p.num_kv_heads), dim3(256), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_mfma_kernel launch");
-  if (rc == MI355_OK) set_kernel_name(FEAT ? "prefill_mfma_feat" : "prefill_mfma");
+  if (rc == MI355_OK) set_kernel_name(!__is_same(T, KVT) ? (FEAT ? "prefill_mfma_fp8_feat" : "prefill_mfma_fp8") : (FEAT ? "prefill_mfma_feat" : "prefill_mfma"));
   return rc;
 }
 
@@ -946,7 +995,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   static const char* variant = getenv("MI355_PREFILL");
   const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', w64 = variant && variant[0] == 'w';
   if (w64 && prefill_w64_applicable(p)) return launch_prefill_w64(p, stream);
-  if (!feat && p.head_size == 128 && !v1) {
+  if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped
     // prologue (measured: +6..15 % at 1 x 4096, +3 % at 16 x 4096, +5 % at 1 x 16384; -8..-20 % at <= 2048
@@ -959,13 +1008,25 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
       return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream) : launch_prefill_dma<f16_t, 8, 3>(p, stream);
     return bf ? launch_prefill_dma<bf16_t, 4, 2>(p, stream) : launch_prefill_dma<f16_t, 4, 2>(p, stream);
   }
-#define MI355_PREFILL_CASE(DD)                                                                            \
+#define MI355_PREFILL_CASE(KV, DD)                                                                        \
   case DD:                                                                                                \
-    if (feat) return bf ? launch_prefill_t<bf16_t, DD, true>(p, stream) : launch_prefill_t<f16_t, DD, true>(p, stream); \
-    return bf ? launch_prefill_t<bf16_t, DD, false>(p, stream) : launch_prefill_t<f16_t, DD, false>(p, stream);
-  switch (p.head_size) {
-    MI355_PREFILL_CASE(64)
-    MI355_PREFILL_CASE(128)
+    if (feat) return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, true>(p, stream) : launch_prefill_t<f16_t, KV<f16_t>, DD, true>(p, stream); \
+    return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, false>(p, stream) : launch_prefill_t<f16_t, KV<f16_t>, DD, false>(p, stream);
+  if (p.kv_dtype == MI355_FP8_E4M3) {
+    switch (p.head_size) {
+      MI355_PREFILL_CASE(kv_e4m3, 64)
+      MI355_PREFILL_CASE(kv_e4m3, 128)
+    }
+  } else if (p.kv_dtype == MI355_FP8_E5M2) {
+    switch (p.head_size) {
+      MI355_PREFILL_CASE(kv_e5m2, 64)
+      MI355_PREFILL_CASE(kv_e5m2, 128)
+    }
+  } else {
+    switch (p.head_size) {
+      MI355_PREFILL_CASE(kv_same, 64)
+      MI355_PREFILL_CASE(kv_same, 128)
+    }
   }
 #undef MI355_PREFILL_CASE
   set_error("prefill: head_size %d not built", p.head_size);

@@ -464,7 +464,7 @@ static int launch_w64_t(const mi355_attn_params& p, hipStream_t stream) {
 bool prefill_w64_applicable(const mi355_attn_params& p) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  return !feat && p.head_size == 128 && G <= 256;
+  return !feat && p.head_size == 128 && G <= 256 && p.kv_dtype == p.q_dtype;
 }
 
 int launch_prefill_w64(const mi355_attn_params& p, hipStream_t stream) {
