@@ -38,6 +38,35 @@ def test_decode_heads_and_head_sizes(dtype, hq, hk, d):
     _check(inp, dtype, force=None, expect="decode")
 
 
+@pytest.mark.parametrize("d", [32, 80, 96, 160, 192, 224])
+def test_decode_head_sizes_that_run_padded(d):
+    """Head sizes between the built ones run on the next built size; the padding columns are never read or written
+    (the reference pads to the next power of two, triton_unified_attention.py:353,:912)."""
+    kv_lens = [1, 17, 33, 700, 1023, 257]
+    inp = orc.make_paged_inputs(30 + d, [1] * len(kv_lens), kv_lens, 8, 2, d, 16, torch.bfloat16)
+    _check(inp, torch.bfloat16, force=None, expect="decode")
+    if d % 16 == 0:
+        inp8 = orc.make_paged_inputs(31 + d, [1] * len(kv_lens), kv_lens, 8, 2, d, 16, torch.float16, kv_dtype=torch.float8_e4m3fn, kv_scale=0.5)
+        _check(inp8, torch.float16, force=None, expect="decode_splitkv_fp8", kv_dtype=torch.float8_e4m3fn, kv_scale=0.5)
+
+
+def test_decode_padded_head_size_leaves_neighbouring_output_columns_alone():
+    """out has a wider row than the head: bytes between heads must keep their contents."""
+    import gpu_util
+
+    d, dw = 96, 128
+    kv_lens = [300, 17, 1023]
+    inp = orc.make_paged_inputs(33, [1] * 3, kv_lens, 8, 2, d, 16, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="3d")
+    t = gpu_util.to_dev(inp)
+    wide = torch.full((3, 8, dw), 7.0, dtype=torch.bfloat16, device=gpu_util.DEV)
+    out, kernel = gpu_util.run_unified(t, inp["scale"], out=wide[:, :, :d])
+    assert kernel.startswith("decode")
+    torch.testing.assert_close(wide[:, :, :d].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    assert torch.all(wide[:, :, d:] == 7.0)
+
+
 @pytest.mark.parametrize("page", [16, 32, 64, 128])
 def test_decode_page_sizes(page):
     kv_lens = [5, 129, 640, 77, 300]

@@ -37,6 +37,29 @@ def test_prefill_mixed_batches(dtype, hq, hk, d):
     _check(inp, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk", [(8, 2), (4, 4)])
+def test_prefill_head_size_256(dtype, hq, hk):
+    """Gemma-class head size: one workgroup per CU on the whole register file; with and without soft-cap + window."""
+    query_lens = [1, 5, 129, 1, 64, 200]
+    kv_lens = [9, 5, 129, 300, 257, 777]
+    inp = orc.make_paged_inputs(28, query_lens, kv_lens, hq, hk, 256, 16, dtype)
+    _check(inp, dtype)
+    _check(inp, dtype, force=2, window=100, softcap=30.0, expect="prefill_mfma_feat")
+
+
+@pytest.mark.parametrize("d", [32, 80, 96, 160, 192, 224])
+def test_prefill_head_sizes_that_run_padded(d):
+    query_lens = [1, 5, 129, 64, 200]
+    kv_lens = [9, 5, 129, 257, 777]
+    inp = orc.make_paged_inputs(40 + d, query_lens, kv_lens, 8, 2, d, 16, torch.bfloat16)
+    _check(inp, torch.bfloat16)
+    _check(inp, torch.bfloat16, force=2, window=64, softcap=30.0, expect="prefill_mfma_feat")
+    if d % 16 == 0 and d <= 128:
+        inp8 = orc.make_paged_inputs(41 + d, query_lens, kv_lens, 8, 2, d, 16, torch.float16, kv_dtype=torch.float8_e4m3fn, kv_scale=0.5)
+        _check(inp8, torch.float16, force=2, expect="prefill_mfma_fp8", kv_dtype=torch.float8_e4m3fn, kv_scale=0.5)
+
+
 @pytest.mark.parametrize("page", [16, 32, 128])
 def test_prefill_page_sizes(page):
     inp = orc.make_paged_inputs(22, [70, 1, 300], [70, 513, 411], 8, 2, 128, page, torch.bfloat16)

@@ -66,7 +66,15 @@ def main():
     for ts, o in samples:
         tag = "busy" if t0 <= ts <= t1 else "idle"
         lines = [l for l in o.strip().splitlines() if l and not l.startswith("WARNING")]
-        print(f"[{ts - t0:6.2f}s {tag}] " + " | ".join(lines[:3]))
+        if len(lines) >= 2 and lines[0].startswith("device"):
+            rec = dict(zip(lines[0].split(","), lines[1].split(",")))
+            sclk = rec.get("sclk clock speed:", "?")
+            pw = next((v for k, v in rec.items() if "Power" in k), "?")
+            tj = rec.get("Temperature (Sensor junction) (C)", "?")
+            tm = rec.get("Temperature (Sensor memory) (C)", "?")
+            print(f"[{ts - t0:6.2f}s {tag}] sclk {sclk} power {pw} W  Tj {tj} C  Tmem {tm} C")
+        else:
+            print(f"[{ts - t0:6.2f}s {tag}] " + " | ".join(lines[:3]))
 
 
 if __name__ == "__main__":

@@ -63,6 +63,7 @@ def main():
     print(f"  workgroups {s[12]}, tiles {s[11]} ({s[11]/n:.1f} per WG)")
     for name, x in (("prologue (entry -> first tile staged)", s[8]), ("tile loop", s[9]), ("epilogue (normalise, store, drain)", s[10])):
         print(f"  {name:40s} {x/n:9.1f} ticks/WG   {100.0*x/(s[8]+s[9]+s[10]):5.1f} %")
+    print(f"  prologue split: entry->metadata {s[15]/n:.0f}, metadata->block table staged {s[7]/n:.0f}, first tiles' DMA {(s[8]-s[15]-s[7])/n:.0f} ticks/WG")
     print(f"  tile loop: {s[9]/max(s[11],1):.2f} ticks per tile; prologue+epilogue = {(s[8]+s[10])/n/(s[9]/max(s[11],1)):.2f} tiles' worth per WG")
     slots = 512
     print(f"  sum of WG lives / {slots} slots = {(s[8]+s[9]+s[10])/slots:.0f} ticks vs span {span}")

@@ -152,6 +152,14 @@ __device__ __forceinline__ int find_seq_by_token(const int32_t* __restrict__ cu,
   return left - 1;
 }
 
+// Head sizes the MFMA kernels are built for; any other multiple of 8 (16 with an fp8 cache) up to 256 runs on the
+// next one with the missing columns never loaded (zero operands) and never stored - the reference pads to the
+// next power of two the same way (HEAD_SIZE_PADDED, triton_unified_attention.py:353,:912). 0 = not served.
+__host__ __device__ inline int padded_head_size(int d, bool fp8_kv) {
+  if (d < 16 || d > 256 || d % (fp8_kv ? 16 : 8) != 0) return 0;
+  return d <= 64 ? 64 : d <= 128 ? 128 : 256;
+}
+
 // wave64 reductions
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

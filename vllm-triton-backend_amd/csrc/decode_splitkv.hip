@@ -65,6 +65,7 @@ struct DecodeArgs {
   int group;       // G = Hq / Hk
   int page_shift;  // log2(page_size)
   int by_seq;      // 1: work items enumerate sequences (only_decodes), 0: query tokens
+  int d_valid;     // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
   int unit_is_seq; // 1: every sequence has exactly one query token (max_seqlen_q == 1), so unit == token == sequence
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated on the host
 };
@@ -146,7 +147,9 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
   return r;
 }
 
-template <typename T, typename KVT, int D, int WAVES, bool FEAT>
+// PAD: the real head size is smaller than D (see padded_head_size); a separate instantiation so that the
+// built head sizes keep their branch-free load stream.
+template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD>
 __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const DecodeArgs a) {
   constexpr bool FP8 = !__is_same(T, KVT);
   // tiles in flight HBM -> VGPR per wave: an fp8 tile is half the bytes of a 16-bit one, so two of
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
     for (int c = 0; c < KSTEPS; ++c) {
       u32x4_t v = {0, 0, 0, 0};
-      if (g_ok) v = *(const u32x4_t*)(qp + 32 * c);
+      if (g_ok && (!PAD || 32 * c + 8 * grp < a.d_valid)) v = *(const u32x4_t*)(qp + 32 * c);
       qf[c] = __builtin_bit_cast(s16x8_t, v);
     }
   };
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     if (split == 0 && g_ok) {  // no visible key at all (no split has a tile): the reference returns acc/L = 0/1 = 0
       const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
 #pragma unroll
-      for (int b = 0; b < DBLK; ++b) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) = u32x2_t{0, 0};
+      for (int b = 0; b < DBLK; ++b)
+        if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) = u32x2_t{0, 0};
     }
     return;
   }
@@ -250,15 +254,20 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const int page_mask = p.page_size - 1;
 
   // per-lane constants of the row-shaped loads: piece idx = lane + 64*i -> (row = idx / PPR, piece = idx % PPR)
+  // PAD: a piece in the padding columns loads the row's piece 0 instead (same instruction stream, always a
+  // valid address) and is zeroed on its way into LDS
   int ld_row[NLD], ld_piece[NLD];
+  bool ld_pad[NLD];
   uint32_t k_toff[NLD], v_toff[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int idx = lane + 64 * i;
     ld_row[i] = idx / PPR;
     ld_piece[i] = idx % PPR;
-    k_toff[i] = (uint32_t)(ld_row[i] * (int)a.k_slot_stride + ld_piece[i] * EPP);
-    v_toff[i] = (uint32_t)(ld_row[i] * (int)a.v_slot_stride + ld_piece[i] * EPP);
+    ld_pad[i] = PAD && ld_piece[i] * EPP >= a.d_valid;
+    const int src_piece = ld_pad[i] ? 0 : ld_piece[i];
+    k_toff[i] = (uint32_t)(ld_row[i] * (int)a.k_slot_stride + src_piece * EPP);
+    v_toff[i] = (uint32_t)(ld_row[i] * (int)a.v_slot_stride + src_piece * EPP);
   }
 
   // block-table entries of the two groups of a tile, via the scalar cache (see scalar_load4)
@@ -331,6 +340,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
         u32x4_t v = VR[h][i];
         // rows past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
         if (tail && (tile * kTileKeys + h * 16 + ld_row[i] >= n_keys)) v = u32x4_t{0, 0, 0, 0};
+        if (PAD && ld_pad[i]) v = u32x4_t{0, 0, 0, 0};
         park(v_lds, h * 16 + ld_row[i], ld_piece[i], v);
       }
     if (tile + PF < t1) {
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) park(k_lds, ld_row[i], ld_piece[i], kcur[h][i]);
+      for (int i = 0; i < NLD; ++i) park(k_lds, ld_row[i], ld_piece[i], (PAD && ld_pad[i]) ? u32x4_t{0, 0, 0, 0} : kcur[h][i]);
       f32x4_t acc = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < KSTEPS; ++c) {
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
-      *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
+      if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
           u32x2_t{mma<T>::pack2(o_acc[b][0] * inv, o_acc[b][1] * inv), mma<T>::pack2(o_acc[b][2] * inv, o_acc[b][3] * inv)};
     return;
   }
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)(head * G + gm) * p.out_stride_head;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
-      *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
+      if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
           u32x2_t{mma<T>::pack2(acc[b][0] * inv, acc[b][1] * inv), mma<T>::pack2(acc[b][2] * inv, acc[b][3] * inv)};
   }
   if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counter zero for the next call
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
   }
   const float inv = l_all > 0.0f ? v_scale / l_all : 0.0f;  // "0 if the overall sum is 0" (:828)
   uint16_t* op = (uint16_t*)p.out + (int64_t)ri.token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
-  *(u32x2_t*)(op + 4 * col) = u32x2_t{mma<T>::pack2(acc[0] * inv, acc[1] * inv), mma<T>::pack2(acc[2] * inv, acc[3] * inv)};
+  if (4 * col < a.d_valid) *(u32x2_t*)(op + 4 * col) = u32x2_t{mma<T>::pack2(acc[0] * inv, acc[1] * inv), mma<T>::pack2(acc[2] * inv, acc[3] * inv)};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,7 +616,7 @@ static bool is_fp8_dtype(int d) { return d == MI355_FP8_E4M3 || d == MI355_FP8_E
 bool decode_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
   if (p.kv_dtype != p.q_dtype && !is_fp8_dtype(p.kv_dtype)) return false;
-  if (!(p.head_size == 64 || p.head_size == 128 || p.head_size == 256)) return false;
+  if (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) == 0) return false;
   if (p.k_new || p.v_new) return false;
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
@@ -661,10 +671,10 @@ size_t decode_workspace_bytes(const mi355_attn_params& p) {
   const int splits = plan_splits(p).num_splits;
   if (splits == 1) return 0;
   const size_t slots = (size_t)decode_units(p) * p.num_q_heads * splits;
-  return counters_bytes(p) + slots * (p.head_size + kSlotPad) * sizeof(float);
+  return counters_bytes(p) + slots * (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) + kSlotPad) * sizeof(float);
 }
 
-template <typename T, typename KVT, int D, bool FEAT>
+template <typename T, typename KVT, int D, bool FEAT, bool PAD>
 static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   constexpr int WAVES = 4;
   constexpr bool FP8 = !__is_same(T, KVT);
@@ -676,6 +686,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.group = p.num_q_heads / p.num_kv_heads;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
   a.by_seq = p.only_decodes ? 1 : 0;
+  a.d_valid = p.head_size;
   a.unit_is_seq = (!p.only_decodes && p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) ? 1 : 0;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
@@ -711,7 +722,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   const long items = units * sp.num_splits * p.num_kv_heads;
   const int grid = (int)((items + WAVES - 1) / WAVES);
   const size_t lds = (size_t)WAVES * 48 * (D * 2 + 32);
-  hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+  hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
   if (rc != MI355_OK) return rc;
   if (sp.num_splits > 1 && !a.fused_merge) {
@@ -726,12 +737,14 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
 template <typename T, typename KVT, int D>
 static int launch_decode_f(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
-  return feat ? launch_decode_t<T, KVT, D, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false>(p, ws, ws_bytes, stream);
+  if (p.head_size != D)
+    return feat ? launch_decode_t<T, KVT, D, true, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, true>(p, ws, ws_bytes, stream);
+  return feat ? launch_decode_t<T, KVT, D, true, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false>(p, ws, ws_bytes, stream);
 }
 
 template <typename T, typename KVT>
 static int launch_decode_d(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
-  switch (p.head_size) {
+  switch (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype))) {
     case 64: return launch_decode_f<T, KVT, 64>(p, ws, ws_bytes, stream);
     case 128: return launch_decode_f<T, KVT, 128>(p, ws, ws_bytes, stream);
     case 256: return launch_decode_f<T, KVT, 256>(p, ws, ws_bytes, stream);

@@ -48,6 +48,7 @@ struct PrefillArgs {
   int group;      // G
   int block_q;    // tokens per Q block = kBlockM / G
   int page_shift; // log2(page_size)
+  int d_valid;    // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
 };
 
@@ -104,8 +105,10 @@ __device__ __forceinline__ void widen_fp8_piece(pu32x4_t in, pu32x4_t& lo, pu32x
 // causal + sequence-length mask. KVT = T, or an fp8 type: the cache tile is widened to T on its way
 // from the staging registers into LDS (reference dequant `(fp8 -> f32) * scale -> Q dtype`, :434-455;
 // the scalar k scale is folded into the softmax scale, the v scale into the output normalisation).
+// D = 256 needs the whole register file (O^T alone is 128 accumulator registers per lane) and 141 KiB of
+// LDS for its two stages: one workgroup per CU.
 template <typename T, typename KVT, int D, bool FEAT>
-__global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs a) {
+__global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(const PrefillArgs a) {
   constexpr bool FP8 = !__is_same(T, KVT);
   constexpr int KVB = FP8 ? 1 : 2;           // bytes per cache element
   constexpr int EPP = 16 / KVB;              // elements per 16-byte piece
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       pu32x4_t v = {0, 0, 0, 0};
-      if (row_ok) v = *(const pu32x4_t*)(qp + 16 * ks);
+      if (row_ok && 16 * ks + 8 * half < a.d_valid) v = *(const pu32x4_t*)(qp + 16 * ks);
       qf[ks] = __builtin_bit_cast(ps16x8_t, v);
     }
   }
@@ -194,14 +197,19 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
   int st_key[NLD], st_off[NLD];             // key inside the tile / element offset inside the row
   uint32_t k_toff[NLD], v_toff[NLD];        // this thread's element offset from the group's first row
   int st_grp[NLD];                          // 16-key group inside the tile (wave-uniform)
+  bool st_pad[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int idx = tid + 256 * i;
     st_key[i] = idx / PPR;
     st_off[i] = (idx % PPR) * EPP;
     st_grp[i] = __builtin_amdgcn_readfirstlane(st_key[i] >> 4);
-    k_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.k_stride_slot + st_off[i]);
-    v_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.v_stride_slot + st_off[i]);
+    // a piece in the padding columns of a non-built head size loads the row's piece 0 instead (same instruction
+    // stream, always a valid address) and is zeroed on its way into LDS
+    st_pad[i] = st_off[i] >= a.d_valid;
+    const int src_off = st_pad[i] ? 0 : st_off[i];
+    k_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.k_stride_slot + src_off);
+    v_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.v_stride_slot + src_off);
   }
   int pg_next[4];                           // physical pages of the NEXT tile's four 16-key groups (SGPRs)
   auto lookup_pages = [&](int tile) {
@@ -236,6 +244,9 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
       pu32x4_t v = vreg[i];
       // slots past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
       if (tile * kTileN + st_key[i] >= seq_len) v = pu32x4_t{0, 0, 0, 0};
+      if (a.d_valid != D) {                   // wave-uniform: the built head sizes skip this
+        if (st_pad[i]) { v = pu32x4_t{0, 0, 0, 0}; kreg[i] = pu32x4_t{0, 0, 0, 0}; }
+      }
       if constexpr (FP8) {
         pu32x4_t lo, hi;
         widen_fp8_piece<T, KVT>(kreg[i], lo, hi);
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void prefill_mfma_kernel(const PrefillArgs 
     for (int c = 0; c < 4; ++c) {
       const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
                           pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
-      *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+      if (32 * b + 8 * c + 4 * half < a.d_valid) *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
     }
 }
 
@@ -511,15 +522,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);
   const int seq = find_seq_by_qblock(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
   if (seq < 0) return;
+  // Prologue order (every step is a memory round trip of ~1-2 us that nothing else on this CU hides when
+  // the workgroup owns it): sequence index -> {block table, sequence lengths} together -> {first K/V
+  // tiles, Q rows} together. The block table is fetched as soon as the sequence is known, bounded by
+  // max_seqlen_k's page count instead of this Q block's own last page (not known yet).
+  const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
+  const int bt_last_any = ((max(p.max_seqlen_k, 1) + p.page_size - 1) >> a.page_shift) - 1;
+  constexpr bool BT_IN_LDS = NST >= 3;
+  const int* bt_lds = (const int*)(smem + NST * STAGE);
+  int bt_chunk = 0, bt_cur = 0, bt_nxt = 0;
+  if constexpr (BT_IN_LDS) {
+    for (int c = wave; c * 64 <= bt_last_any; c += NW) glds4(bt + min(c * 64 + lane, bt_last_any), lds_addr(bt_lds) + c * 256);
+  } else {
+    bt_cur = bt[min(lane, bt_last_any)];
+    bt_nxt = bt[min(64 + lane, bt_last_any)];
+  }
   const int q_start = p.cu_seqlens_q[seq];
   const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
   const int qb_local = qblock - (q_start / BQ + seq);
-  if (qb_local * BQ >= q_len) return;
-  if (p.skip_decodes && q_len == 1) return;
-  if (p.only_decodes && q_len != 1) return;
   const int seq_len = p.seqused_k[seq];
+  if (qb_local * BQ >= q_len || (p.skip_decodes && q_len == 1) || (p.only_decodes && q_len != 1)) {
+    if constexpr (BT_IN_LDS) glds_wait_all();   // never leave with a DMA into this workgroup's LDS in flight
+    return;
+  }
   const int ctx_len = seq_len - q_len;
   const int tok0 = qb_local * BQ;
+  MI355_WG_STAMP(wg_ta);   // metadata known
+
 
   const int qr = lane & 31, half = lane >> 5;
   const int m_row = wave * 32 + qr;
@@ -537,33 +566,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   const bool wave_has_rows = w_tok_lo <= w_tok_hi;
   const int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
 
-  // ---- Q fragments, pre-scaled into the log2 domain ---------------------------------------------
   const float scale2 = p.scale * kLog2eP;
-  ps16x8_t qf[KSTEPS];
+  // ---- Q rows: the longest round trip of the prologue (cold HBM), issued as soon as the row is known ----
+  pu32x4_t qraw[KSTEPS];
   {
-    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)(q_start + tok_local) * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * half;
+    // padding rows read the sequence's last query row (always a valid address) and are zeroed at the conversion:
+    // unconditional loads, no branch per load
+    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)(q_start + min(tok_local, q_len - 1)) * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * half;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      pu32x4_t v = {0, 0, 0, 0};
-      if (row_ok) v = *(const pu32x4_t*)(qp + 16 * ks);
-      pu32x4_t w;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float lo, hi;
-        if constexpr (__is_same(T, bf16_t)) {
-          lo = bf16_to_f32((uint16_t)(v[e] & 0xffff)); hi = bf16_to_f32((uint16_t)(v[e] >> 16));
-        } else {
-          lo = f16_to_f32((uint16_t)(v[e] & 0xffff)); hi = f16_to_f32((uint16_t)(v[e] >> 16));
-        }
-        w[e] = pmma<T>::pack2(lo * scale2, hi * scale2);
-      }
-      qf[ks] = __builtin_bit_cast(ps16x8_t, w);
-    }
+    for (int ks = 0; ks < KSTEPS; ++ks) qraw[ks] = *(const pu32x4_t*)(qp + 16 * ks);
   }
 
   // ---- DMA staging constants ----------------------------------------------------------------------
   // lane handles LDS chunk (row = (tid>>4) + 16 i, c = tid & 15) of both tiles; 16-key group i <-> load i
-  const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
   const char* kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
   const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
@@ -579,22 +594,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
 
   const int last_entry = (last_group << 4) >> a.page_shift;
   const uint32_t k_page_bytes = a.k_page_stride * 2, v_page_bytes = a.v_page_stride * 2;
-  // Block-table entries of this workgroup's keys.
+  // Block-table entries of this workgroup's keys (fetch issued at the top of the kernel).
   //   NST == 2: 64 at a time in a VGPR (lane l = entry chunk*64 + l), one chunk ahead, picked with
   //             v_readlane: no scalar-cache round trip inside the loop.
   //   NST >= 3: the whole prefix is staged once in LDS behind the tile stages by LDS-DMA. A VGPR chunk
   //             is a compiler-visible load carried round the loop: hipcc waits for it with vmcnt(0) at
   //             every copy, which would also drain the tile that is meant to stay in flight.
-  constexpr bool BT_IN_LDS = NST >= 3;
-  const int* bt_lds = (const int*)(smem + NST * STAGE);
-  int bt_chunk = 0, bt_cur = 0, bt_nxt = 0;
   if constexpr (BT_IN_LDS) {
-    for (int c = wave; c * 64 <= last_entry; c += NW) glds4(bt + min(c * 64 + lane, last_entry), lds_addr(bt_lds) + c * 256);
-    glds_wait_all();     // the first tiles' addresses come out of this table
+    // the first tiles' addresses come out of this table; the KSTEPS Q loads issued after it stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KSTEPS) : "memory");
     __syncthreads();
-  } else {
-    bt_cur = bt[min(lane, last_entry)];
-    bt_nxt = bt[min(64 + lane, last_entry)];
   }
   auto dma_begin = [&](int tile) {          // call once per tile before its pieces
     if constexpr (!BT_IN_LDS) {
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
       if ((e0 >> 6) != bt_chunk) {            // wave-uniform; entries only ever move forward
         bt_chunk = e0 >> 6;
         bt_cur = bt_nxt;
-        bt_nxt = bt[min((bt_chunk + 1) * 64 + lane, last_entry)];
+        bt_nxt = bt[min((bt_chunk + 1) * 64 + lane, bt_last_any)];
       }
     }
   };
@@ -667,11 +676,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
 
+  MI355_WG_STAMP(wg_tb);   // block table staged
 #pragma unroll
   for (int t = 0; t < PD; ++t)
     if (t < tile_hi) issue_dma(t, smem + t * STAGE);
+  // Q fragments, pre-scaled into the log2 domain (the compiler's wait for the Q loads lands here: they
+  // are older than the DMA, so it does not wait for the tiles)
+  ps16x8_t qf[KSTEPS];
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));   // also retires the Q loads (older than the DMA)
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const pu32x4_t v = row_ok ? qraw[ks] : pu32x4_t{0, 0, 0, 0};
+    pu32x4_t w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo, hi;
+      if constexpr (__is_same(T, bf16_t)) {
+        lo = bf16_to_f32((uint16_t)(v[e] & 0xffff)); hi = bf16_to_f32((uint16_t)(v[e] >> 16));
+      } else {
+        lo = f16_to_f32((uint16_t)(v[e] & 0xffff)); hi = f16_to_f32((uint16_t)(v[e] >> 16));
+      }
+      w[e] = pmma<T>::pack2(lo * scale2, hi * scale2);
+    }
+    qf[ks] = __builtin_bit_cast(ps16x8_t, w);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
   wait_next_tile(max(0, min(PD - 1, tile_hi - 1)));                        // tile 0 has landed
   __syncthreads();
   MI355_WG_STAMP(wg_t1);
@@ -883,6 +912,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
     if (dbg && tid == 0) {
       atomicAdd(dbg + 8, wg_t1 - wg_t0);     // prologue: entry -> first tile staged
+      atomicAdd(dbg + 15, wg_ta - wg_t0);    //   of which: entry -> sequence metadata known
+      atomicAdd(dbg + 7, wg_tb - wg_ta);     //   of which: metadata -> block table staged, Q landed
       atomicAdd(dbg + 9, wg_t2 - wg_t1);     // tile loop
       atomicAdd(dbg + 10, wg_t3 - wg_t2);    // epilogue incl. store drain
       atomicAdd(dbg + 11, (unsigned long long)tile_hi);
@@ -903,7 +934,8 @@ bool prefill_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
   const bool fp8_kv = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
   if (p.kv_dtype != p.q_dtype && !fp8_kv) return false;
-  if (!(p.head_size == 64 || p.head_size == 128)) return false;
+  const int dpad = padded_head_size(p.head_size, fp8_kv);
+  if (dpad == 0 || (dpad == 256 && fp8_kv)) return false;
   if (p.k_new || p.v_new) return false;
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
@@ -934,6 +966,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = kBlockM / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
+  a.d_valid = p.head_size;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;  // static upper bound (:886-889,:935-943)
@@ -965,6 +998,7 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = (NW * 32) / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
+  a.d_valid = p.head_size;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
@@ -1012,20 +1046,22 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   case DD:                                                                                                \
     if (feat) return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, true>(p, stream) : launch_prefill_t<f16_t, KV<f16_t>, DD, true>(p, stream); \
     return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, false>(p, stream) : launch_prefill_t<f16_t, KV<f16_t>, DD, false>(p, stream);
+  const int dpad = padded_head_size(p.head_size, p.kv_dtype != p.q_dtype);
   if (p.kv_dtype == MI355_FP8_E4M3) {
-    switch (p.head_size) {
+    switch (dpad) {
       MI355_PREFILL_CASE(kv_e4m3, 64)
       MI355_PREFILL_CASE(kv_e4m3, 128)
     }
   } else if (p.kv_dtype == MI355_FP8_E5M2) {
-    switch (p.head_size) {
+    switch (dpad) {
       MI355_PREFILL_CASE(kv_e5m2, 64)
       MI355_PREFILL_CASE(kv_e5m2, 128)
     }
   } else {
-    switch (p.head_size) {
+    switch (dpad) {
       MI355_PREFILL_CASE(kv_same, 64)
       MI355_PREFILL_CASE(kv_same, 128)
+      MI355_PREFILL_CASE(kv_same, 256)
     }
   }
 #undef MI355_PREFILL_CASE
