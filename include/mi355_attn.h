@@ -196,6 +196,15 @@ MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
  * `paged_attention_triton_2d/3d` (legacy/triton_paged_decode_attention_2d.py:283-398,
  * legacy/triton_paged_decode_attention_3d.py:348-499) and `chunked_prefill_paged_decode`
  * (legacy/triton_chunked_prefill_paged_decode.py:28-117).
+ *
+ * Which kernel serves a call (AUTO; mi355_last_kernel() names it afterwards):
+ *   matrix-core kernels - f16/bf16 queries, flash-layout cache of the same type or fp8 e4m3fn/e5m2 with scalar
+ *     scales, page size a power of two >= 16, head size any multiple of 8 (16 with an fp8 cache) up to 256 (run on
+ *     the next of 64/128/256; the reference pads to the next power of two, :353,:912; fp8 prefill up to 128):
+ *       max_seqlen_q == 1            -> split-KV decode ("decode_splitkv[_fp8]" / "decode_single[_fp8]")
+ *       every sequence a prefill     -> Q-block prefill ("prefill_mfma[_fp8][_feat]")
+ *       mixed batch                  -> both, prefill rows then decode rows ("prefill_mfma+decode_splitkv")
+ *   everything else (f32, other head sizes, the legacy v0 layout, linear new-token K/V) -> "generic".
  */
 MI355_API int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);
