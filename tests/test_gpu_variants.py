@@ -1,0 +1,48 @@
+"""-m gpu: the kernel variants the dispatcher picks by shape (or that an A/B switch pins) must each pass the parity
+tests on the SMALL shapes too, not only where the dispatcher would choose them. The switches are read once per
+process, so each variant runs a reduced selection of the parity tests in a child process (one at a time)."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(env_extra, selection):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *selection]
+    r = subprocess.run(cmd, cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"{env_extra}: {' '.join(selection)}\n{r.stdout[-3000:]}\n{r.stderr[-1000:]}"
+    assert " passed" in r.stdout
+
+
+def test_prefill_wide_workgroup_variant_on_small_shapes():
+    """8 waves / 256-row Q blocks / 3 stages / block table in LDS (auto-selected only for >= 4096 keys)."""
+    _run({"MI355_PREFILL": "d8"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
+                                   "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_golden.py"])
+
+
+def test_prefill_narrow_workgroup_variant_at_full_size():
+    """4 waves / 128-row Q blocks / 2 stages at the C2 size, where the dispatcher would pick the wide one."""
+    _run({"MI355_PREFILL": "d4"}, ["tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"])
+
+
+def test_prefill_register_staged_kernel_for_plain_head_size_128():
+    _run({"MI355_PREFILL": "v1"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"])
+
+
+def test_prefill_64_rows_per_wave_experimental_kernel():
+    _run({"MI355_PREFILL": "w64"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"])
+
+
+def test_decode_merge_in_a_launch_of_its_own():
+    """The separate merge kernel, also where the in-kernel last-arriver merge would be used."""
+    _run({"MI355_DECODE_MERGE_KERNEL": "1"}, ["tests/test_gpu_decode.py::test_decode_heads_and_head_sizes", "tests/test_gpu_decode.py::test_decode_split_counts_agree",
+                                              "tests/test_gpu_decode.py::test_decode_fp8_kv_cache_on_the_mfma_path"])
