@@ -203,7 +203,7 @@ MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
  *     the next of 64/128/256; the reference pads to the next power of two, :353,:912; fp8 prefill up to 128):
  *       max_seqlen_q == 1            -> split-KV decode ("decode_splitkv[_fp8]" / "decode_single[_fp8]")
  *       every sequence a prefill     -> Q-block prefill ("prefill_mfma[_fp8][_feat]")
- *       mixed batch                  -> both, prefill rows then decode rows ("prefill_mfma+decode_splitkv")
+ *       mixed batch                  -> both, prefill rows then decode rows ("<prefill kernel>+<decode kernel>", e.g. "prefill_mfma+decode_splitkv")
  *   everything else (f32, other head sizes, the legacy v0 layout, linear new-token K/V) -> "generic".
  */
 MI355_API int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,

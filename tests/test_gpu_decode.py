@@ -227,7 +227,7 @@ def test_mixed_batch_splits_into_prefill_and_decode_launches():
                                        inp["scale"], mode="2d", block_n=64)
     d = gpu_util.to_dev(inp)
     out, kernel = gpu_util.run_unified(d, inp["scale"])
-    assert kernel == "prefill_mfma+decode_splitkv"
+    assert kernel in ("prefill_mfma+decode_splitkv", "prefill_mfma+decode_single"), kernel
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
     # and the single-kernel 2D path gives the same answer

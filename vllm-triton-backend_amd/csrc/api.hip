@@ -120,8 +120,13 @@ int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t 
       pp.skip_decodes = 1;
       pd.only_decodes = 1;
       rc = launch_prefill(pp, s);
+      const char* prefill_name = g_kernel;
       if (rc == MI355_OK) rc = launch_decode(pd, workspace, workspace_bytes, s);
-      if (rc == MI355_OK) set_kernel_name("prefill_mfma+decode_splitkv");
+      if (rc == MI355_OK) {                      // "<prefill kernel>+<decode kernel>"
+        static thread_local char both[96];
+        snprintf(both, sizeof(both), "%s+%s", prefill_name, g_kernel);
+        set_kernel_name(both);
+      }
       break;
     }
     default:
