@@ -61,3 +61,26 @@ def test_pages_beyond_4_gib(case):
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
     del t
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("case", ["decode", "chunked_prefill"])
+def test_long_context_100k_keys(case):
+    """One sequence with ~100k keys (6250+ pages): decode (64 splits), and a 512-token chunk over that context (the wide
+    prefill kernel, whose block table is staged in LDS, runs the same case in tests/test_gpu_variants.py)."""
+    import gpu_util
+
+    ctx = 100_003
+    dtype = torch.bfloat16
+    if case == "decode":
+        query_lens, kv_lens, mode = [1, 1], [ctx, 70_001], "3d"
+    else:
+        query_lens, kv_lens, mode = [512, 300], [ctx + 512, 4096 + 300], "2d"
+    inp = orc.make_paged_inputs(60, query_lens, kv_lens, 8, 2, 128, 16, dtype)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode=mode, block_n=64)
+    t = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(t, inp["scale"])
+    assert kernel.startswith("decode" if case == "decode" else "prefill_mfma"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)

@@ -26,7 +26,8 @@ def _run(env_extra, selection):
 def test_prefill_wide_workgroup_variant_on_small_shapes():
     """8 waves / 256-row Q blocks / 3 stages / block table in LDS (auto-selected only for >= 4096 keys)."""
     _run({"MI355_PREFILL": "d8"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
-                                   "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_golden.py"])
+                                   "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_golden.py",
+                                   "tests/test_gpu_large_cache.py::test_long_context_100k_keys", "tests/test_gpu_large_cache.py::test_pages_beyond_4_gib"])
 
 
 def test_prefill_narrow_workgroup_variant_at_full_size():
