@@ -74,7 +74,7 @@ def test_decode_page_sizes(page):
     _check(inp, torch.bfloat16, force=None, expect="decode")
 
 
-@pytest.mark.parametrize("segments", [1, 2, 3, 16, 64])
+@pytest.mark.parametrize("segments", [1, 3, 64])
 def test_decode_split_counts_agree(segments):
     """Any split count must give the same answer (merge is exact up to fp32 rounding)."""
     import gpu_util

@@ -65,17 +65,17 @@ def test_pages_beyond_4_gib(case):
 
 @pytest.mark.parametrize("case", ["decode", "chunked_prefill"])
 def test_long_context_100k_keys(case):
-    """One sequence with ~100k keys (6250+ pages): decode (64 splits), and a 512-token chunk over that context (the wide
+    """One sequence with 100k-131k keys (6250-8192 pages): decode (64 splits), and a 128-token chunk over that context (the wide
     prefill kernel, whose block table is staged in LDS, runs the same case in tests/test_gpu_variants.py)."""
     import gpu_util
 
-    ctx = 100_003
+    ctx = 100_003 if case != "decode" else 131_071
     dtype = torch.bfloat16
     if case == "decode":
-        query_lens, kv_lens, mode = [1, 1], [ctx, 70_001], "3d"
+        query_lens, kv_lens, mode = [1], [ctx], "3d"
     else:
-        query_lens, kv_lens, mode = [512, 300], [ctx + 512, 4096 + 300], "2d"
-    inp = orc.make_paged_inputs(60, query_lens, kv_lens, 8, 2, 128, 16, dtype)
+        query_lens, kv_lens, mode = [128, 200], [ctx + 128, 4096 + 200], "2d"
+    inp = orc.make_paged_inputs(60, query_lens, kv_lens, 4, 1, 128, 16, dtype)
     ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
                                        inp["scale"], mode=mode, block_n=64)
     t = gpu_util.to_dev(inp)

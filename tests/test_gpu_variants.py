@@ -13,11 +13,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(env_extra, selection):
+def _run(env_extra, selection, keyword=None):
     env = dict(os.environ)
     env.update(env_extra)
     env["PYTHONDONTWRITEBYTECODE"] = "1"
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *selection]
+    if keyword:
+        cmd += ["-k", keyword]
     r = subprocess.run(cmd, cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"{env_extra}: {' '.join(selection)}\n{r.stdout[-3000:]}\n{r.stderr[-1000:]}"
     assert " passed" in r.stdout
@@ -27,7 +29,8 @@ def test_prefill_wide_workgroup_variant_on_small_shapes():
     """8 waves / 256-row Q blocks / 3 stages / block table in LDS (auto-selected only for >= 4096 keys)."""
     _run({"MI355_PREFILL": "d8"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
                                    "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_golden.py",
-                                   "tests/test_gpu_large_cache.py::test_long_context_100k_keys", "tests/test_gpu_large_cache.py::test_pages_beyond_4_gib"])
+                                   "tests/test_gpu_large_cache.py"],
+         keyword="(mixed and 128 and (8-2 or 32-1 or 6-2)) or page_sizes or strided or golden or chunked_prefill or prefill_dma")
 
 
 def test_prefill_narrow_workgroup_variant_at_full_size():
@@ -36,14 +39,17 @@ def test_prefill_narrow_workgroup_variant_at_full_size():
 
 
 def test_prefill_register_staged_kernel_for_plain_head_size_128():
-    _run({"MI355_PREFILL": "v1"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"])
+    _run({"MI355_PREFILL": "v1"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"],
+         keyword="(mixed and 128 and (8-2 or 32-1)) or c2_full")
 
 
 def test_prefill_64_rows_per_wave_experimental_kernel():
-    _run({"MI355_PREFILL": "w64"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"])
+    _run({"MI355_PREFILL": "w64"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"],
+         keyword="(mixed and 128 and (8-2 or 32-1)) or c2_full")
 
 
 def test_decode_merge_in_a_launch_of_its_own():
     """The separate merge kernel, also where the in-kernel last-arriver merge would be used."""
     _run({"MI355_DECODE_MERGE_KERNEL": "1"}, ["tests/test_gpu_decode.py::test_decode_heads_and_head_sizes", "tests/test_gpu_decode.py::test_decode_split_counts_agree",
-                                              "tests/test_gpu_decode.py::test_decode_fp8_kv_cache_on_the_mfma_path"])
+                                              "tests/test_gpu_decode.py::test_decode_fp8_kv_cache_on_the_mfma_path"],
+         keyword="(heads and (128-32-8 or 64-6-2 or 256-16-1)) or (counts and (3 or 64)) or (fp8 and 32-8-128 and dtype0)")
