@@ -664,6 +664,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     v_rd0[b] = (uint32_t)(KBUF + r0 * ROWB + ((lc ^ f0) << 4) + 8 * (pp & 1));
     v_rd1[b] = (uint32_t)(KBUF + r1 * ROWB + ((lc ^ f1) << 4) + 8 * (pp & 1));
   }
+  // ds_read's immediate offset reaches 64 KiB: stages 0 and 1 are immediates on the addresses above, a stage
+  // beyond that gets per-lane addresses of its own (16 VGPRs) instead of one v_add per read
+  constexpr bool HI_STAGE = NST > 2;
+  uint32_t k_rdH[HI_STAGE ? KSTEPS : 1], v_rd0H[HI_STAGE ? DBLK : 1], v_rd1H[HI_STAGE ? DBLK : 1];
+  if constexpr (HI_STAGE) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) k_rdH[ks] = k_rd[ks] + 2 * STAGE;
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b) { v_rd0H[b] = v_rd0[b] + 2 * STAGE; v_rd1H[b] = v_rd1[b] + 2 * STAGE; }
+  }
+  auto k_addr = [&](const char* stage, int ks) -> const char* {
+    if constexpr (HI_STAGE) { if (stage == smem + 2 * STAGE) return smem + k_rdH[ks]; }
+    return stage + k_rd[ks];
+  };
+  auto v_addr0 = [&](const char* stage, int b) -> const char* {
+    if constexpr (HI_STAGE) { if (stage == smem + 2 * STAGE) return smem + v_rd0H[b]; }
+    return stage + v_rd0[b];
+  };
+  auto v_addr1 = [&](const char* stage, int b) -> const char* {
+    if constexpr (HI_STAGE) { if (stage == smem + 2 * STAGE) return smem + v_rd1H[b]; }
+    return stage + v_rd1[b];
+  };
 
   float m_ref = 0.0f, l_run = 0.0f;
   bool started = !row_ok;               // padding rows never see a key: do not let them force the slow path
@@ -722,12 +744,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
 #else
     pu32x4_t kf[KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const pu32x4_t*)(stage + k_rd[ks]);
+    for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const pu32x4_t*)k_addr(stage, ks);
     __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       s_acc[0] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], ks == 0 ? cinit : s_acc[0]);
-      kf[ks] = *(const pu32x4_t*)(stage + 32 * ROWB + k_rd[ks]);
+      kf[ks] = *(const pu32x4_t*)(k_addr(stage, ks) + 32 * ROWB);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #ifndef MI355_ABLATE_DMA
@@ -792,15 +814,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
     }
-    float psum = 0.0f;
+    // row sum in four independent packed partial sums (v_pk_add_f32): a quarter of the add instructions and
+    // dependent chains of 4 instead of one of 32
+    pf32x2_t ps2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float e[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        e[r] = __builtin_amdgcn_exp2f(s_acc[kb][r]);
-        psum += e[r];
-      }
+      for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(s_acc[kb][r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) ps2[(r >> 1) & 3] += pf32x2_t{e[r], e[r + 1]};
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const pu32x4_t w = {pmma<T>::pack2(e[8 * s + 0], e[8 * s + 1]), pmma<T>::pack2(e[8 * s + 2], e[8 * s + 3]),
@@ -808,7 +831,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
         pf[2 * kb + s] = __builtin_bit_cast(ps16x8_t, w);
       }
     }
-    l_run += psum;
+    const pf32x2_t ps = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]);
+    l_run += ps[0] + ps[1];
 #endif
     MI355_STAMP(2);
   };
@@ -822,8 +846,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     auto read_v_block = [&](int b, ps16x8_t (&dst)[4]) {
 #pragma unroll
       for (int sk = 0; sk < 4; ++sk) {
-        const ps16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd0[b]));
-        const ps16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(stage + sk * 16 * ROWB + v_rd1[b]));
+        const ps16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(v_addr0(stage, b) + sk * 16 * ROWB));
+        const ps16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(v_addr1(stage, b) + sk * 16 * ROWB));
         dst[sk] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
     };
