@@ -39,7 +39,8 @@ def main():
     cu = (torch.arange(batch + 1, device=dev) * L).to(torch.int32)
     sl = torch.full((batch,), L, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
-    dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+    max_wgs = (batch * L // 32 + batch) * Hk + 64
+    dbg = torch.zeros(16 + 4 * max_wgs, dtype=torch.int64, device=dev)
     p, keep = ua.fill_attn_params(q, k, v, out, cu, L, sl, L, 1 / math.sqrt(D), (-1, -1), bt, 0.0, None, None, None, 2)
     addr = dbg.data_ptr()
     p.reserved0 = C.c_int32(addr & 0xFFFFFFFF).value
@@ -67,6 +68,53 @@ def main():
     print(f"  tile loop: {s[9]/max(s[11],1):.2f} ticks per tile; prologue+epilogue = {(s[8]+s[10])/n/(s[9]/max(s[11],1)):.2f} tiles' worth per WG")
     slots = 512
     print(f"  sum of WG lives / {slots} slots = {(s[8]+s[9]+s[10])/slots:.0f} ticks vs span {span}")
+    # ---- schedule reconstruction -------------------------------------------------------------------
+    recs = [s[16 + 4 * i: 20 + 4 * i] for i in range(max_wgs)]
+    recs = [(i, r) for i, r in enumerate(recs) if r[1] != 0]
+    if not recs:
+        return
+    # records carry s_memrealtime stamps (100 MHz, one counter for the chip)
+    def xcc_of(r):
+        return (r[2] >> 32) & 0xF
+    t_first = min(r[0] for _, r in recs)
+    tmin = {x: t_first for x in range(16)}
+    per_cu = {}
+    for i, r in recs:
+        hw = r[2] & 0xFFFFFFFF
+        xcc = xcc_of(r)
+        cu = (xcc, (hw >> 13) & 0x7, (hw >> 12) & 0x1, (hw >> 8) & 0xF)   # (xcc, se, sh, cu)
+        per_cu.setdefault(cu, []).append((r[0] - tmin[xcc], r[1] - tmin[xcc], i, r[3]))
+    span2 = max(e for v in per_cu.values() for _, e, _, _ in v)
+    busy = sorted(sum(e - b for b, e, _, _ in v) / span2 for v in per_cu.values())
+    ends = sorted(max(e for _, e, _, _ in v) / span2 for v in per_cu.values())
+    starts = sorted(min(b for b, _, _, _ in v) / span2 for v in per_cu.values())
+    nw = sorted(len(v) for v in per_cu.values())
+    print(f"  schedule: {len(recs)} workgroups on {len(per_cu)} CUs, first entry -> last exit {span2 / 100:.1f} us (event time {us:.1f} us)")
+    print(f"    workgroups per CU: min {nw[0]} median {nw[len(nw)//2]} max {nw[-1]}")
+    print(f"    CU busy fraction of the span: min {busy[0]:.3f} p10 {busy[len(busy)//10]:.3f} median {busy[len(busy)//2]:.3f} max {busy[-1]:.3f} mean {sum(busy)/len(busy):.3f}")
+    print(f"    first start: median {starts[len(starts)//2]:.3f} max {starts[-1]:.3f}; last end: min {ends[0]:.3f} p10 {ends[len(ends)//10]:.3f} median {ends[len(ends)//2]:.3f}")
+    gaps = sorted((sorted(v)[1][0] - sorted(v)[0][1]) / span2 for v in per_cu.values() if len(v) >= 2)
+    if gaps:
+        print(f"    gap between a CU's first and second workgroup: median {gaps[len(gaps)//2]:.4f} max {gaps[-1]:.4f} of the span")
+    xspan = {}
+    for cu, v in per_cu.items():
+        xspan[cu[0]] = max(xspan.get(cu[0], 0), max(e for _, e, _, _ in v))
+    print("    last exit per XCC (us after the first entry):", {k: round(v / 100, 1) for k, v in sorted(xspan.items())})
+    xs = {}
+    for cu, v in per_cu.items():
+        xs.setdefault(cu[0], []).append(sum(e - b for b, e, _, _ in v) / span2)
+    print("    mean busy fraction per XCC:", {k: round(sum(v) / len(v), 3) for k, v in sorted(xs.items())}, "CUs per XCC:", {k: len(v) for k, v in sorted(xs.items())})
+    worst = max(per_cu.items(), key=lambda kv: max(e for _, e, _, _ in kv[1]))
+    print("    CU that finishes last:", worst[0], [(round(b / 100, 1), round(e / 100, 1), int(t)) for b, e, _, t in sorted(worst[1])][:8], "(start us, end us, tiles)")
+    r1 = sorted(e for v in per_cu.values() for b, e, _, _ in v if b < span2 * 0.1)
+    r2 = sorted(b for v in per_cu.values() for b, e, _, _ in v if b >= span2 * 0.1)
+    if r1 and r2:
+        print(f"    first round ends {r1[0]/100:.1f}..{r1[-1]/100:.1f} us, later rounds start {r2[0]/100:.1f}..{r2[-1]/100:.1f} us")
+    heads = {}
+    for cu, v in per_cu.items():
+        for b, e, i, t in v:
+            heads.setdefault(i % Hk, set()).add(cu[0])
+    print("    XCCs each KV head ran on:", {h: sorted(x) for h, x in sorted(heads.items())})
 
 
 if __name__ == "__main__":

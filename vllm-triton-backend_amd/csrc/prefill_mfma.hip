@@ -485,8 +485,12 @@ constexpr float kDeferThr = 8.0f;
 #define MI355_WG_STAMP(var)                                                                \
   unsigned long long var;                                                                  \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define MI355_WG_REALTIME(var)                                                             \
+  unsigned long long var;                                                                  \
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
 #else
 #define MI355_WG_STAMP(var) do { } while (0)
+#define MI355_WG_REALTIME(var) do { } while (0)
 #endif
 
 // NW waves of 32 rows share the staged K/V tiles (Q block = 32*NW rows), NST stages of 32 KiB.
@@ -517,6 +521,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.group, BQ = a.block_q;
   MI355_WG_STAMP(wg_t0);
+  MI355_WG_REALTIME(wg_r0);
 
   const int head = (int)(blockIdx.x % p.num_kv_heads);
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);
@@ -926,13 +931,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
       for (int c = 0; c < 4; ++c) {
         const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
                             pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
-        *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+        *(pu32x2_t*)(op + 32 * b + 8 * c) = w;   // plain stores: nontemporal 8-byte pieces cost 16 % (no write-combining in L2)
       }
   }
 #ifdef MI355_PROFILE_WG
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MI355_WG_STAMP(wg_t3);
+    MI355_WG_REALTIME(wg_r3);
     unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
     if (dbg && tid == 0) {
       atomicAdd(dbg + 8, wg_t1 - wg_t0);     // prologue: entry -> first tile staged
@@ -944,6 +950,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
       atomicAdd(dbg + 12, 1ull);
       atomicMin(dbg + 13, wg_t0);
       atomicMax(dbg + 14, wg_t3);
+      // per-workgroup record for schedule reconstruction: entry, exit, where it ran, how many tiles
+      const unsigned hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+      const unsigned xcc_id = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+      unsigned long long* rec = dbg + 16 + 4ull * blockIdx.x;
+      // rec[0..1]: s_memrealtime, 100 MHz, one counter for the whole chip
+      rec[0] = wg_r0; rec[1] = wg_r3; rec[2] = ((unsigned long long)xcc_id << 32) | hw_id; rec[3] = (unsigned long long)tile_hi;
     }
   }
 #endif
