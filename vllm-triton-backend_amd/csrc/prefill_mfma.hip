@@ -922,8 +922,35 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   }
 #endif
   l_run += lane_xor32(l_run);
-  if (row_ok) {
-    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+  const float inv = (row_ok && l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+  // O leaves through LDS: a lane owns 8-byte pieces of one row (the accumulator layout), which as global stores
+  // touch 32 rows per instruction. Each wave parks its 32 rows in its own corner of the (now idle) stages and
+  // writes them out as whole 256-byte rows, 16 bytes per lane. (Nontemporal stores of the 8-byte pieces were
+  // measured 16 % slower over the whole kernel: no write-combining.) Needs 16-byte aligned output rows.
+  const bool wide_store = (((uintptr_t)p.out & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
+  if (wide_store) {
+    constexpr int ORS = ROWB + 16;                       // padded row stride of the parked rows
+    char* ost = smem + wave * (32 * ORS);
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
+                            pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+        *(pu32x2_t*)(ost + qr * ORS + (32 * b + 8 * c + 4 * half) * 2) = w;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same wave reads other lanes' pieces back: LDS is in order per wave
+    const int orow = lane >> 4, och = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 4 * j + orow;
+      const int m = wave * 32 + r;                       // row inside the Q block
+      const int tok = tok0 + m / G;
+      const pu32x4_t v = *(const pu32x4_t*)(ost + r * ORS + och * 16);
+      if (m < BQ * G && tok < q_len)
+        *(pu32x4_t*)((uint16_t*)p.out + (int64_t)(q_start + tok) * p.out_stride_token + (int64_t)(head * G + m % G) * p.out_stride_head + och * 8) = v;
+    }
+  } else if (row_ok) {
     uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
@@ -931,7 +958,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
       for (int c = 0; c < 4; ++c) {
         const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
                             pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
-        *(pu32x2_t*)(op + 32 * b + 8 * c) = w;   // plain stores: nontemporal 8-byte pieces cost 16 % (no write-combining in L2)
+        *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
       }
   }
 #ifdef MI355_PROFILE_WG
