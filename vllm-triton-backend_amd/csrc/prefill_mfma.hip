@@ -429,17 +429,45 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
 
   // ---- epilogue: O = O^T / l, lane (qr, half) register r of block b <-> d = 32b + (r&3) + 8(r>>2) + 4half
   l_run += lane_xor32(l_run);
-  if (!row_ok) return;
-  const float inv = l_run > 0.0f ? v_scale / l_run : 0.0f;
-  uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
+  const float inv = (row_ok && l_run > 0.0f) ? v_scale / l_run : 0.0f;
+  // O leaves through LDS as whole rows, 16 bytes per lane, nontemporal (see prefill_dma_kernel's epilogue); the
+  // 8-byte pieces of the accumulator layout go out directly only when the output rows are not 16-byte aligned.
+  const bool wide_store = (((uintptr_t)p.out & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
+  if (wide_store) {
+    constexpr int ORS = D * 2 + 16;                      // padded row stride of the parked rows
+    constexpr int CPR = D / 8, RPI = 64 / CPR;           // 16-byte chunks per row, rows per store instruction
+    char* ost = smem + wave * (32 * ORS);                // every wave is past the last tile's barrier: the stages are idle
 #pragma unroll
-  for (int b = 0; b < DBLK; ++b)
+    for (int b = 0; b < DBLK; ++b)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
-                          pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
-      if (32 * b + 8 * c + 4 * half < a.d_valid) *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+      for (int c = 0; c < 4; ++c) {
+        const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
+                            pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+        *(pu32x2_t*)(ost + qr * ORS + (32 * b + 8 * c + 4 * half) * 2) = w;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int orow = lane / CPR, och = lane % CPR;
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const int r = RPI * j + orow;
+      const int m = wave * 32 + r;
+      const int tok = tok0 + m / G;
+      const pu32x4_t v = *(const pu32x4_t*)(ost + r * ORS + och * 16);
+      if (m < BQ * G && tok < q_len && och * 8 < a.d_valid)
+        __builtin_nontemporal_store(v, (pu32x4_t*)((uint16_t*)p.out + (int64_t)(q_start + tok) * p.out_stride_token +
+                                                   (int64_t)(head * G + m % G) * p.out_stride_head + och * 8));
     }
+  } else if (row_ok) {
+    uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
+                            pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+        if (32 * b + 8 * c + 4 * half < a.d_valid) *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
+      }
+  }
 }
 
 // =============================================================================================
