@@ -200,7 +200,9 @@ def main():
                        "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
             "roofline": {"bound": "mfma", "achieved": round(pf_ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(pf_ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": measured_traffic("prefill_dma_kernel"), "kernel": pf["kernel"],
-                         "kernel_us": round(pf["per_launch"] * 1e6, 2), "algorithmic_flops_per_launch": pf["w"]["flops"]},
+                         "kernel_us": round(pf["per_launch"] * 1e6, 2), "algorithmic_flops_per_launch": pf["w"]["flops"],
+                         "note": "peak = nominal dense bf16 MFMA rate; the package is power-limited (1.4 kW) under MFMA load: a dense bf16 "
+                                 "hipBLASLt GEMM sustains 1403 TFLOP/s on the same chip (profiles/r01/gemm_reference_point.log)"},
             "decode": {"metric": "KV GB/s (paged decode)", "value": round(dc_val, 1), "unit": "GB/s", "ms_per_step": round(dc["wall"] / K * 1e3, 4),
                        "config": {"workload": "C3 decode: Hq32/Hk8/D128, batch 64 x kv_len 8192 per GPU, bf16, 16-token pages",
                                   "global_batch": 64 * n_gpus, "kernel": dc["kernel"]},
