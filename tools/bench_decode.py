@@ -15,6 +15,8 @@ from mi355_attn.kernels import unified as ua_mod  # noqa: E402
 
 
 def main():
+    if os.environ.get("MI355_LIB"):        # A/B: benchmark another build of the library on the same box
+        _lib.LIB_PATH = os.path.abspath(os.environ["MI355_LIB"])
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--kv", type=int, default=8192)

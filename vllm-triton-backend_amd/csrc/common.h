@@ -211,6 +211,32 @@ __device__ __forceinline__ void scalar_load4(const int32_t* base, int i0, int i1
       : "memory");
 }
 
+// Four fp8 values (one 32-bit word) -> four values of the 16-bit type T as two packed words, exact. gfx950 converts a
+// PAIR of fp8 straight to packed bf16/f16 in one instruction (v_cvt_scalef32_pk_{bf16,f16}_{fp8,bf8}, scale 1.0):
+// half the instructions of fp8 -> f32 -> pack.
+template <typename T, typename KVT>
+__device__ __forceinline__ void widen_fp8x4(uint32_t in, uint32_t& lo, uint32_t& hi) {
+  if constexpr (__is_same(T, bf16_t)) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 pk_t;
+    if constexpr (__is_same(KVT, e4m3_t)) {
+      lo = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(in, 1.0f, false));
+      hi = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(in, 1.0f, true));
+    } else {
+      lo = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(in, 1.0f, false));
+      hi = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(in, 1.0f, true));
+    }
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 pk_t;
+    if constexpr (__is_same(KVT, e4m3_t)) {
+      lo = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(in, 1.0f, false));
+      hi = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(in, 1.0f, true));
+    } else {
+      lo = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(in, 1.0f, false));
+      hi = __builtin_bit_cast(uint32_t, (pk_t)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(in, 1.0f, true));
+    }
+  }
+}
+
 // One word at `w` and two words of `base` in the same scalar round trip (all wave-uniform).
 __device__ __forceinline__ void scalar_load_word_and_pair(const int32_t* w, const int32_t* base, int i0, int i1, int& rw, int& r0, int& r1) {
   const int o0 = __builtin_amdgcn_readfirstlane(i0 * 4), o1 = __builtin_amdgcn_readfirstlane(i1 * 4);

@@ -89,18 +89,7 @@ template <typename T, typename KVT>
 __device__ __forceinline__ void widen_fp8x16(u32x4_t in, u32x4_t& lo, u32x4_t& hi) {
   uint32_t o[8];
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    f32x2_t a, b;
-    if constexpr (__is_same(KVT, e4m3_t)) {
-      a = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], false);
-      b = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], true);
-    } else {
-      a = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], false);
-      b = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], true);
-    }
-    o[2 * w] = mma<T>::pack2(a[0], a[1]);
-    o[2 * w + 1] = mma<T>::pack2(b[0], b[1]);
-  }
+  for (int w = 0; w < 4; ++w) widen_fp8x4<T, KVT>(in[w], o[2 * w], o[2 * w + 1]);
   lo = u32x4_t{o[0], o[1], o[2], o[3]};
   hi = u32x4_t{o[4], o[5], o[6], o[7]};
 }

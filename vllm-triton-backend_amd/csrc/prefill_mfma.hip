@@ -85,18 +85,7 @@ template <typename T, typename KVT>
 __device__ __forceinline__ void widen_fp8_piece(pu32x4_t in, pu32x4_t& lo, pu32x4_t& hi) {
   uint32_t o[8];
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    pf32x2_t a, b;
-    if constexpr (__is_same(KVT, e4m3_t)) {
-      a = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], false);
-      b = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], true);
-    } else {
-      a = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], false);
-      b = __builtin_amdgcn_cvt_pk_f32_bf8(in[w], true);
-    }
-    o[2 * w] = pmma<T>::pack2(a[0], a[1]);
-    o[2 * w + 1] = pmma<T>::pack2(b[0], b[1]);
-  }
+  for (int w = 0; w < 4; ++w) widen_fp8x4<T, KVT>(in[w], o[2 * w], o[2 * w + 1]);
   lo = pu32x4_t{o[0], o[1], o[2], o[3]};
   hi = pu32x4_t{o[4], o[5], o[6], o[7]};
 }
