@@ -24,7 +24,9 @@ def main():
     cmd = sys.argv[sys.argv.index("--") + 1:]
     os.makedirs(out_dir, exist_ok=True)
     res = {}
-    for i, group in enumerate(PASSES):
+    sel = os.environ.get("PMC_PASSES")
+    passes = [PASSES[int(x)] for x in sel.split(",")] if sel else PASSES
+    for i, group in enumerate(passes):
         d = os.path.join(out_dir, f"pass{i}")
         rc = subprocess.call(["rocprofv3", "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", d, "--", *cmd],
                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
