@@ -33,7 +33,9 @@ def _check(inp, dtype, *, force, window=0, softcap=0.0, alibi=None, expect=None,
 @pytest.mark.parametrize("hq,hk", [(32, 8), (8, 8), (16, 1), (40, 8), (6, 2)])
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_decode_heads_and_head_sizes(dtype, hq, hk, d):
-    kv_lens = [1, 15, 16, 17, 31, 32, 33, 700, 1023, 257]
+    if dtype == torch.float16 and d != 128:
+        pytest.skip("fp16 is covered at head size 128; the other head sizes run in bf16 (suite run time)")
+    kv_lens = [1, 15, 16, 17, 33, 257, 1023]
     inp = orc.make_paged_inputs(5, [1] * len(kv_lens), kv_lens, hq, hk, d, 16, dtype)
     _check(inp, dtype, force=None, expect="decode")
 
