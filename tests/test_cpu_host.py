@@ -177,6 +177,30 @@ def test_plugin_surface_matches_the_reference_contract():
     platform.envs.VLLM_USE_V1 = True
 
 
+def test_op_signatures_keep_the_reference_parameter_names():
+    """Parameter names and order of the ops a user of the reference package calls (LIB/kernels/__init__.py:65-71,
+    triton_unified_attention.py:839-860, triton_flash_attention.py:1326-1340), recorded from the reference."""
+    import inspect
+
+    from mi355_attn import kernels
+
+    def names(f):
+        return list(inspect.signature(f).parameters)
+
+    assert names(kernels.unified_attention) == [
+        "q", "k", "v", "out", "cu_seqlens_q", "max_seqlen_q", "seqused_k", "max_seqlen_k", "avg_seqlen_q", "avg_seqlen_k",
+        "softmax_scale", "causal", "window_size", "block_table", "softcap", "q_descale", "k_descale", "v_descale",
+        "alibi_slopes", "force_selection"]
+    assert names(kernels.prefill_flash_attention) == [
+        "q", "k", "v", "max_seqlen_q", "max_seqlen_k", "cu_seqlens_q", "cu_seqlens_k", "causal", "sm_scale", "bias", "config",
+        "in_place_output", "do_not_return_softmax_encodings"]
+    sig = inspect.signature(kernels.prefill_flash_attention)
+    assert sig.parameters["causal"].default is False and sig.parameters["sm_scale"].default == 1.0
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        kernels.prefill_flash_attention(torch.zeros(4, 2, 64), torch.zeros(4, 2, 64), torch.zeros(4, 2, 64), 4, 4,
+                                        torch.tensor([0, 4]), torch.tensor([0, 4]), causal=True)
+
+
 def test_metadata_builder_mirrors_the_reference():
     from mi355_attn.backend import attn
 

@@ -1,0 +1,74 @@
+"""-m gpu: `prefill_flash_attention` (the reference's non-paged varlen prefill op, LIB/kernels/triton_flash_attention.py:
+1326-1484) against an independent dense float64 softmax, incl. seqlen_q < seqlen_k (bottom-right aligned causal mask),
+grouped-query heads, lengths that are not multiples of the 16-token scratch page, and in-place output."""
+
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_reference(q, k, v, cu_q, cu_k, scale):
+    Hq, Hk = q.shape[1], k.shape[1]
+    G = Hq // Hk
+    out = torch.zeros(q.shape, dtype=torch.float64)
+    for i in range(len(cu_q) - 1):
+        q0, q1, k0, k1 = cu_q[i], cu_q[i + 1], cu_k[i], cu_k[i + 1]
+        lq, lk = q1 - q0, k1 - k0
+        qp = torch.arange(lq)[:, None] + (lk - lq)
+        mask = torch.arange(lk)[None, :] <= qp
+        for h in range(Hq):
+            s = scale * (q[q0:q1, h].double() @ k[k0:k1, h // G].double().T)
+            s = s.masked_fill(~mask, float("-inf"))
+            p = torch.softmax(s, dim=-1)
+            p = torch.nan_to_num(p, nan=0.0)            # rows that see no key (lq > lk) return 0
+            out[q0:q1, h] = p @ v[k0:k1, h // G].double()
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk,d", [(8, 2, 128), (4, 4, 64), (8, 1, 96)])
+def test_varlen_causal_prefill(dtype, hq, hk, d):
+    from mi355_attn import _lib
+    from mi355_attn.kernels import prefill_flash_attention
+
+    g = torch.Generator().manual_seed(70 + hq + d)
+    q_lens = [129, 1, 64, 200, 17]
+    k_lens = [129, 45, 257, 200, 33]
+    cu_q = [0] + torch.tensor(q_lens).cumsum(0).tolist()
+    cu_k = [0] + torch.tensor(k_lens).cumsum(0).tolist()
+    q = (torch.rand(cu_q[-1], hq, d, generator=g) * 2 - 1).to(dtype)
+    k = (torch.rand(cu_k[-1], hk, d, generator=g) * 2 - 1).to(dtype)
+    v = (torch.rand(cu_k[-1], hk, d, generator=g) * 2 - 1).to(dtype)
+    scale = 1.0 / math.sqrt(d)
+    ref = _dense_reference(q, k, v, cu_q, cu_k, scale)
+    dev = torch.device("cuda:0")
+    cq = torch.tensor(cu_q, dtype=torch.int32, device=dev)
+    ck = torch.tensor(cu_k, dtype=torch.int32, device=dev)
+    out = prefill_flash_attention(q.to(dev), k.to(dev), v.to(dev), max(q_lens), max(k_lens), cq, ck, causal=True, sm_scale=scale)
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("prefill_mfma"), _lib.last_kernel()
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(out.double().cpu(), ref, atol=tol, rtol=tol)
+    # in-place output buffer
+    buf = torch.full_like(q.to(dev), float("nan"))
+    ret = prefill_flash_attention(q.to(dev), k.to(dev), v.to(dev), max(q_lens), max(k_lens), cq, ck, causal=True, sm_scale=scale,
+                                  in_place_output=buf)
+    assert ret is buf
+    torch.testing.assert_close(buf.double().cpu(), ref, atol=tol, rtol=tol)
+
+
+def test_varlen_unsupported_modes_raise():
+    from mi355_attn.kernels import prefill_flash_attention
+
+    dev = torch.device("cuda:0")
+    q = torch.zeros(16, 4, 64, dtype=torch.bfloat16, device=dev)
+    cu = torch.tensor([0, 16], dtype=torch.int32, device=dev)
+    with pytest.raises(NotImplementedError):
+        prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=False)
+    with pytest.raises(NotImplementedError):
+        prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=True, bias=torch.zeros(1, device=dev))
+    with pytest.raises(NotImplementedError):
+        prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=True, do_not_return_softmax_encodings=False)

@@ -3,5 +3,6 @@
 
 from .unified import unified_attention
 from .cache import reshape_and_cache_flash
+from .flash import prefill_flash_attention
 
-__all__ = ["unified_attention", "reshape_and_cache_flash"]
+__all__ = ["unified_attention", "reshape_and_cache_flash", "prefill_flash_attention"]

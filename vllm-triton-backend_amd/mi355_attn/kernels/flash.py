@@ -1,0 +1,73 @@
+"""`prefill_flash_attention` — the reference package's non-paged variable-length prefill op
+(`triton_wrapper_forward_prefill`, LIB/kernels/triton_flash_attention.py:1326-1484, exported at
+LIB/kernels/__init__.py:65-67), served by the paged MFMA kernels: K/V are laid out as 16-token pages in a scratch cache
+(one pass of `reshape_and_cache_flash`, pages of a sequence contiguous) and `unified_attention` runs over them.
+Everything is device-side torch arithmetic on `cu_seqlens_*`: no host synchronisation.
+
+Served: the "thd" variable-length layout (`q [total_q, Hq, D]`, `k, v [total_k, Hk, D]`), causal masking with the
+reference's bottom-right alignment (query t of a sequence sees keys j <= t + seqlen_k - seqlen_q, :954-960),
+grouped-query heads. Not served (raise `NotImplementedError`, nothing silently ignored): non-causal attention, `bias`,
+softmax encodings, dropout.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .cache import reshape_and_cache_flash
+from .unified import unified_attention
+
+_PAGE = 16
+
+
+def prefill_flash_attention(
+    q,
+    k,
+    v,
+    max_seqlen_q,
+    max_seqlen_k,
+    cu_seqlens_q,
+    cu_seqlens_k,
+    causal=False,
+    sm_scale=1.0,
+    bias=None,
+    config=None,
+    in_place_output=None,
+    do_not_return_softmax_encodings=True,
+):
+    if not q.is_cuda:
+        raise RuntimeError("mi355_attn.prefill_flash_attention needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
+    if not causal:
+        raise NotImplementedError("prefill_flash_attention: only causal attention is served by the paged kernels")
+    if bias is not None:
+        raise NotImplementedError("prefill_flash_attention: bias is not supported")
+    if not do_not_return_softmax_encodings:
+        raise NotImplementedError("prefill_flash_attention: softmax encodings are not produced")
+    if cu_seqlens_q is None or cu_seqlens_k is None:
+        raise NotImplementedError("prefill_flash_attention: only the variable-length (thd) layout is served")
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3 or k.shape != v.shape:
+        raise ValueError("q must be [total_q, Hq, D] and k, v [total_k, Hk, D]")
+    total_k, hk, d = k.shape
+    dev = q.device
+    cu_k = cu_seqlens_k.to(torch.int64)
+    num_seqs = cu_k.numel() - 1
+    lens = cu_k[1:] - cu_k[:-1]
+    pages_per_seq = (lens + (_PAGE - 1)) // _PAGE
+    page_base = torch.cumsum(pages_per_seq, 0) - pages_per_seq
+    tok_seq = torch.repeat_interleave(torch.arange(num_seqs, device=dev), lens, output_size=total_k)
+    tok_pos = torch.arange(total_k, device=dev) - cu_k[tok_seq]
+    slot_mapping = page_base[tok_seq] * _PAGE + tok_pos
+    num_pages = total_k // _PAGE + num_seqs                      # host-known upper bound of sum(ceil(len / 16))
+    k_cache = torch.empty((num_pages, _PAGE, hk, d), dtype=k.dtype, device=dev)
+    v_cache = torch.empty_like(k_cache)
+    reshape_and_cache_flash(k, v, k_cache, v_cache, slot_mapping, "auto", None, None)
+    max_pages = (int(max_seqlen_k) + _PAGE - 1) // _PAGE
+    block_table = (page_base[:, None] + torch.arange(max_pages, device=dev)[None, :]).clamp_(max=num_pages - 1).to(torch.int32)
+    out = in_place_output if in_place_output is not None else torch.empty_like(q)
+    unified_attention(
+        q=q, k=k_cache, v=v_cache, out=out, cu_seqlens_q=cu_seqlens_q.to(torch.int32), max_seqlen_q=int(max_seqlen_q),
+        seqused_k=lens.to(torch.int32), max_seqlen_k=int(max_seqlen_k), avg_seqlen_q=0.0, avg_seqlen_k=0.0,
+        softmax_scale=float(sm_scale), causal=True, window_size=(-1, -1), block_table=block_table, softcap=0.0,
+        q_descale=None, k_descale=None, v_descale=None,
+    )
+    return out
