@@ -1,0 +1,63 @@
+"""-m gpu: seeded random differential test. The matrix-core kernels (whatever the dispatcher picks) against the
+shape-agnostic VALU kernel (`force_selection=9`, independent code, fp32 math) over random batches, head counts, head
+sizes, page sizes, dtypes, fp8 caches and features. The generic kernel itself is pinned by the golden fixtures and the
+oracle (tests/test_gpu_golden.py); here it stands in for the oracle so that many cases run in seconds."""
+
+import math
+import random
+
+import pytest
+import torch
+
+import golden_io
+from oracle import paged_attention_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = 160
+
+
+def _random_case(rng):
+    n_seq = rng.randint(1, 6)
+    kind = rng.choice(["decode", "prefill", "mixed", "mixed"])
+    q_lens, kv_lens = [], []
+    for _ in range(n_seq):
+        if kind == "decode" or (kind == "mixed" and rng.random() < 0.5):
+            ql = 1
+        else:
+            ql = rng.choice([2, 5, 16, 31, 64, 65, 129, 200, 300])
+        ctx = rng.choice([0, 0, 1, 15, 16, 17, 63, 64, 255, 700, 1500])
+        q_lens.append(ql)
+        kv_lens.append(ql + ctx)
+    hk = rng.choice([1, 2, 4, 8])
+    g = rng.choice([1, 2, 3, 4, 5, 8, 16])
+    d = rng.choice([64, 64, 96, 128, 128, 128, 256, 32, 160])
+    page = rng.choice([16, 16, 32, 64])
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    kv_dtype = rng.choice([None, None, torch.float8_e4m3fn, torch.float8_e5m2]) if d % 16 == 0 else None
+    window = rng.choice([0, 0, 0, 7, 64, 300])
+    softcap = rng.choice([0.0, 0.0, 0.0, 25.0])
+    use_alibi = rng.random() < 0.2
+    return dict(q_lens=q_lens, kv_lens=kv_lens, hq=hk * g, hk=hk, d=d, page=page, dtype=dtype, kv_dtype=kv_dtype, window=window,
+                softcap=softcap, use_alibi=use_alibi)
+
+
+@pytest.mark.parametrize("case_id", range(CASES))
+def test_fast_kernels_agree_with_the_generic_kernel(case_id):
+    import gpu_util
+
+    rng = random.Random(1000 + case_id)
+    c = _random_case(rng)
+    kw = dict(kv_dtype=c["kv_dtype"], kv_scale=0.5) if c["kv_dtype"] is not None else {}
+    inp = orc.make_paged_inputs(2000 + case_id, c["q_lens"], c["kv_lens"], c["hq"], c["hk"], c["d"], c["page"], c["dtype"], **kw)
+    t = gpu_util.to_dev(inp)
+    if c["use_alibi"]:
+        t["alibi_slopes"] = torch.tensor([2.0 ** (-(i % 8 + 1)) for i in range(c["hq"])], dtype=torch.float32, device=gpu_util.DEV)
+    scale = 1.0 / math.sqrt(c["d"])
+    kv_scale = 0.5 if c["kv_dtype"] is not None else None
+    ref, ref_kernel = gpu_util.run_unified(t, scale, window=c["window"], softcap=c["softcap"], kv_scale=kv_scale, force=9)
+    assert ref_kernel == "generic"
+    out, kernel = gpu_util.run_unified(t, scale, window=c["window"], softcap=c["softcap"], kv_scale=kv_scale)
+    assert not torch.isnan(out).any(), (kernel, c)
+    atol, rtol = golden_io.tolerance(c["dtype"], c["kv_dtype"])
+    torch.testing.assert_close(out.float(), ref.float(), atol=atol, rtol=rtol, msg=lambda m: f"[{kernel}] {c}\n{m}")
