@@ -29,8 +29,8 @@ def test_prefill_wide_workgroup_variant_on_small_shapes():
     """8 waves / 256-row Q blocks / 3 stages / block table in LDS (auto-selected only for >= 4096 keys)."""
     _run({"MI355_PREFILL": "d8"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
                                    "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_golden.py",
-                                   "tests/test_gpu_large_cache.py"],
-         keyword="(mixed and 128 and (8-2 or 32-1 or 6-2)) or page_sizes or strided or golden or chunked_prefill or prefill_dma")
+                                   "tests/test_gpu_large_cache.py", "tests/test_gpu_fuzz.py"],
+         keyword="(mixed and 128 and (8-2 or 32-1 or 6-2)) or page_sizes or strided or golden or chunked_prefill or prefill_dma or agree")
 
 
 def test_prefill_narrow_workgroup_variant_at_full_size():
