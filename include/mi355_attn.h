@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 100 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 200 /* major*10000 + minor*100 + patch */
 
 #if defined(__GNUC__)
 #define MI355_API __attribute__((visibility("default")))
@@ -137,6 +137,14 @@ typedef struct mi355_attn_params {
   int32_t kernel_select;       /* mi355_kernel_select                                            */
   int32_t num_segments;        /* split-KV segment count for MI355_SELECT_3D; 0 = library picks  */
   int32_t reserved1;
+
+  /* optional second output (library version >= 0.2.0; not in the reference): the natural-log sum of exponentials of every
+   * row's masked, scaled scores, fp32. With it partial results over disjoint key ranges - e.g. one long sequence whose
+   * pages are striped over GPUs, SURVEY.md 8e "cross-GPU split-KV" - merge exactly:
+   *   lse = log sum_r exp(lse_r),  out = sum_r out_r * exp(lse_r - lse)      (same math as reduce_segments, :804-828)
+   * A row that sees no key gets -inf (and out 0). NULL = not wanted. */
+  float* lse;                  /* [num_tokens, Hq] or NULL                                        */
+  int64_t lse_stride_token;    /* elements between tokens; heads are contiguous                   */
 } mi355_attn_params;
 
 /*

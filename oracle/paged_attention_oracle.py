@@ -150,13 +150,16 @@ def unified_attention_oracle(
 
 def dense_attention_fp64(
     q, k_cache, v_cache, cu_seqlens_q, seqused_k, block_table, scale, sliding_window=0, softcap=0.0,
-    alibi_slopes=None, k_scale=1.0, v_scale=1.0,
-) -> torch.Tensor:
-    """Independent check: gather, one dense softmax per (sequence, head) in float64."""
+    alibi_slopes=None, k_scale=1.0, v_scale=1.0, return_lse=False,
+):
+    """Independent check: gather, one dense softmax per (sequence, head) in float64. With `return_lse` also the
+    log-sum-exp of every row's masked scores [T, Hq] (-inf for a row that sees no key): the library's optional second
+    output, which the reference does not have."""
     T, Hq, D = q.shape
     page, Hk = k_cache.shape[1], k_cache.shape[2]
     G = Hq // Hk
     out = torch.zeros(T, Hq, D, dtype=torch.float64)
+    lse = torch.full((T, Hq), NEG_INF, dtype=torch.float64)
     cu = cu_seqlens_q.tolist()
     for i in range(len(seqused_k)):
         q0, q1 = cu[i], cu[i + 1]
@@ -183,7 +186,9 @@ def dense_attention_fp64(
             P = torch.softmax(S, dim=-1)
             P = torch.nan_to_num(P, nan=0.0)
             out[q0:q1, hq] = P @ V
-    return out
+            if seq_len > 0:
+                lse[q0:q1, hq] = torch.logsumexp(S, dim=-1)
+    return (out, lse) if return_lse else out
 
 
 def reshape_and_cache_flash_oracle(key, value, key_cache, value_cache, slot_mapping, k_scale=1.0, v_scale=1.0):

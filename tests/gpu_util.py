@@ -12,7 +12,7 @@ def to_dev(d):
     return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
 
 
-def run_unified(t, scale, *, window=0, softcap=0.0, kv_scale=None, force=None, out=None):
+def run_unified(t, scale, *, window=0, softcap=0.0, kv_scale=None, force=None, out=None, lse=None):
     """t: dict with q, k_cache, v_cache, cu_seqlens_q, seqused_k, block_table[, alibi_slopes] on DEV."""
     q = t["q"]
     if out is None:
@@ -24,7 +24,7 @@ def run_unified(t, scale, *, window=0, softcap=0.0, kv_scale=None, force=None, o
         seqused_k=t["seqused_k"], max_seqlen_k=int(t["seqused_k"].max()), avg_seqlen_q=float(ql.float().mean()),
         avg_seqlen_k=float(t["seqused_k"].float().mean()), softmax_scale=scale, causal=True,
         window_size=(window - 1, 0) if window else (-1, -1), block_table=t["block_table"], softcap=softcap,
-        q_descale=None, k_descale=ks, v_descale=ks, alibi_slopes=t.get("alibi_slopes"), force_selection=force,
+        q_descale=None, k_descale=ks, v_descale=ks, alibi_slopes=t.get("alibi_slopes"), force_selection=force, softmax_lse=lse,
     )
     torch.cuda.synchronize()
     return out, _lib.last_kernel()

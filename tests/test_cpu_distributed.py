@@ -69,3 +69,50 @@ def test_batch_and_head_sharding_world2_gloo():
         assert ok_heads, f"rank {rank}: concatenated head-sharded output differs"
         owned += seq_ids
     assert sorted(owned) == list(range(7))
+
+
+def _cp_worker(rank, world, port, q_out):
+    """Context parallelism: each rank attends its page-aligned key range of every (decode) sequence; the exchange step
+    (all_gather of partial outputs + log-sum-exps over gloo, then the merge) must give the full result on every rank."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "vllm-triton-backend_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mi355_attn import parallel
+        from oracle import paged_attention_oracle as orc
+
+        page, kv_lens = 16, [1000, 40, 17, 1]
+        inp = orc.make_paged_inputs(5, [1] * len(kv_lens), kv_lens, 8, 2, 64, page, torch.float32)
+        full, full_lse = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"],
+                                                  inp["block_table"], inp["scale"], return_lse=True)
+        ranges = [parallel.split_key_range(n, page, world)[rank] for n in kv_lens]
+        width = max(max((k1 - k0 + page - 1) // page for k0, k1 in ranges), 1)
+        bt = torch.zeros((len(kv_lens), width), dtype=torch.int32)
+        for i, (k0, k1) in enumerate(ranges):
+            n_pages = (k1 - k0 + page - 1) // page
+            bt[i, :n_pages] = inp["block_table"][i, k0 // page: k0 // page + n_pages]
+        lens = torch.tensor([k1 - k0 for k0, k1 in ranges], dtype=torch.int32)
+        # the oracle stands in for the kernel: the split, the exchange and the merge are what is under test
+        part, part_lse = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], lens, bt, inp["scale"],
+                                                  return_lse=True)
+        merged, merged_lse = parallel.all_gather_and_merge(part, part_lse.to(torch.float32))
+        q_out.put((rank, float((merged.double() - full).abs().max()), float((merged_lse.double() - full_lse).abs().max()), lens.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_context_parallel_exchange_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cp_worker, args=(r, 2, port, q_out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q_out.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err_out, err_lse, lens in sorted(res):
+        assert err_out < 1e-5 and err_lse < 1e-5, (rank, err_out, err_lse)
+    assert sorted(res)[0][3] == [512, 32, 16, 1] and sorted(res)[1][3] == [488, 8, 1, 0]   # rank 1 holds no key of the last sequence

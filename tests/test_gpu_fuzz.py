@@ -55,9 +55,15 @@ def test_fast_kernels_agree_with_the_generic_kernel(case_id):
         t["alibi_slopes"] = torch.tensor([2.0 ** (-(i % 8 + 1)) for i in range(c["hq"])], dtype=torch.float32, device=gpu_util.DEV)
     scale = 1.0 / math.sqrt(c["d"])
     kv_scale = 0.5 if c["kv_dtype"] is not None else None
-    ref, ref_kernel = gpu_util.run_unified(t, scale, window=c["window"], softcap=c["softcap"], kv_scale=kv_scale, force=9)
+    n_tok = t["q"].shape[0]
+    ref_lse = torch.full((n_tok, c["hq"]), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    lse = torch.full_like(ref_lse, float("nan"))
+    ref, ref_kernel = gpu_util.run_unified(t, scale, window=c["window"], softcap=c["softcap"], kv_scale=kv_scale, force=9, lse=ref_lse)
     assert ref_kernel == "generic"
-    out, kernel = gpu_util.run_unified(t, scale, window=c["window"], softcap=c["softcap"], kv_scale=kv_scale)
+    out, kernel = gpu_util.run_unified(t, scale, window=c["window"], softcap=c["softcap"], kv_scale=kv_scale, lse=lse)
     assert not torch.isnan(out).any(), (kernel, c)
     atol, rtol = golden_io.tolerance(c["dtype"], c["kv_dtype"])
     torch.testing.assert_close(out.float(), ref.float(), atol=atol, rtol=rtol, msg=lambda m: f"[{kernel}] {c}\n{m}")
+    # the second output: log-sum-exp per row (finite everywhere here: every query sees at least its own key)
+    assert not torch.isnan(lse).any() and not torch.isnan(ref_lse).any(), (kernel, c)
+    torch.testing.assert_close(lse, ref_lse, atol=5e-2, rtol=0, msg=lambda m: f"[{kernel}] lse {c}\n{m}")

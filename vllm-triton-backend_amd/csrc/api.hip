@@ -47,6 +47,7 @@ static int validate(const mi355_attn_params* p) {
     return MI355_ERR_BAD_ARG;
   }
   if (p->sliding_window < 0) { set_error("sliding_window must be >= 0"); return MI355_ERR_BAD_ARG; }
+  if (p->lse && p->lse_stride_token < p->num_q_heads) { set_error("lse_stride_token %lld is smaller than num_q_heads %d", (long long)p->lse_stride_token, p->num_q_heads); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
   return MI355_OK;
 }

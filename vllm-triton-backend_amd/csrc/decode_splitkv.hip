@@ -50,6 +50,7 @@ constexpr int kTileKeys = 32;
 constexpr int kMaxSplits = 64;
 constexpr int kSlotPad = 32;   // floats appended to a D-float partial (m, l, padding to a 128-byte multiple)
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
 struct DecodeArgs {
   mi355_attn_params p;
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
       for (int b = 0; b < DBLK; ++b)
         if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) = u32x2_t{0, 0};
+      if (p.lse && grp == 0) p.lse[(int64_t)token * p.lse_stride_token + hq] = -INFINITY;
     }
     return;
   }
@@ -427,6 +429,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const float l_tot = sum_over_lane_groups(l_run);
   if (direct) {
     if (!g_ok) return;
+    if (p.lse && grp == 0)   // m_run is the row max of the scaled scores in the log2 domain
+      p.lse[(int64_t)token * p.lse_stride_token + hq] = l_tot > 0.0f ? (m_run + __builtin_amdgcn_logf(l_tot)) * kLn2 : -INFINITY;
     const float inv = l_tot > 0.0f ? v_scale / l_tot : 0.0f;
     const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
 #pragma unroll
@@ -516,6 +520,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     fold(m_in, l_in, v_in);
   }
   if (gm_ok && sub == 0) {
+    if (p.lse && grp == 0)
+      p.lse[(int64_t)token * p.lse_stride_token + head * G + gm] = l_acc > 0.0f ? (m_acc + __builtin_amdgcn_logf(l_acc)) * kLn2 : -INFINITY;
     const float inv = l_acc > 0.0f ? v_scale / l_acc : 0.0f;              // "0 if the overall sum is 0" (:828)
     const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)(head * G + gm) * p.out_stride_head;
 #pragma unroll
@@ -592,6 +598,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
     acc += *(const f32x4_t*)&red[rr][4 * col] * w;
   }
   const float inv = l_all > 0.0f ? v_scale / l_all : 0.0f;  // "0 if the overall sum is 0" (:828)
+  if (p.lse && col == 0) p.lse[(int64_t)ri.token * p.lse_stride_token + hq] = l_all > 0.0f ? (m_all + __builtin_amdgcn_logf(l_all)) * kLn2 : -INFINITY;
   uint16_t* op = (uint16_t*)p.out + (int64_t)ri.token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
   if (4 * col < a.d_valid) *(u32x2_t*)(op + 4 * col) = u32x2_t{mma<T>::pack2(acc[0] * inv, acc[1] * inv), mma<T>::pack2(acc[2] * inv, acc[3] * inv)};
 }

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(64) void generic_attn_kernel(const GenericArgs a) {
     const int d = lane + 64 * i;
     if (d < D) elem<QT>::store(p.out, o_off + d, acc[i] * inv_l);
   }
+  if (p.lse && lane == 0) p.lse[(int64_t)token * p.lse_stride_token + head] = l > 0.0f ? m + logf(l) : -INFINITY;
 }
 
 template <typename QT>

@@ -418,6 +418,8 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
 
   // ---- epilogue: O = O^T / l, lane (qr, half) register r of block b <-> d = 32b + (r&3) + 8(r>>2) + 4half
   l_run += lane_xor32(l_run);
+  if (p.lse && row_ok && half == 0)    // m_run: row max of the scaled scores in the log2 domain
+    p.lse[(int64_t)(q_start + tok_local) * p.lse_stride_token + hq] = l_run > 0.0f ? (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f : -INFINITY;
   const float inv = (row_ok && l_run > 0.0f) ? v_scale / l_run : 0.0f;
   // O leaves through LDS as whole rows, 16 bytes per lane, nontemporal (see prefill_dma_kernel's epilogue); the
   // 8-byte pieces of the accumulator layout go out directly only when the output rows are not 16-byte aligned.
@@ -939,6 +941,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   }
 #endif
   l_run += lane_xor32(l_run);
+  if (p.lse && row_ok && half == 0)    // P = exp2(score - m_ref): the sum is relative to the reference max
+    p.lse[(int64_t)(q_start + tok_local) * p.lse_stride_token + hq] = l_run > 0.0f ? (m_ref + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f : -INFINITY;
   const float inv = (row_ok && l_run > 0.0f) ? 1.0f / l_run : 0.0f;
   // O leaves through LDS: a lane owns 8-byte pieces of one row (the accumulator layout), which as global stores
   // touch 32 rows per instruction. Each wave parks its 32 rows in its own corner of the (now idle) stages and
@@ -1114,7 +1118,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), w64 (64 rows/wave, one wave per SIMD); default = LDS-DMA, 32 rows/wave
   static const char* variant = getenv("MI355_PREFILL");
   const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', w64 = variant && variant[0] == 'w';
-  if (w64 && prefill_w64_applicable(p)) return launch_prefill_w64(p, stream);
+  if (w64 && prefill_w64_applicable(p) && !p.lse) return launch_prefill_w64(p, stream);   // the experimental kernel has no lse output
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped

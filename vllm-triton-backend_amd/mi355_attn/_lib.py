@@ -90,6 +90,8 @@ class AttnParams(C.Structure):
         ("kernel_select", C.c_int32),
         ("num_segments", C.c_int32),
         ("reserved1", C.c_int32),
+        ("lse", C.c_void_p),
+        ("lse_stride_token", C.c_int64),
     ]
 
 

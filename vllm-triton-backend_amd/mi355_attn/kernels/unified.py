@@ -34,7 +34,7 @@ def fill_attn_params(
     q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_size,
     block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection,
     k_new=None, v_new=None, skip_decodes=False, only_decodes=False, num_segments=0,
-    legacy_v0_layout=False,
+    legacy_v0_layout=False, lse=None,
 ):
     """Build the C struct. Returns (params, keepalive) — keepalive holds temporaries whose device
     memory the struct points to."""
@@ -110,6 +110,10 @@ def fill_attn_params(
     except KeyError:
         raise ValueError(f"force_selection must be None, 2, 3 or 9, got {force_selection}") from None
     p.num_segments = int(num_segments)
+    if lse is not None:
+        if lse.dtype != torch.float32 or lse.dim() != 2 or lse.shape[0] != q.shape[0] or lse.shape[1] != q.shape[1] or lse.stride(1) != 1:
+            raise ValueError("softmax_lse must be a float32 [num_tokens, num_heads] tensor with contiguous heads")
+        p.lse, p.lse_stride_token = lse.data_ptr(), lse.stride(0)
     return p, keep
 
 
@@ -144,6 +148,7 @@ def unified_attention(
     v_descale,
     alibi_slopes=None,
     force_selection=None,  # None, 2, 3 to select kernel (9: generic correctness kernel)
+    softmax_lse=None,      # extension: float32 [num_tokens, num_heads], receives log(sum(exp(scores))) per row
 ):
     """Causal paged attention over vLLM block tables; writes `out` in place and returns None, as
     the reference does. `avg_seqlen_q/k` only fed the reference's autotuner keys
@@ -156,7 +161,7 @@ def unified_attention(
         raise RuntimeError("mi355_attn.unified_attention needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
     p, keep = fill_attn_params(
         q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_size,
-        block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection,
+        block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection, lse=softmax_lse,
     )
     launch(p, q.device)
     del keep

@@ -130,3 +130,47 @@ def gather_outputs(local_out: torch.Tensor, local: LocalBatch, total_tokens: int
     for o, ix, n in zip(outs, idxs, counts):
         full[ix[:n]] = o[:n]
     return full
+
+
+# ---------------------------------------------------------------------------------------------
+# Context parallelism for one very long sequence (SURVEY.md §8e "cross-GPU split-KV", §8f-3): the
+# sequence's KV pages are striped over the ranks, every rank attends its own key range and the
+# partial results meet in ONE exchange step - the only place on this path where a collective
+# carries data. The merge is the arithmetic of `reduce_segments`
+# (LIB/kernels/triton_unified_attention.py:804-828) with the log-sum-exp in place of (max, sum).
+# ---------------------------------------------------------------------------------------------
+def merge_partial_attention(outs: torch.Tensor, lses: torch.Tensor) -> tuple:
+    """outs [R, T, H, D] (any float dtype), lses [R, T, H] float32: partial attention results of R disjoint key
+    ranges and the log-sum-exp of each range's scores (`softmax_lse` of `unified_attention`). Returns (out [T, H, D]
+    float32, lse [T, H]). A range that saw no key has lse = -inf and contributes nothing; a row no range saw gets 0."""
+    lses = lses.to(torch.float32)
+    lse = torch.logsumexp(lses, dim=0)                                   # [T, H]; -inf where every range is empty
+    w = torch.exp(lses - torch.where(torch.isinf(lse), torch.zeros_like(lse), lse)[None])
+    w = torch.where(torch.isinf(lses) & (lses < 0), torch.zeros_like(w), w)
+    out = (outs.to(torch.float32) * w[..., None]).sum(dim=0)
+    return out, lse
+
+
+def split_key_range(seq_len: int, page_size: int, world_size: int) -> List[tuple]:
+    """Page-aligned contiguous key ranges [(first_key, end_key)] of one sequence, one per rank (possibly empty)."""
+    pages = (seq_len + page_size - 1) // page_size
+    per = (pages + world_size - 1) // world_size
+    out = []
+    for r in range(world_size):
+        k0 = min(r * per * page_size, seq_len)
+        k1 = min((r + 1) * per * page_size, seq_len)
+        out.append((k0, k1))
+    return out
+
+
+def all_gather_and_merge(local_out: torch.Tensor, local_lse: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> tuple:
+    """The exchange step: all_gather of (out as float32, lse) over the group - RCCL over xGMI with backend "nccl",
+    "gloo" in the CPU tests - then the merge on every rank. Payload per rank: T*H*(D+1)*4 bytes (decode: a few MB)."""
+    world = dist.get_world_size(group)
+    o32 = local_out.to(torch.float32).contiguous()
+    l32 = local_lse.to(torch.float32).contiguous()
+    outs = [torch.empty_like(o32) for _ in range(world)]
+    lses = [torch.empty_like(l32) for _ in range(world)]
+    dist.all_gather(outs, o32, group=group)
+    dist.all_gather(lses, l32, group=group)
+    return merge_partial_attention(torch.stack(outs), torch.stack(lses))
