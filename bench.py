@@ -75,27 +75,29 @@ def build_call(w, device):
 
 
 def timed_steps(call, steps, warmup, device, distributed):
-    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize; HIP events around
-    every launch (on the stream the kernel is launched on) give the per-launch kernel time."""
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize. One HIP event pair brackets the K
+    launches on the stream they are launched on: the kernel's average launch duration is that span / K (it includes
+    the gaps between back-to-back launches, as a serving loop would see them; rocprofv3's per-kernel average under
+    profiles/ is the same number minus those gaps). No event is recorded between launches: an event record is a
+    barrier packet, and two of them per launch cost ~3 % of a 165 us kernel."""
     for _ in range(warmup):
         call()
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
+    e0.record()
+    for _ in range(steps):
         call()
-        e1.record()
+    e1.record()
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
-    per_launch = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in evs]
-    return wall, sum(per_launch) / len(per_launch)
+    return wall, e0.elapsed_time(e1) * 1e-3 / steps
 
 
 def cpu_baseline(w, out_gpu):
