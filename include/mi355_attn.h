@@ -212,7 +212,9 @@ MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
  *       max_seqlen_q == 1            -> split-KV decode ("decode_splitkv[_fp8]" / "decode_single[_fp8]")
  *       every sequence a prefill     -> Q-block prefill ("prefill_mfma[_fp8][_feat]")
  *       mixed batch                  -> both, prefill rows then decode rows ("<prefill kernel>+<decode kernel>", e.g. "prefill_mfma+decode_splitkv")
- *   everything else (f32, other head sizes, the legacy v0 layout, linear new-token K/V) -> "generic".
+ *     the legacy v0 layout (16-bit, k_x == 8, head size 64/128/256) with max_seqlen_q == 1 -> the same split-KV decode
+ *     kernel reading that layout directly ("decode_splitkv_v0" / "decode_single_v0")
+ *   everything else (f32, other head sizes, other v0 caches, linear new-token K/V) -> "generic".
  */
 MI355_API int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);

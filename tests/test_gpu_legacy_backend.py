@@ -30,7 +30,69 @@ def test_legacy_paged_attention_golden(name):
     torch.cuda.synchronize()
     atol, rtol = golden_io.tolerance(t["q"].dtype)
     torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol)
-    assert _lib.last_kernel() == "generic"
+    # 16-bit 5-D caches run on the MFMA decode kernel, the rest (fp32 goldens, 4-D key caches) on the generic one
+    fast = t["q"].dtype in (torch.bfloat16, torch.float16) and t["k_cache_v0"].dim() == 5 and t["k_cache_v0"].shape[4] == 8 and D in (64, 128, 256)
+    assert _lib.last_kernel() == "generic" or (fast and _lib.last_kernel().endswith("_v0")), _lib.last_kernel()
+
+
+def _flash_to_v0(k, v):
+    """flash [nb, page, Hk, D] -> legacy K [nb, Hk, D/8, page, 8], V [nb, Hk, D, page]"""
+    nb, page, hk, d = k.shape
+    k0 = k.view(nb, page, hk, d // 8, 8).permute(0, 2, 3, 1, 4).contiguous()
+    v0 = v.permute(0, 2, 3, 1).contiguous()
+    return k0, v0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk,d,page", [(32, 8, 128, 16), (8, 8, 64, 16), (16, 1, 128, 32), (40, 8, 128, 16), (8, 2, 256, 16), (6, 2, 64, 32)])
+def test_legacy_paged_decode_on_the_mfma_kernel(dtype, hq, hk, d, page):
+    """paged_attention_2d/3d over a 16-bit v0-layout cache: the split-KV MFMA decode kernel reads that layout directly."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels.legacy import paged_attention_2d, paged_attention_3d
+
+    kv_lens = [1, 15, 16, 17, 33, 257, 1023, 700]
+    inp = orc.make_paged_inputs(90 + hq + d, [1] * len(kv_lens), kv_lens, hq, hk, d, page, dtype)
+    alibi = torch.tensor([2.0 ** (-(i % 8 + 1)) for i in range(hq)], dtype=torch.float32)
+    dev = gpu_util.DEV
+    k0, v0 = _flash_to_v0(inp["k_cache"], inp["v_cache"])
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    for fn, slopes in ((paged_attention_2d, None), (paged_attention_3d, alibi)):
+        ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                           inp["scale"], alibi_slopes=slopes, mode="3d")
+        out = torch.full_like(inp["q"].to(dev), float("nan"))
+        fn(out, inp["q"].to(dev), k0.to(dev), v0.to(dev), inp["scale"], one, one, "auto", inp["block_table"].to(dev), inp["seqused_k"].to(dev),
+           None if slopes is None else slopes.to(dev), page, len(kv_lens), hq, hq // hk, d)
+        torch.cuda.synchronize()
+        assert _lib.last_kernel() in ("decode_splitkv_v0", "decode_single_v0"), _lib.last_kernel()
+        assert not torch.isnan(out).any()
+        atol, rtol = golden_io.tolerance(dtype)
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+def test_legacy_paged_decode_ignores_stale_nan_slots():
+    import gpu_util
+    from mi355_attn.kernels.legacy import paged_attention_2d
+
+    kv_lens, page = [33, 100, 5, 1000], 16
+    inp = orc.make_paged_inputs(95, [1] * len(kv_lens), kv_lens, 8, 2, 128, page, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="3d")
+    used = torch.zeros(inp["k_cache"].shape[:2], dtype=torch.bool)
+    for i, n in enumerate(kv_lens):
+        for j in range(n):
+            used[inp["block_table"][i, j // page], j % page] = True
+    inp["k_cache"][~used] = float("nan")
+    inp["v_cache"][~used] = float("nan")
+    dev = gpu_util.DEV
+    k0, v0 = _flash_to_v0(inp["k_cache"], inp["v_cache"])
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    out = torch.full_like(inp["q"].to(dev), float("nan"))
+    paged_attention_2d(out, inp["q"].to(dev), k0.to(dev), v0.to(dev), inp["scale"], one, one, "auto", inp["block_table"].to(dev),
+                       inp["seqused_k"].to(dev), None, page, len(kv_lens), 8, 4, 128)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
 
 
 @pytest.mark.parametrize("name", golden_io.names("legacy_ctxfwd"))

@@ -69,6 +69,7 @@ struct DecodeArgs {
   int d_valid;     // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
   int unit_is_seq; // 1: every sequence has exactly one query token (max_seqlen_q == 1), so unit == token == sequence
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated on the host
+  uint32_t k_dx_stride, v_d_stride;   // legacy v0 layout only: K [page][Hk][D/8][slot][8], V [page][Hk][D][slot]
 };
 
 template <typename T> struct mma;
@@ -139,8 +140,13 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
 
 // PAD: the real head size is smaller than D (see padded_head_size); a separate instantiation so that the
 // built head sizes keep their branch-free load stream.
-template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD>
+// V0: the legacy vLLM v0 cache layout (K [page][Hk][D/8][slot][8], V [page][Hk][D][slot], 16-bit). A (page, head)
+// tile is one contiguous block there and its 16-byte pieces are exactly what the kernel wants: a K piece is 8
+// consecutive d of one key (parked like a flash-layout piece, only the global offset differs), a V piece is 8
+// consecutive keys of one d - V is parked d-major and the P.V operand is read with two plain 8-byte reads, no transpose.
+template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD, bool V0>
 __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const DecodeArgs a) {
+  static_assert(!V0 || (__is_same(T, KVT) && !PAD), "the v0 layout path serves same-type 16-bit caches of a built head size");
   constexpr bool FP8 = !__is_same(T, KVT);
   // tiles in flight HBM -> VGPR per wave: an fp8 tile is half the bytes of a 16-bit one, so two of
   // them are kept in flight to put the same number of bytes on the wire per CU
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   constexpr int RS = D * 2 + 32;                    // LDS row stride in bytes (16-bit rows)
   constexpr int KSTEPS = D / 32;                    // MFMA k-steps of Q.K^T
   constexpr int DBLK = D / 16;                      // 16-wide output blocks of P.V
-  constexpr int LDS_PER_WAVE = 48 * RS;             // K: one 16-key group, V: two
+  constexpr int RSV0 = 80;                          // v0: bytes per d-row of the parked V tile (32 keys + pad)
+  constexpr int LDS_PER_WAVE = 16 * RS + (V0 ? D * RSV0 : 32 * RS);   // K: one 16-key group; V: two groups (or D rows of 32 keys)
   static_assert(NLD >= 1, "head size too small for the row-shaped load");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -253,12 +260,21 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int idx = lane + 64 * i;
-    ld_row[i] = idx / PPR;
-    ld_piece[i] = idx % PPR;
-    ld_pad[i] = PAD && ld_piece[i] * EPP >= a.d_valid;
-    const int src_piece = ld_pad[i] ? 0 : ld_piece[i];
-    k_toff[i] = (uint32_t)(ld_row[i] * (int)a.k_slot_stride + src_piece * EPP);
-    v_toff[i] = (uint32_t)(ld_row[i] * (int)a.v_slot_stride + src_piece * EPP);
+    if constexpr (V0) {
+      // K: piece (d-chunk c, key row) at c*dx_stride + row*8; V: piece (d, 8 slots hf) at d*d_stride + 8*hf
+      ld_row[i] = idx % 16;
+      ld_piece[i] = idx / 16;
+      ld_pad[i] = false;
+      k_toff[i] = (uint32_t)(ld_piece[i] * (int)a.k_dx_stride + ld_row[i] * (int)a.k_slot_stride);
+      v_toff[i] = (uint32_t)((idx / 2) * (int)a.v_d_stride + (idx % 2) * 8);
+    } else {
+      ld_row[i] = idx / PPR;
+      ld_piece[i] = idx % PPR;
+      ld_pad[i] = PAD && ld_piece[i] * EPP >= a.d_valid;
+      const int src_piece = ld_pad[i] ? 0 : ld_piece[i];
+      k_toff[i] = (uint32_t)(ld_row[i] * (int)a.k_slot_stride + src_piece * EPP);
+      v_toff[i] = (uint32_t)(ld_row[i] * (int)a.v_slot_stride + src_piece * EPP);
+    }
   }
 
   // block-table entries of the two groups of a tile, via the scalar cache (see scalar_load4)
@@ -329,10 +345,24 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         u32x4_t v = VR[h][i];
-        // rows past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
-        if (tail && (tile * kTileKeys + h * 16 + ld_row[i] >= n_keys)) v = u32x4_t{0, 0, 0, 0};
-        if (PAD && ld_pad[i]) v = u32x4_t{0, 0, 0, 0};
-        park(v_lds, h * 16 + ld_row[i], ld_piece[i], v);
+        if constexpr (V0) {
+          // the piece is 8 consecutive keys of row d: zero the keys past the sequence (stale slots), park d-major
+          const int idx = lane + 64 * i, d_row = idx / 2, hf = idx % 2;
+          if (tail) {
+            const int valid = n_keys - (tile * kTileKeys + h * 16 + hf * 8);     // keys of this piece inside the sequence
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const uint32_t keep = valid >= 2 * w + 2 ? 0xffffffffu : valid == 2 * w + 1 ? 0x0000ffffu : 0u;
+              v[w] &= keep;
+            }
+          }
+          *(u32x4_t*)(v_lds + d_row * RSV0 + (h * 16 + hf * 8) * 2) = v;
+        } else {
+          // rows past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
+          if (tail && (tile * kTileKeys + h * 16 + ld_row[i] >= n_keys)) v = u32x4_t{0, 0, 0, 0};
+          if (PAD && ld_pad[i]) v = u32x4_t{0, 0, 0, 0};
+          park(v_lds, h * 16 + ld_row[i], ld_piece[i], v);
+        }
       }
     if (tile + PF < t1) {
       issue_loads(tile + PF, KR, VR);
@@ -406,10 +436,18 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     for (int b = 0; b < DBLK; ++b) {
       // transposed read: lane 4q+pp of group grp addresses row 4*grp+q, columns 16b+4pp..+3 and
       // receives V[4*grp + e][16b + (lane&15)] in element e
-      const int q4 = g >> 2, pp = g & 3;
-      const char* va = v_lds + (grp * 4 + q4) * RS + (16 * b + 4 * pp) * 2;
-      const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va));
-      const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + 16 * RS));
+      s16x4_t v0, v1;
+      if constexpr (V0) {
+        // d-major tile: lane (g, grp) is row d = 16b + g and takes keys 4grp .. 4grp+3 of each 16-key group as they lie
+        const char* va = v_lds + (16 * b + g) * RSV0 + (4 * grp) * 2;
+        v0 = *(const s16x4_t*)va;
+        v1 = *(const s16x4_t*)(va + 32);
+      } else {
+        const int q4 = g >> 2, pp = g & 3;
+        const char* va = v_lds + (grp * 4 + q4) * RS + (16 * b + 4 * pp) * 2;
+        v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va));
+        v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + 16 * RS));
+      }
       const s16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (rescale) {
 #pragma unroll
@@ -609,20 +647,32 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
 static bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 static bool is_fp8_dtype(int d) { return d == MI355_FP8_E4M3 || d == MI355_FP8_E5M2; }
 
+// flash layout [page][slot][Hk][D] (what vLLM V1 uses)
+static bool layout_is_flash(const mi355_attn_params& p) { return p.k_x == p.head_size && p.k_stride_d == 1 && p.v_stride_d == 1; }
+// legacy v0 layout K [page][Hk][D/8][slot][8], V [page][Hk][D][slot], 16-bit elements, as the reference's legacy ops
+// lay it out (LIB/kernels/legacy/triton_paged_decode_attention_2d.py:103-104): slots of a d-chunk / of a d contiguous
+static bool layout_is_v0(const mi355_attn_params& p) {
+  return p.k_x == 8 && p.k_stride_d == 1 && p.k_stride_slot == 8 && p.k_stride_dx == (int64_t)p.page_size * 8 &&
+         p.v_stride_slot == 1 && p.v_stride_d == p.page_size && p.kv_dtype == p.q_dtype &&
+         (p.head_size == 64 || p.head_size == 128 || p.head_size == 256);
+}
+
 bool decode_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
   if (p.kv_dtype != p.q_dtype && !is_fp8_dtype(p.kv_dtype)) return false;
   if (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) == 0) return false;
   if (p.k_new || p.v_new) return false;
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
-  if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
+  const bool v0 = !layout_is_flash(p) && layout_is_v0(p);
+  if (!layout_is_flash(p) && !v0) return false;
   const int G = p.num_q_heads / p.num_kv_heads;
   if (G > 16) return false;
   if (!aligned16(p.q) || !aligned16(p.k_cache) || !aligned16(p.v_cache)) return false;
   if (((uintptr_t)p.out & 7) != 0) return false;
   const int64_t kv_align = is_fp8_dtype(p.kv_dtype) ? 16 : 8;   // elements per 16 bytes
-  const int64_t kv_strides[] = {p.k_stride_page, p.k_stride_slot, p.k_stride_head, p.v_stride_page, p.v_stride_slot, p.v_stride_head};
+  const int64_t kv_strides[] = {p.k_stride_page, v0 ? kv_align : p.k_stride_slot, p.k_stride_head, p.v_stride_page, v0 ? kv_align : p.v_stride_slot, p.v_stride_head};
   for (int64_t s : kv_strides) if (s % kv_align != 0 || s < 0) return false;
+  if (v0 && (p.k_stride_dx >= (1 << 24) || p.v_stride_d >= (1 << 24))) return false;
   if (p.q_stride_token % 8 != 0 || p.q_stride_head % 8 != 0) return false;
   if (p.out_stride_token % 4 != 0 || p.out_stride_head % 4 != 0) return false;
   if (p.k_stride_slot >= (1 << 24) || p.v_stride_slot >= (1 << 24)) return false;      // 32-bit in-page offsets
@@ -670,7 +720,7 @@ size_t decode_workspace_bytes(const mi355_attn_params& p) {
   return counters_bytes(p) + slots * (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) + kSlotPad) * sizeof(float);
 }
 
-template <typename T, typename KVT, int D, bool FEAT, bool PAD>
+template <typename T, typename KVT, int D, bool FEAT, bool PAD, bool V0>
 static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   constexpr int WAVES = 4;
   constexpr bool FP8 = !__is_same(T, KVT);
@@ -686,6 +736,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.unit_is_seq = (!p.only_decodes && p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) ? 1 : 0;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
+  a.k_dx_stride = (uint32_t)p.k_stride_dx; a.v_d_stride = (uint32_t)p.v_stride_d;
   a.ws_slots = nullptr;
   a.ws_cnt = nullptr;
   a.ws_slot_bytes_total = 0;
@@ -717,8 +768,8 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   if (units == 0) return MI355_OK;
   const long items = units * sp.num_splits * p.num_kv_heads;
   const int grid = (int)((items + WAVES - 1) / WAVES);
-  const size_t lds = (size_t)WAVES * 48 * (D * 2 + 32);
-  hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+  const size_t lds = (size_t)WAVES * (16 * (D * 2 + 32) + (V0 ? D * 80 : 32 * (D * 2 + 32)));
+  hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD, V0>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
   if (rc != MI355_OK) return rc;
   if (sp.num_splits > 1 && !a.fused_merge) {
@@ -726,16 +777,21 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     rc = check_hip(hipGetLastError(), "reduce_splits_kernel launch");
   }
   if (rc == MI355_OK)
-    set_kernel_name(sp.num_splits > 1 ? (FP8 ? "decode_splitkv_fp8" : "decode_splitkv") : (FP8 ? "decode_single_fp8" : "decode_single"));
+    set_kernel_name(V0 ? (sp.num_splits > 1 ? "decode_splitkv_v0" : "decode_single_v0")
+                       : sp.num_splits > 1 ? (FP8 ? "decode_splitkv_fp8" : "decode_splitkv") : (FP8 ? "decode_single_fp8" : "decode_single"));
   return rc;
 }
 
 template <typename T, typename KVT, int D>
 static int launch_decode_f(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+  if constexpr (__is_same(T, KVT)) {
+    if (!layout_is_flash(p))   // decode_supported admitted it: the legacy v0 layout
+      return feat ? launch_decode_t<T, KVT, D, true, false, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, true>(p, ws, ws_bytes, stream);
+  }
   if (p.head_size != D)
-    return feat ? launch_decode_t<T, KVT, D, true, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, true>(p, ws, ws_bytes, stream);
-  return feat ? launch_decode_t<T, KVT, D, true, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false>(p, ws, ws_bytes, stream);
+    return feat ? launch_decode_t<T, KVT, D, true, true, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, true, false>(p, ws, ws_bytes, stream);
+  return feat ? launch_decode_t<T, KVT, D, true, false, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, false>(p, ws, ws_bytes, stream);
 }
 
 template <typename T, typename KVT>

@@ -5,8 +5,10 @@ same names and keyword signatures, old vLLM v0 cache layout
 All four ops are served by libmi355_attn.so through `mi355_unified_attention`: the C ABI's stride
 description covers the v0 layout and its optional linear "new token" K/V source covers
 context_attention_fwd, so one launch replaces the reference's kernels (and the two launches of
-chunked_prefill_paged_decode). These layouts run on the shape-agnostic HIP kernel; the MFMA
-kernels serve the flash layout that vLLM V1 uses.
+chunked_prefill_paged_decode). `paged_attention_2d/3d` over a 16-bit 5-D v0 cache (x = 8) with head size
+64/128/256 run on the split-KV MFMA decode kernel ("decode_*_v0": a (page, head) tile of that layout is one
+contiguous block of MFMA-shaped 16-byte pieces); everything else here (fp8 or 4-D key caches, the ops with a
+linear new-token source) runs on the shape-agnostic HIP kernel.
 """
 
 from __future__ import annotations
@@ -79,9 +81,11 @@ def _paged_decode(output, query, key_cache, value_cache, scale, k_scale, v_scale
     assert num_seqs <= 4096  # the reference's static launch grid (triton_paged_decode_attention_2d.py:355)
     assert value_cache.shape[3] == block_size and query.shape[1] == num_query_heads and query.shape[2] == head_size
     cu = _decode_cu_seqlens(num_seqs, query.device)
+    # the legacy signature carries no maximum sequence length: the block table's width bounds it (host-known)
+    max_seq_len = block_tables.shape[1] * block_size
     p, keep = fill_attn_params(
-        query[:num_seqs], key_cache, value_cache, output[:num_seqs], cu, 1, seq_lens[:num_seqs], 0, scale, (-1, -1),
-        block_tables, 0.0, k_scale, v_scale, alibi_slopes, 9, legacy_v0_layout=True,
+        query[:num_seqs], key_cache, value_cache, output[:num_seqs], cu, 1, seq_lens[:num_seqs], max_seq_len, scale, (-1, -1),
+        block_tables, 0.0, k_scale, v_scale, alibi_slopes, None, legacy_v0_layout=True,
     )
     launch(p, query.device)
     del keep
