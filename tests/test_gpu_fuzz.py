@@ -14,7 +14,7 @@ from oracle import paged_attention_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-CASES = 160
+CASES = 200
 
 
 def _random_case(rng):
@@ -26,13 +26,13 @@ def _random_case(rng):
             ql = 1
         else:
             ql = rng.choice([2, 5, 16, 31, 64, 65, 129, 200, 300])
-        ctx = rng.choice([0, 0, 1, 15, 16, 17, 63, 64, 255, 700, 1500])
+        ctx = rng.choice([0, 0, 1, 15, 16, 17, 63, 64, 255, 700, 1500, 4097, 6000])
         q_lens.append(ql)
         kv_lens.append(ql + ctx)
     hk = rng.choice([1, 2, 4, 8])
     g = rng.choice([1, 2, 3, 4, 5, 8, 16])
-    d = rng.choice([64, 64, 96, 128, 128, 128, 256, 32, 160])
-    page = rng.choice([16, 16, 32, 64])
+    d = rng.choice([64, 64, 96, 128, 128, 128, 256, 32, 160, 224, 80])
+    page = rng.choice([16, 16, 32, 64, 128])
     dtype = rng.choice([torch.bfloat16, torch.float16])
     kv_dtype = rng.choice([None, None, torch.float8_e4m3fn, torch.float8_e5m2]) if d % 16 == 0 else None
     window = rng.choice([0, 0, 0, 7, 64, 300])
