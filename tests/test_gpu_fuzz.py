@@ -67,3 +67,34 @@ def test_fast_kernels_agree_with_the_generic_kernel(case_id):
     # the second output: log-sum-exp per row (finite everywhere here: every query sees at least its own key)
     assert not torch.isnan(lse).any() and not torch.isnan(ref_lse).any(), (kernel, c)
     torch.testing.assert_close(lse, ref_lse, atol=5e-2, rtol=0, msg=lambda m: f"[{kernel}] lse {c}\n{m}")
+
+
+@pytest.mark.parametrize("q_lens,kv_lens", [([5, 0, 1, 0, 64], [70, 33, 45, 0, 64]), ([0, 1, 1], [16, 300, 1]), ([0, 200], [0, 777])])
+def test_sequences_without_query_tokens_are_skipped(q_lens, kv_lens):
+    """A sequence may contribute no query token to a step (equal neighbours in cu_seqlens_q): nothing is computed for it and
+    the other sequences' rows are unaffected - fast kernels vs the generic kernel."""
+    import gpu_util
+
+    dtype = torch.bfloat16
+    keep = [i for i, n in enumerate(q_lens) if n > 0]
+    inp = orc.make_paged_inputs(3000, [q_lens[i] for i in keep], [kv_lens[i] for i in keep], 8, 2, 128, 16, dtype)
+    # re-insert the empty sequences: same q / cache, longer metadata
+    cu, sl, bt_rows, j = [0], [], [], 0
+    for i, n in enumerate(q_lens):
+        cu.append(cu[-1] + n)
+        sl.append(kv_lens[i])
+        if n > 0:
+            bt_rows.append(inp["block_table"][j])
+            j += 1
+        else:
+            bt_rows.append(torch.zeros_like(inp["block_table"][0]))
+    t = gpu_util.to_dev(inp)
+    t["cu_seqlens_q"] = torch.tensor(cu, dtype=torch.int32, device=gpu_util.DEV)
+    t["seqused_k"] = torch.tensor(sl, dtype=torch.int32, device=gpu_util.DEV)
+    t["block_table"] = torch.stack(bt_rows).to(gpu_util.DEV)
+    scale = 1.0 / math.sqrt(128)
+    ref, _ = gpu_util.run_unified(t, scale, force=9)
+    out, kernel = gpu_util.run_unified(t, scale)
+    assert kernel != "generic"
+    assert not torch.isnan(out).any() and not torch.isnan(ref).any()
+    torch.testing.assert_close(out.float(), ref.float(), atol=2e-2, rtol=2e-2, msg=lambda m: f"[{kernel}] {m}")
