@@ -183,23 +183,21 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   const kv_elem_t* vbase = (const kv_elem_t*)p.v_cache + (int64_t)head * p.v_stride_head;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
   const int page_mask = p.page_size - 1;
-  int st_key[NLD], st_off[NLD];             // key inside the tile / element offset inside the row
-  uint32_t k_toff[NLD], v_toff[NLD];        // this thread's element offset from the group's first row
-  int st_grp[NLD];                          // 16-key group inside the tile (wave-uniform)
-  bool st_pad[NLD];
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = tid + 256 * i;
-    st_key[i] = idx / PPR;
-    st_off[i] = (idx % PPR) * EPP;
-    st_grp[i] = __builtin_amdgcn_readfirstlane(st_key[i] >> 4);
-    // a piece in the padding columns of a non-built head size loads the row's piece 0 instead (same instruction
-    // stream, always a valid address) and is zeroed on its way into LDS
-    st_pad[i] = st_off[i] >= a.d_valid;
-    const int src_off = st_pad[i] ? 0 : st_off[i];
-    k_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.k_stride_slot + src_off);
-    v_toff[i] = (uint32_t)((st_key[i] & 15) * (int)p.v_stride_slot + src_off);
-  }
+  // Thread t stages pieces t + 256 i of the 64 x PPR tile. 256 is a multiple of PPR, so piece i of a thread is the
+  // same column chunk of key row st_key0 + i*KS: everything below derives from two per-thread values instead of
+  // NLD-long arrays (32 registers at D = 256, where the kernel otherwise spills).
+  static_assert(256 % PPR == 0, "staging pattern");
+  constexpr int KS = 256 / PPR;                                   // key rows between a thread's consecutive pieces
+  const int st_key0 = tid / PPR;
+  const int st_off0 = (tid % PPR) * EPP;                         // element offset inside the row
+  // a piece in the padding columns of a non-built head size loads the row's piece 0 instead (same instruction
+  // stream, always a valid address) and is zeroed on its way into LDS
+  const bool st_pad0 = st_off0 >= a.d_valid;
+  const int st_src_off = st_pad0 ? 0 : st_off0;
+  auto st_key_of = [&](int i) { return st_key0 + i * KS; };       // key inside the tile
+  auto st_grp_of = [&](int i) { return __builtin_amdgcn_readfirstlane(st_key_of(i) >> 4); };   // its 16-key group (wave-uniform)
+  auto k_toff_of = [&](int i) { return (uint32_t)((st_key_of(i) & 15) * (int)p.k_stride_slot + st_src_off); };
+  auto v_toff_of = [&](int i) { return (uint32_t)((st_key_of(i) & 15) * (int)p.v_stride_slot + st_src_off); };
   int pg_next[4];                           // physical pages of the NEXT tile's four 16-key groups (SGPRs)
   auto lookup_pages = [&](int tile) {
     int idx[4];
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   auto issue_loads = [&](int tile) {        // uses pg_next, which must hold this tile's pages
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int gi = min(tile * (kTileN / 16) + st_grp[i], last_group);
+      const int gi = min(tile * (kTileN / 16) + st_grp_of(i), last_group);
       const int slot0 = (gi << 4) & page_mask;
       int page;
       if constexpr (PPR >= 16) {            // a load round covers one group (D=128) or half of one (D=256)
@@ -223,33 +221,51 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
       }
       const kv_elem_t* kp = kbase + ((uint64_t)(uint32_t)page * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride);
       const kv_elem_t* vp = vbase + ((uint64_t)(uint32_t)page * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
-      kreg[i] = *(const pu32x4_t*)(kp + k_toff[i]);
-      vreg[i] = *(const pu32x4_t*)(vp + v_toff[i]);
+      kreg[i] = *(const pu32x4_t*)(kp + k_toff_of(i));
+      vreg[i] = *(const pu32x4_t*)(vp + v_toff_of(i));
     }
   };
-  auto write_lds = [&](int tile, char* stage) {
+  // staging registers -> LDS, K and V separately: at D = 256 the K half is written before the P.V phase (its loads
+  // were issued a phase earlier) so that its 32 registers are free while P.V runs - with both halves held to the end
+  // of the tile the kernel spills
+  auto write_lds_k = [&](char* stage) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      pu32x4_t kk = kreg[i];
+      if (a.d_valid != D) {                   // wave-uniform: the built head sizes skip this
+        if (st_pad0) kk = pu32x4_t{0, 0, 0, 0};
+      }
+      if constexpr (FP8) {
+        pu32x4_t lo, hi;
+        widen_fp8_piece<T, KVT>(kk, lo, hi);
+        *(pu32x4_t*)(stage + st_key_of(i) * RSK + st_off0 * 2) = lo;
+        *(pu32x4_t*)(stage + st_key_of(i) * RSK + st_off0 * 2 + 16) = hi;
+      } else {
+        *(pu32x4_t*)(stage + st_key_of(i) * RSK + st_off0 * 2) = kk;
+      }
+    }
+  };
+  auto write_lds_v = [&](int tile, char* stage) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       pu32x4_t v = vreg[i];
       // slots past the sequence hold stale cache contents: keep NaN/Inf out of 0 * V
-      if (tile * kTileN + st_key[i] >= seq_len) v = pu32x4_t{0, 0, 0, 0};
-      if (a.d_valid != D) {                   // wave-uniform: the built head sizes skip this
-        if (st_pad[i]) { v = pu32x4_t{0, 0, 0, 0}; kreg[i] = pu32x4_t{0, 0, 0, 0}; }
+      if (tile * kTileN + st_key_of(i) >= seq_len) v = pu32x4_t{0, 0, 0, 0};
+      if (a.d_valid != D) {
+        if (st_pad0) v = pu32x4_t{0, 0, 0, 0};
       }
       if constexpr (FP8) {
         pu32x4_t lo, hi;
-        widen_fp8_piece<T, KVT>(kreg[i], lo, hi);
-        *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2) = lo;
-        *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2 + 16) = hi;
         widen_fp8_piece<T, KVT>(v, lo, hi);
-        *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2) = lo;
-        *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2 + 16) = hi;
+        *(pu32x4_t*)(stage + KBUF + st_key_of(i) * RSV + st_off0 * 2) = lo;
+        *(pu32x4_t*)(stage + KBUF + st_key_of(i) * RSV + st_off0 * 2 + 16) = hi;
       } else {
-        *(pu32x4_t*)(stage + st_key[i] * RSK + st_off[i] * 2) = kreg[i];
-        *(pu32x4_t*)(stage + KBUF + st_key[i] * RSV + st_off[i] * 2) = v;
+        *(pu32x4_t*)(stage + KBUF + st_key_of(i) * RSV + st_off0 * 2) = v;
       }
     }
   };
+  auto write_lds = [&](int tile, char* stage) { write_lds_k(stage); write_lds_v(tile, stage); };
+  constexpr bool EARLY_K = D >= 256;
 
   float m_run = -INFINITY, l_run = 0.0f;
   pf32x16_t o_acc[DBLK];
@@ -287,6 +303,7 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
     const char* v_rd = stage + v_rd_off;
 
     const int key_base = tile * kTileN;
+    bool k_written = false;                    // wave-uniform
     if (wave_has_rows && key_base < wave_keys) {
       // ---- S^T = K . Q^T ---------------------------------------------------------------------------
       // All K fragments of a 32-key block are requested before its first MFMA, and the next block's
@@ -297,21 +314,22 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.0f;
-      pu32x4_t kf[KSTEPS];
+      // a ring of KW fragments: the whole 32-key block for D <= 128; for D = 256 half of it, or the 64 fragment
+      // registers push the kernel over the register file (it spilled ~100 VGPRs)
+      constexpr int KW = D >= 256 ? 4 : (KSTEPS < 8 ? KSTEPS : 8);
+      pu32x4_t kf[KW];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const pu32x4_t*)(k_rd + ks * 32);
-      __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);   // DS reads
+      for (int m = 0; m < KW; ++m) kf[m] = *(const pu32x4_t*)(k_rd + (m / KSTEPS) * 32 * RSK + (m % KSTEPS) * 32);
+      __builtin_amdgcn_sched_group_barrier(0x100, KW, 0);       // DS reads
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        s_acc[0] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], s_acc[0]);
-        kf[ks] = *(const pu32x4_t*)(k_rd + 32 * RSK + ks * 32);
+      for (int m = 0; m < 2 * KSTEPS; ++m) {
+        const int kb = m / KSTEPS, ks = m % KSTEPS;
+        s_acc[kb] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[m % KW]), qf[ks], s_acc[kb]);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-      }
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        s_acc[1] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], s_acc[1]);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m + KW < 2 * KSTEPS) {
+          kf[m % KW] = *(const pu32x4_t*)(k_rd + ((m + KW) / KSTEPS) * 32 * RSK + ((m + KW) % KSTEPS) * 32);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read
+        }
       }
       // ---- softmax (log2 domain) -------------------------------------------------------------------
       // register r of block kb <-> key key_base + 32kb + (r&3) + 8(r>>2) + 4half
@@ -378,6 +396,10 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;
+      if (EARLY_K && has_next) {               // the other stage is idle during this whole tile
+        write_lds_k(smem + (((tile - tile_lo) & 1) ^ 1) * BUF);
+        k_written = true;
+      }
       // ---- O^T = alpha * O^T + V^T . P^T -----------------------------------------------------------
       const bool rescale = !__all(alpha == 1.0f);                 // exact: skipped only when no row's max moved
       if (rescale) {
@@ -386,33 +408,36 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
 #pragma unroll
           for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
       }
-      // transposed V reads run one 32-wide output block ahead of the MFMAs that consume them
-      ps16x4_t vt[2][8];
-      auto read_v_block = [&](int b, ps16x4_t (&dst)[8]) {
-#pragma unroll
-        for (int sk = 0; sk < 4; ++sk) {
-          const char* va = v_rd + sk * 16 * RSV + b * 64;
-          dst[2 * sk] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va));
-          dst[2 * sk + 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va + 8 * RSV));
-        }
+      // transposed V reads run VW k-steps (a 32-wide output block; half of one at D = 256, for registers) ahead of
+      // the MFMAs that consume them
+      constexpr int VW = D >= 256 ? 4 : 8;
+      ps16x4_t vt[VW][2];
+      auto read_v_step = [&](int m, ps16x4_t (&dst)[2]) {       // m = 4*b + sk
+        const char* va = v_rd + (m & 3) * 16 * RSV + (m >> 2) * 64;
+        dst[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va));
+        dst[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va + 8 * RSV));
       };
-      read_v_block(0, vt[0]);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-      for (int b = 0; b < DBLK; ++b) {
-        if (b + 1 < DBLK) read_v_block(b + 1, vt[(b + 1) & 1]);
+      for (int m = 0; m < VW; ++m) read_v_step(m, vt[m]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * VW, 0);
 #pragma unroll
-        for (int sk = 0; sk < 4; ++sk) {
-          const ps16x4_t v0 = vt[b & 1][2 * sk], v1 = vt[b & 1][2 * sk + 1];
-          const ps16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          o_acc[b] = pmma<T>::run(vf, pf[sk], o_acc[b]);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (b + 1 < DBLK) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      for (int m = 0; m < 4 * DBLK; ++m) {
+        const ps16x4_t v0 = vt[m % VW][0], v1 = vt[m % VW][1];
+        const ps16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o_acc[m >> 2] = pmma<T>::run(vf, pf[m & 3], o_acc[m >> 2]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m + VW < 4 * DBLK) {
+          read_v_step(m + VW, vt[m % VW]);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
       }
     }
     // the other stage was last read one iteration ago and every wave has passed a barrier since
-    if (has_next) write_lds(tile + 1, smem + (((tile - tile_lo) & 1) ^ 1) * BUF);
+    if (has_next) {
+      char* other = smem + (((tile - tile_lo) & 1) ^ 1) * BUF;
+      if (!k_written) write_lds_k(other);
+      write_lds_v(tile + 1, other);
+    }
     __syncthreads();
   }
 
