@@ -693,8 +693,16 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
     want = p.num_segments;
   } else {
     const long base = std::max(1L, decode_units(p) * p.num_kv_heads);  // waves with one split each
-    const long target = 256L * 8 * 2;                                   // ~2 waves per resident slot (8 waves/CU)
+    // One wave per resident slot (8 waves/CU x 256 CUs): a second round of waves only adds partials and a tail
+    // (sweep at the C3 shape, 8192 keys: batch 64 -> 4 splits 367 us vs 8 splits 378; batch 128 -> 2 vs 4: 697 vs 711).
+    const long target = 256L * 8;
     want = (int)((target + base - 1) / base);
+    // The in-kernel merge (one launch instead of two) serves up to `one_trip` splits: take it while that still gives
+    // every second slot a wave (batch 16: 8 splits 100 us, 16 splits 103, 32 splits 107).
+    const int G = p.num_q_heads / p.num_kv_heads, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));
+    const int dpad = padded_head_size(p.head_size, p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2);
+    const int one_trip = (16 / std::min(Gp, 16)) * (dpad >= 128 ? 2 : 4);
+    if (want > one_trip && base * one_trip >= target / 2) want = one_trip;
     want = std::min(want, std::max(1, max_tiles / 4));                  // keep each split >= 4 tiles (128 keys)
   }
   want = std::max(1, std::min(want, std::min(max_tiles, kMaxSplits)));
