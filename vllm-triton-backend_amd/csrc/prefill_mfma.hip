@@ -1147,11 +1147,12 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped
-    // prologue (measured: +6..15 % at 1 x 4096, +3 % at 16 x 4096, +5 % at 1 x 16384; -8..-20 % at <= 2048
-    // keys); otherwise 4 waves / 128-row Q blocks / 2 stages, two workgroups per CU.
+    // prologue (sustained rates, wide vs narrow: 1 x 4096 1009 vs 888 TFLOP/s, 4 x 4096 1024 vs 968, 1 x 8192 1081 vs
+    // 1003, 2 x 2048 896 vs 821; but 4 x 1024 610 vs 655, 1 x 2048 592 vs 660, 1 x 3072 856 vs 882);
+    // otherwise 4 waves / 128-row Q blocks / 2 stages, two workgroups per CU.
     // MI355_PREFILL=d4 | d8 pins one of the two for measurements.
     const long wgs8 = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 256 + p.num_seqs) * p.num_kv_heads;
-    bool wide = wgs8 >= 2 * 256 && p.max_seqlen_k >= 4096;
+    bool wide = wgs8 >= 2 * 256 && p.max_seqlen_k >= 2048;
     if (variant && variant[0] == 'd') wide = variant[1] == '8';
     if (wide && prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3))
       return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream) : launch_prefill_dma<f16_t, 8, 3>(p, stream);
