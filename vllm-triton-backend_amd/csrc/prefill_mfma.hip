@@ -49,6 +49,7 @@ struct PrefillArgs {
   int block_q;    // tokens per Q block = kBlockM / G
   int page_shift; // log2(page_size)
   int d_valid;    // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
+  int kv_same_strides;  // K and V cache strides are equal (two views of one tensor)
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
 };
 
@@ -679,10 +680,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
       kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
       vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
     }
-    const char* kp = kbase + ((uint64_t)(uint32_t)page * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2);
-    const char* vp = vbase + ((uint64_t)(uint32_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2);
-    glds16(kp + kvo, lds_addr(stage) + lds_wave + i * (RP * ROWB));
-    glds16(vp + vvo, lds_addr(stage) + KBUF + lds_wave + i * (RP * ROWB));
+    // K and V caches are two views of one tensor in vLLM: with equal strides (wave-uniform test, one scalar offset
+    // serves both) the 64-bit page arithmetic is done once
+    const uint64_t k_off = (uint64_t)(uint32_t)page * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2;
+    const uint64_t v_off = a.kv_same_strides ? k_off : (uint64_t)(uint32_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2;
+    glds16(kbase + k_off + kvo, lds_addr(stage) + lds_wave + i * (RP * ROWB));
+    glds16(vbase + v_off + vvo, lds_addr(stage) + KBUF + lds_wave + i * (RP * ROWB));   // (vvo carries V's own swizzle)
   };
   auto issue_dma = [&](int tile, char* stage) {
     dma_begin(tile);
@@ -1082,6 +1085,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   a.block_q = kBlockM / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
   a.d_valid = p.head_size;
+  a.kv_same_strides = (p.k_stride_page == p.v_stride_page && p.k_stride_slot == p.v_stride_slot && p.k_stride_head == p.v_stride_head) ? 1 : 0;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;  // static upper bound (:886-889,:935-943)
@@ -1114,6 +1118,7 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   a.block_q = (NW * 32) / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
   a.d_valid = p.head_size;
+  a.kv_same_strides = (p.k_stride_page == p.v_stride_page && p.k_stride_slot == p.v_stride_slot && p.k_stride_head == p.v_stride_head) ? 1 : 0;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
