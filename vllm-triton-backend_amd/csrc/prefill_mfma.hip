@@ -716,28 +716,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     v_rd0[b] = (uint32_t)(KBUF + r0 * ROWB + ((lc ^ f0) << 4) + 8 * (pp & 1));
     v_rd1[b] = (uint32_t)(KBUF + r1 * ROWB + ((lc ^ f1) << 4) + 8 * (pp & 1));
   }
-  // ds_read's immediate offset reaches 64 KiB: stages 0 and 1 are immediates on the addresses above, a stage
-  // beyond that gets per-lane addresses of its own (16 VGPRs) instead of one v_add per read
-  constexpr bool HI_STAGE = NST > 2;
-  uint32_t k_rdH[HI_STAGE ? KSTEPS : 1], v_rd0H[HI_STAGE ? DBLK : 1], v_rd1H[HI_STAGE ? DBLK : 1];
-  if constexpr (HI_STAGE) {
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) k_rdH[ks] = k_rd[ks] + 2 * STAGE;
-#pragma unroll
-    for (int b = 0; b < DBLK; ++b) { v_rd0H[b] = v_rd0[b] + 2 * STAGE; v_rd1H[b] = v_rd1[b] + 2 * STAGE; }
-  }
-  auto k_addr = [&](const char* stage, int ks) -> const char* {
-    if constexpr (HI_STAGE) { if (stage == smem + 2 * STAGE) return smem + k_rdH[ks]; }
-    return stage + k_rd[ks];
-  };
-  auto v_addr0 = [&](const char* stage, int b) -> const char* {
-    if constexpr (HI_STAGE) { if (stage == smem + 2 * STAGE) return smem + v_rd0H[b]; }
-    return stage + v_rd0[b];
-  };
-  auto v_addr1 = [&](const char* stage, int b) -> const char* {
-    if constexpr (HI_STAGE) { if (stage == smem + 2 * STAGE) return smem + v_rd1H[b]; }
-    return stage + v_rd1[b];
-  };
+  // ds_read's immediate offset reaches 64 KiB: stages 0 and 1 are immediates on the addresses above, a stage beyond
+  // that costs one v_add per read. (Per-lane addresses of its own for that stage, 16 more VGPRs, measured 0.7 %
+  // SLOWER sustained than the adds.)
+  auto k_addr = [&](const char* stage, int ks) -> const char* { return stage + k_rd[ks]; };
+  auto v_addr0 = [&](const char* stage, int b) -> const char* { return stage + v_rd0[b]; };
+  auto v_addr1 = [&](const char* stage, int b) -> const char* { return stage + v_rd1[b]; };
 
   float m_ref = 0.0f, l_run = 0.0f;
   bool started = !row_ok;               // padding rows never see a key: do not let them force the slow path
@@ -866,16 +850,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
     }
-    // row sum in four independent packed partial sums (v_pk_add_f32): a quarter of the add instructions and
-    // dependent chains of 4 instead of one of 32
+#ifdef MI355_PACKED_ROWSUM
+    // row sum in four independent packed partial sums (v_pk_add_f32)
     pf32x2_t ps2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#else
+    // row sum in four independent scalar chains seeded by the first four terms: packed f32 adds beside MFMAs cost
+    // more than the two scalar adds they replace (MI355X_MICROARCH: "an anti-lever beside MFMAs")
+    float ps1[4];
+#endif
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float e[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(s_acc[kb][r]);
+#ifdef MI355_PACKED_ROWSUM
 #pragma unroll
       for (int r = 0; r < 16; r += 2) ps2[(r >> 1) & 3] += pf32x2_t{e[r], e[r + 1]};
+#else
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kb == 0 && r < 4) ps1[r] = e[r];
+        else ps1[r & 3] += e[r];
+      }
+#endif
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const pu32x4_t w = {pmma<T>::pack2(e[8 * s + 0], e[8 * s + 1]), pmma<T>::pack2(e[8 * s + 2], e[8 * s + 3]),
@@ -883,8 +880,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
         pf[2 * kb + s] = __builtin_bit_cast(ps16x8_t, w);
       }
     }
+#ifdef MI355_PACKED_ROWSUM
     const pf32x2_t ps = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]);
     l_run += ps[0] + ps[1];
+#else
+    l_run += (ps1[0] + ps1[1]) + (ps1[2] + ps1[3]);
+#endif
 #endif
     MI355_STAMP(2);
   };
