@@ -98,6 +98,7 @@ def test_legacy_paged_decode_ignores_stale_nan_slots():
 @pytest.mark.parametrize("name", golden_io.names("legacy_ctxfwd"))
 def test_legacy_context_attention_fwd_golden(name):
     import gpu_util
+    from mi355_attn import _lib
     from mi355_attn.kernels.legacy import chunked_prefill_paged_decode, context_attention_fwd
 
     meta, t = golden_io.load(name)
@@ -109,6 +110,8 @@ def test_legacy_context_attention_fwd_golden(name):
     torch.cuda.synchronize()
     atol, rtol = golden_io.tolerance(t["q"].dtype)
     torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol)   # decode rows stay zero, as in the reference
+    sixteen_bit = t["q"].dtype in (torch.bfloat16, torch.float16)
+    assert _lib.last_kernel().startswith("repack+prefill") == sixteen_bit, _lib.last_kernel()   # fp32: generic kernel
     # chunked_prefill_paged_decode = the same prefill rows + the decode rows from the cache. The cache
     # must then hold the new tokens too: write them with our cache op into a flash-layout copy.
     kf, vf = orc.v0_to_flash(t["k_cache_v0"], t["v_cache_v0"])
@@ -129,6 +132,82 @@ def test_legacy_context_attention_fwd_golden(name):
                                  max(meta["query_lens"]), one, one, None, meta["window"] or None, meta["scale"])
     torch.cuda.synchronize()
     torch.testing.assert_close(out2.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    if sixteen_bit:   # prefill rows repacked, decode rows straight from the v0 cache
+        assert _lib.last_kernel().startswith("repack+prefill") and _lib.last_kernel().endswith("_v0"), _lib.last_kernel()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D,x", [(128, 8), (64, 8), (80, 8), (128, 1), (256, 8)])
+@pytest.mark.parametrize("feat", ["plain", "alibi", "window"])
+def test_legacy_prefill_ops_repacked_match_generic_kernel(dtype, D, x, feat):
+    """context_attention_fwd / chunked_prefill_paged_decode over v0 caches (5-D x=8 and 4-D) run on the repack +
+    matrix-core path; same call forced onto the shape-agnostic kernel is the reference (itself pinned by the goldens
+    above). Unused cache slots are NaN, rows of query_len == 1 must stay untouched in context_attention_fwd."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels.legacy import chunked_prefill_paged_decode, context_attention_fwd
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+
+    if feat != "plain" and (D, x) not in ((128, 8), (80, 8)):
+        pytest.skip("feature variants on two shapes only")
+    dev = gpu_util.DEV
+    Hq, Hk, page = 8, 2, 16
+    query_lens, ctx_lens = [70, 1, 300, 128, 1, 33], [0, 100, 37, 1000, 17, 16]
+    kv_lens = [a + b for a, b in zip(query_lens, ctx_lens)]
+    inp = orc.make_paged_inputs(77, query_lens, kv_lens, Hq, Hk, D, page, dtype)
+    T = sum(query_lens)
+    g = torch.Generator().manual_seed(78)
+    k_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype).to(dev)
+    v_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype).to(dev)
+    used = torch.zeros(inp["k_cache"].shape[:2], dtype=torch.bool)
+    for i, n in enumerate(kv_lens):
+        for j in range(n):
+            used[inp["block_table"][i, j // page], j % page] = True
+    inp["k_cache"][~used] = float("nan")
+    inp["v_cache"][~used] = float("nan")
+    nb = inp["k_cache"].shape[0]
+    k0 = inp["k_cache"].view(nb, page, Hk, D // x, x).permute(0, 2, 3, 1, 4).contiguous()
+    if x == 1:
+        k0 = k0.view(nb, Hk, D, page)
+    v0 = inp["v_cache"].permute(0, 2, 3, 1).contiguous()
+    k0, v0 = k0.to(dev), v0.to(dev)
+    q, bt, cu, sl = inp["q"].to(dev), inp["block_table"].to(dev), inp["cu_seqlens_q"].to(dev), inp["seqused_k"].to(dev)
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    slopes = torch.tensor([0.5 ** (i + 1) for i in range(Hq)], dtype=torch.float32, device=dev) if feat == "alibi" else None
+    window = 48 if feat == "window" else None
+    atol, rtol = golden_io.tolerance(dtype)
+    bound = bt.shape[1] * page + max(query_lens)
+
+    def generic(skip_decodes):
+        ref = torch.full_like(q, 7.0)
+        p, keep = fill_attn_params(q, k0, v0, ref, cu, max(query_lens), sl, bound, inp["scale"], (window - 1, 0) if window else (-1, -1), bt,
+                                   0.0, one, one, slopes, 9, k_new=k_new, v_new=v_new, skip_decodes=skip_decodes, legacy_v0_layout=True)
+        launch(p, dev)
+        torch.cuda.synchronize()
+        assert _lib.last_kernel() == "generic"
+        return ref
+
+    out = torch.full_like(q, 7.0)
+    context_attention_fwd(q, k_new, v_new, out, "auto", k0, v0, bt, cu, sl, max(query_lens), one, one, alibi_slopes=slopes,
+                          sliding_window=window, sm_scale=inp["scale"])
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("repack+prefill"), _lib.last_kernel()
+    ref = generic(True)
+    assert not torch.isnan(out).any()
+    for i, ql in enumerate(query_lens):
+        if ql == 1:
+            assert (out[int(inp["cu_seqlens_q"][i])] == 7.0).all()
+    torch.testing.assert_close(out.float(), ref.float(), atol=atol, rtol=rtol)
+
+    out2 = torch.full_like(q, float("nan"))
+    chunked_prefill_paged_decode(q, k_new, v_new, out2, "auto", k0, v0, bt, cu, sl, max(query_lens), one, one, slopes, window, inp["scale"])
+    torch.cuda.synchronize()
+    name = _lib.last_kernel()
+    assert name.startswith("repack+prefill"), name
+    if x == 8 and D in (64, 128, 256):
+        assert name.endswith("_v0"), name        # decode rows straight from the caller's cache
+    ref2 = generic(False)
+    torch.testing.assert_close(out2.float(), ref2.float(), atol=atol, rtol=rtol)
 
 
 @pytest.mark.parametrize("kv_cache_dtype,dtype", [("auto", torch.bfloat16), ("auto", torch.float16), ("fp8", torch.bfloat16), ("fp8_e5m2", torch.float16)])

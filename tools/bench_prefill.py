@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--page", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kvdtype", default="same", choices=["same", "fp8", "fp8_e5m2"])
+    ap.add_argument("--legacy", action="store_true", help="context_attention_fwd: v0 cache layout for the first --ctx keys, the rest from linear k/v")
+    ap.add_argument("--ctx", type=int, default=0, help="with --legacy: context keys per sequence (query length = seq - ctx)")
+    ap.add_argument("--generic", action="store_true", help="with --legacy: force the shape-agnostic kernel (the path before the repack)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16
@@ -43,6 +46,18 @@ def main():
     out = torch.empty_like(q)
     flops = 4 * L * L * args.d * args.hq / 2 * B
     p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, None)
+    if args.legacy:
+        QL = L - args.ctx
+        q = q[: B * QL].contiguous()
+        out = torch.empty_like(q)
+        cu = (torch.arange(B + 1, dtype=torch.int32, device=dev) * QL).to(torch.int32)
+        k0 = k.view(nb, page, args.hk, args.d // 8, 8).permute(0, 2, 3, 1, 4).contiguous()
+        v0 = v.permute(0, 2, 3, 1).contiguous()
+        k_new = (torch.rand(B * QL, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+        v_new = (torch.rand(B * QL, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+        flops = 4 * args.d * args.hq * (QL * args.ctx + QL * (QL + 1) / 2) * B
+        p, keep = ua_mod.fill_attn_params(q, k0, v0, out, cu, QL, sl, pps * page + QL, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, None, None, None,
+                                          9 if args.generic else None, k_new=k_new, v_new=v_new, skip_decodes=True, legacy_v0_layout=True)
     for _ in range(3):
         ua_mod.launch(p, dev)
     torch.cuda.synchronize()

@@ -55,11 +55,14 @@ static int validate(const mi355_attn_params* p) {
 // AUTO policy. The reference picks 3D iff max_seqlen_q == 1 (:884). We do the same for the
 // split-KV decode kernel, send everything else the MFMA prefill kernel covers there, and the
 // remainder to the generic kernel.
-enum class Path { Generic, Decode, Prefill, PrefillPlusDecode };
+enum class Path { Generic, Decode, Prefill, PrefillPlusDecode, Repacked };
 
 static Path choose(const mi355_attn_params& p) {
   const int sel = p.kernel_select;
   if (sel == MI355_SELECT_GENERIC) return Path::Generic;
+  // legacy ops: cache in the v0 layout and/or new keys in linear tensors - gathered into a flash-layout scratch
+  // cache first, then the kernels below run on that (repack.hip)
+  if (sel != MI355_SELECT_3D && repack_supported(p)) return Path::Repacked;
   const bool dec_ok = decode_supported(p);
   const bool pre_ok = prefill_supported(p);
   if (sel == MI355_SELECT_3D) return dec_ok ? Path::Decode : Path::Generic;
@@ -76,6 +79,72 @@ static Path choose(const mi355_attn_params& p) {
   return Path::Generic;
 }
 
+// workspace of a call that needs no repacking: follows the dispatch decision, host-known sizes only
+static size_t plain_workspace_bytes(const mi355_attn_params& p) {
+  switch (choose(p)) {
+    case Path::Decode: return decode_workspace_bytes(p);
+    case Path::PrefillPlusDecode: {
+      mi355_attn_params pd = p;
+      pd.only_decodes = 1;
+      return decode_workspace_bytes(pd);
+    }
+    default: return 0;
+  }
+}
+
+static int dispatch_plain(const mi355_attn_params& p, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  int rc;
+  switch (choose(p)) {
+    case Path::Decode:
+      return launch_decode(p, workspace, workspace_bytes, s);
+    case Path::Prefill:
+      return launch_prefill(p, s);
+    case Path::PrefillPlusDecode: {
+      mi355_attn_params pp = p, pd = p;
+      pp.skip_decodes = 1;
+      pd.only_decodes = 1;
+      rc = launch_prefill(pp, s);
+      const char* prefill_name = g_kernel;
+      if (rc == MI355_OK) rc = launch_decode(pd, workspace, workspace_bytes, s);
+      if (rc == MI355_OK) {                      // "<prefill kernel>+<decode kernel>"
+        static thread_local char both[96];
+        snprintf(both, sizeof(both), "%s+%s", prefill_name, g_kernel);
+        set_kernel_name(both);
+      }
+      return rc;
+    }
+    default:
+      rc = launch_generic(p, s);
+      if (rc == MI355_OK) set_kernel_name("generic");
+      return rc;
+  }
+}
+
+// Repacked call: how its query_len == 1 rows are served, and the bytes the attention kernels want ahead of the scratch.
+struct RepackPlan {
+  bool direct_decode;        // decode rows read the caller's cache with the split-KV kernel (no copy of their keys)
+  mi355_attn_params pd;      // that decode call
+  size_t head;
+};
+
+static RepackPlan plan_repack(const mi355_attn_params& p) {
+  RepackPlan r;
+  r.pd = p;
+  r.pd.k_new = r.pd.v_new = nullptr;         // decode rows never read the linear source (generic_attn.hip: use_new)
+  r.pd.only_decodes = 1;
+  const bool uniform_prefill = (int64_t)p.num_seqs * p.max_seqlen_q == p.num_tokens;
+  r.direct_decode = !p.skip_decodes && !uniform_prefill && p.num_seqs > 1 && decode_supported(r.pd);
+  mi355_attn_params pr = repacked_params(p, nullptr, 0);
+  if (r.direct_decode) pr.skip_decodes = 1;
+  const size_t a = plain_workspace_bytes(pr), b = r.direct_decode ? decode_workspace_bytes(r.pd) : 0;
+  r.head = a > b ? a : b;
+  // the first 256 KiB of every workspace are the split-KV arrival counters, which stay zero between calls
+  // (include/mi355_attn.h): the scratch never lands there, also when this call needs no split-KV partials
+  const size_t counters = (size_t)256 << 10;
+  if (r.head < counters) r.head = counters;
+  return r;
+}
+
 }  // namespace mi355
 
 using namespace mi355;
@@ -90,17 +159,9 @@ const char* mi355_last_kernel(void) { return g_kernel; }
 
 size_t mi355_attn_workspace_bytes(const mi355_attn_params* p) {
   if (!p || p->num_tokens <= 0 || p->num_seqs <= 0) return 0;
-  // follows the dispatch decision, which depends on host-known sizes only
   if (validate(p) != MI355_OK) return 0;
-  switch (choose(*p)) {
-    case Path::Decode: return decode_workspace_bytes(*p);
-    case Path::PrefillPlusDecode: {
-      mi355_attn_params pd = *p;
-      pd.only_decodes = 1;
-      return decode_workspace_bytes(pd);
-    }
-    default: return 0;
-  }
+  if (choose(*p) == Path::Repacked) return repack_scratch_bytes(*p, plan_repack(*p).head);
+  return plain_workspace_bytes(*p);
 }
 
 int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
@@ -109,32 +170,27 @@ int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t 
   if (rc != MI355_OK) return rc;
   if (p->num_tokens == 0 || p->num_seqs == 0) return MI355_OK;
   hipStream_t s = (hipStream_t)stream;
-  switch (choose(*p)) {
-    case Path::Decode:
-      rc = launch_decode(*p, workspace, workspace_bytes, s);
-      break;
-    case Path::Prefill:
-      rc = launch_prefill(*p, s);
-      break;
-    case Path::PrefillPlusDecode: {
-      mi355_attn_params pp = *p, pd = *p;
-      pp.skip_decodes = 1;
-      pd.only_decodes = 1;
-      rc = launch_prefill(pp, s);
-      const char* prefill_name = g_kernel;
-      if (rc == MI355_OK) rc = launch_decode(pd, workspace, workspace_bytes, s);
-      if (rc == MI355_OK) {                      // "<prefill kernel>+<decode kernel>"
-        static thread_local char both[96];
-        snprintf(both, sizeof(both), "%s+%s", prefill_name, g_kernel);
-        set_kernel_name(both);
-      }
-      break;
-    }
-    default:
-      rc = launch_generic(*p, s);
-      if (rc == MI355_OK) set_kernel_name("generic");
-      break;
+  if (choose(*p) != Path::Repacked) return dispatch_plain(*p, workspace, workspace_bytes, s);
+
+  const RepackPlan plan = plan_repack(*p);
+  const size_t need = repack_scratch_bytes(*p, plan.head);
+  if (!workspace || workspace_bytes < need) {
+    set_error("workspace of %zu bytes is smaller than the %zu this call needs (mi355_attn_workspace_bytes)", workspace_bytes, need);
+    return MI355_ERR_WORKSPACE;
   }
+  rc = launch_repack(*p, workspace, plan.head, p->skip_decodes || plan.direct_decode, s);
+  if (rc != MI355_OK) return rc;
+  mi355_attn_params pr = repacked_params(*p, workspace, plan.head);
+  if (plan.direct_decode) pr.skip_decodes = 1;
+  rc = dispatch_plain(pr, workspace, plan.head, s);
+  static thread_local char name[128];
+  snprintf(name, sizeof(name), "repack+%s", g_kernel);
+  if (rc == MI355_OK && plan.direct_decode) {
+    rc = launch_decode(plan.pd, workspace, plan.head, s);
+    const size_t n = strlen(name);
+    snprintf(name + n, sizeof(name) - n, "+%s", g_kernel);
+  }
+  if (rc == MI355_OK) set_kernel_name(name);
   return rc;
 }
 

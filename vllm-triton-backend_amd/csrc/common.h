@@ -300,6 +300,11 @@ int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStre
 
 bool prefill_supported(const mi355_attn_params& p);
 int launch_prefill(const mi355_attn_params& p, hipStream_t stream);
+// legacy layouts / linear new-token source -> flash-layout scratch cache (repack.hip)
+bool repack_supported(const mi355_attn_params& p);
+size_t repack_scratch_bytes(const mi355_attn_params& p, size_t head);
+mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, size_t head);
+int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool skip_single, hipStream_t stream);
 bool prefill_w64_applicable(const mi355_attn_params& p);   // beyond prefill_supported()
 int launch_prefill_w64(const mi355_attn_params& p, hipStream_t stream);
 

@@ -7,8 +7,10 @@ description covers the v0 layout and its optional linear "new token" K/V source 
 context_attention_fwd, so one launch replaces the reference's kernels (and the two launches of
 chunked_prefill_paged_decode). `paged_attention_2d/3d` over a 16-bit 5-D v0 cache (x = 8) with head size
 64/128/256 run on the split-KV MFMA decode kernel ("decode_*_v0": a (page, head) tile of that layout is one
-contiguous block of MFMA-shaped 16-byte pieces); everything else here (fp8 or 4-D key caches, the ops with a
-linear new-token source) runs on the shape-agnostic HIP kernel.
+contiguous block of MFMA-shaped 16-byte pieces). `context_attention_fwd` and `chunked_prefill_paged_decode` with a
+16-bit cache gather each sequence's keys (context pages of either v0 form, new rows from the linear tensors) into a
+flash-layout scratch cache in the workspace and run the matrix-core prefill kernel on it ("repack+prefill_dma..."),
+decode rows of a mixed batch going straight to the v0 decode kernel; fp8 caches run on the shape-agnostic HIP kernel.
 """
 
 from __future__ import annotations
@@ -65,9 +67,11 @@ def context_attention_fwd(
     assert b_seq_len.shape[0] + 1 == len(b_start_loc)
     if sliding_window is None or sliding_window <= 0:
         sliding_window = 0
+    # the signature carries no maximum key length: context fits the block table, new keys number at most max_input_len
+    max_seq_len = b_loc.shape[1] * v_cache.shape[3] + max_input_len
     p, keep = fill_attn_params(
-        q, k_cache, v_cache, o, b_start_loc, max_input_len, b_seq_len, max_input_len, sm_scale,
-        (sliding_window - 1, 0) if sliding_window else (-1, -1), b_loc, 0.0, k_scale, v_scale, alibi_slopes, 9,
+        q, k_cache, v_cache, o, b_start_loc, max_input_len, b_seq_len, max_seq_len, sm_scale,
+        (sliding_window - 1, 0) if sliding_window else (-1, -1), b_loc, 0.0, k_scale, v_scale, alibi_slopes, None,
         k_new=k, v_new=v, skip_decodes=True, legacy_v0_layout=True,
     )
     launch(p, q.device)
@@ -113,9 +117,10 @@ def chunked_prefill_paged_decode(query, key, value, output, kv_cache_dtype, key_
     _require_gpu(query, "chunked_prefill_paged_decode")
     key_cache, value_cache = _fp8_view(key_cache, kv_cache_dtype), _fp8_view(value_cache, kv_cache_dtype)
     sw = sliding_window if sliding_window is not None and sliding_window > 0 else 0
+    max_seq_len = block_table.shape[1] * value_cache.shape[3] + max_query_len   # as in context_attention_fwd
     p, keep = fill_attn_params(
-        query, key_cache, value_cache, output, query_start_loc, max_query_len, seq_lens, 0, scale,
-        (sw - 1, 0) if sw else (-1, -1), block_table, 0.0, k_scale, v_scale, alibi_slopes, 9,
+        query, key_cache, value_cache, output, query_start_loc, max_query_len, seq_lens, max_seq_len, scale,
+        (sw - 1, 0) if sw else (-1, -1), block_table, 0.0, k_scale, v_scale, alibi_slopes, None,
         k_new=key, v_new=value, legacy_v0_layout=True,
     )
     launch(p, query.device)
