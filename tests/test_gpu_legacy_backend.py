@@ -210,6 +210,45 @@ def test_legacy_prefill_ops_repacked_match_generic_kernel(dtype, D, x, feat):
     torch.testing.assert_close(out2.float(), ref2.float(), atol=atol, rtol=rtol)
 
 
+def test_legacy_context_attention_fwd_c2_size_equals_unified_attention():
+    """Size-independent property at the C2 shape (Hq 32 / Hk 8 / D 128, 4096 keys, bf16): context_attention_fwd over
+    a v0 cache + linear new K/V gives what unified_attention gives over a flash-layout cache holding the same keys."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels import reshape_and_cache_flash, unified_attention
+    from mi355_attn.kernels.legacy import context_attention_fwd
+
+    dev = gpu_util.DEV
+    B, ctx, QL, Hq, Hk, D, page = 2, 1024, 3072, 32, 8, 128, 16
+    L = ctx + QL
+    pps = L // page
+    nb = B * pps + 5
+    g = torch.Generator(device="cpu").manual_seed(5)
+    kf = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    vf = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    q = (torch.rand(B * QL, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    k_new = (torch.rand(B * QL, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    v_new = (torch.rand(B * QL, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    bt = torch.randperm(nb, generator=g)[: B * pps].to(torch.int32).view(B, pps).to(dev)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * QL).to(dev)
+    sl = torch.full((B,), L, dtype=torch.int32, device=dev)
+    # v0 view of the cache BEFORE the new tokens are written: the legacy op must take them from the linear tensors
+    k0 = kf.view(nb, page, Hk, D // 8, 8).permute(0, 2, 3, 1, 4).contiguous()
+    v0 = vf.permute(0, 2, 3, 1).contiguous()
+    pos = torch.arange(ctx, L, device=dev)
+    slots = torch.cat([bt[i].long()[pos // page] * page + pos % page for i in range(B)])
+    reshape_and_cache_flash(k_new, v_new, kf, vf, slots, "auto", None, None)
+    scale = 1.0 / D ** 0.5
+    out_u = torch.empty_like(q)
+    unified_attention(q, kf, vf, out_u, cu, QL, sl, L, QL, L, scale, True, (-1, -1), bt, 0.0, None, None, None)
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    out_l = torch.empty_like(q)
+    context_attention_fwd(q, k_new, v_new, out_l, "auto", k0, v0, bt, cu, sl, QL, one, one, sm_scale=scale)
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("repack+prefill"), _lib.last_kernel()
+    torch.testing.assert_close(out_l.float(), out_u.float(), atol=1e-2, rtol=0)   # bf16 tolerance of the suite: 2e-2
+
+
 @pytest.mark.parametrize("kv_cache_dtype,dtype", [("auto", torch.bfloat16), ("auto", torch.float16), ("fp8", torch.bfloat16), ("fp8_e5m2", torch.float16)])
 def test_impl_forward_writes_cache_then_attends(kv_cache_dtype, dtype):
     """What vLLM calls per layer: forward(layer, q, k, v, kv_cache, metadata, output)."""
