@@ -27,6 +27,26 @@ def main():
     dev = torch.device("cuda:0")
     dt, page = torch.bfloat16, 16
     torch.manual_seed(0)
+    # floor: a one-element torch kernel, same two measurements
+    x = torch.zeros(1, device=dev)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x.add_(1.0)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(50):
+                x.add_(1.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"floor: one-element kernel in a graph {e0.elapsed_time(e1) * 1e3 / 500:5.1f} us/node", flush=True)
     for B in args.batch:
         for L in args.kv:
             pps = (L + page - 1) // page
@@ -69,7 +89,7 @@ def main():
             graph_us = e0.elapsed_time(e1) * 1e3 / 500
             nbytes = 2 * B * L * args.hk * args.d * 2
             print(f"B={B} kv={L:6d} kernel={_lib.last_kernel():16s} stream {stream_us:7.1f} us/call   graph {graph_us:7.1f} us/call   "
-                  f"({nbytes / graph_us / 1e6:7.1f} GB/s)", flush=True)
+                  f"({nbytes / graph_us / 1e3:7.1f} GB/s)", flush=True)
 
 
 if __name__ == "__main__":
