@@ -210,6 +210,59 @@ def test_legacy_prefill_ops_repacked_match_generic_kernel(dtype, D, x, feat):
     torch.testing.assert_close(out2.float(), ref2.float(), atol=atol, rtol=rtol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_cache_dtype", ["fp8", "fp8_e5m2"])
+def test_legacy_prefill_ops_fp8_cache_repacked_match_generic_kernel(dtype, kv_cache_dtype):
+    """fp8 v0 caches (uint8 tensors + kv_cache_dtype, x = 16): the repack pass dequantises the context the way the
+    reference's kernels do on load, new keys stay 16-bit. Reference: the same call on the shape-agnostic kernel."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels.legacy import chunked_prefill_paged_decode, context_attention_fwd
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page, x = 8, 2, 128, 16, 16
+    f8 = torch.float8_e4m3fn if kv_cache_dtype == "fp8" else torch.float8_e5m2
+    query_lens, ctx_lens = [70, 1, 300, 1, 33], [0, 100, 37, 17, 16]
+    kv_lens = [a + b for a, b in zip(query_lens, ctx_lens)]
+    inp = orc.make_paged_inputs(81, query_lens, kv_lens, Hq, Hk, D, page, dtype)
+    T = sum(query_lens)
+    g = torch.Generator().manual_seed(82)
+    k_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype).to(dev)
+    v_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype).to(dev)
+    nb = inp["k_cache"].shape[0]
+    ks, vs = 0.5, 0.25
+    k8 = (inp["k_cache"].float() / ks).to(f8)
+    v8 = (inp["v_cache"].float() / vs).to(f8)
+    k0 = k8.view(torch.uint8).view(nb, page, Hk, D // x, x).permute(0, 2, 3, 1, 4).contiguous().to(dev)
+    v0 = v8.view(torch.uint8).permute(0, 2, 3, 1).contiguous().to(dev)
+    q, bt, cu, sl = inp["q"].to(dev), inp["block_table"].to(dev), inp["cu_seqlens_q"].to(dev), inp["seqused_k"].to(dev)
+    k_scale = torch.tensor([ks], dtype=torch.float32, device=dev)
+    v_scale = torch.tensor([vs], dtype=torch.float32, device=dev)
+    atol, rtol = golden_io.tolerance(dtype, f8)
+    bound = bt.shape[1] * page + max(query_lens)
+
+    def generic(skip_decodes):
+        ref = torch.full_like(q, 7.0)
+        p, keep = fill_attn_params(q, k0.view(f8), v0.view(f8), ref, cu, max(query_lens), sl, bound, inp["scale"], (-1, -1), bt, 0.0, k_scale, v_scale,
+                                   None, 9, k_new=k_new, v_new=v_new, skip_decodes=skip_decodes, legacy_v0_layout=True)
+        launch(p, dev)
+        torch.cuda.synchronize()
+        assert _lib.last_kernel() == "generic"
+        return ref
+
+    out = torch.full_like(q, 7.0)
+    context_attention_fwd(q, k_new, v_new, out, kv_cache_dtype, k0, v0, bt, cu, sl, max(query_lens), k_scale, v_scale, sm_scale=inp["scale"])
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("repack+prefill"), _lib.last_kernel()
+    torch.testing.assert_close(out.float(), generic(True).float(), atol=atol, rtol=rtol)
+    out2 = torch.full_like(q, float("nan"))
+    chunked_prefill_paged_decode(q, k_new, v_new, out2, kv_cache_dtype, k0, v0, bt, cu, sl, max(query_lens), k_scale, v_scale, None, None, inp["scale"])
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("repack+prefill"), _lib.last_kernel()
+    torch.testing.assert_close(out2.float(), generic(False).float(), atol=atol, rtol=rtol)
+
+
 def test_legacy_context_attention_fwd_c2_size_equals_unified_attention():
     """Size-independent property at the C2 shape (Hq 32 / Hk 8 / D 128, 4096 keys, bf16): context_attention_fwd over
     a v0 cache + linear new K/V gives what unified_attention gives over a flash-layout cache holding the same keys."""

@@ -2,7 +2,7 @@
 // LIB/kernels/legacy/triton_prefix_prefill.py:588-765, triton_chunked_prefill_paged_decode.py:28-117).
 //
 // Those ops read context keys from the vLLM v0 cache layout (K [nb, Hk, D/x, page, x], V [nb, Hk, D, page]) and the
-// keys of the tokens being prefilled from linear [T, Hk, D] tensors. The matrix-core prefill kernel stages whole
+// keys of the tokens being prefilled from linear [T, Hk, D] tensors (the cache may be fp8, the linear tensors never are). The matrix-core prefill kernel stages whole
 // flash-layout rows through LDS-DMA; rather than a second copy of that kernel for a d-major V and a two-source key
 // stream, one pass gathers every sequence's keys - context pages from the cache (any layout the ABI's strides
 // describe), new rows from the linear tensors - into a flash-layout scratch cache in the caller's workspace with an
@@ -27,16 +27,58 @@ struct RepackArgs {
   int skip_single;             // sequences with query_len == 1 are not repacked (left out or served from the cache)
 };
 
-__device__ inline uint4 gather8(const uint16_t* base, int64_t off0, int64_t stride) {
-  uint16_t e[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) e[i] = base[off0 + i * stride];
+__device__ inline uint4 pack8(const uint16_t (&e)[8]) {
   return uint4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
                (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
 }
 
+__device__ inline uint4 gather8(const uint16_t* base, int64_t off0, int64_t stride) {
+  uint16_t e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = base[off0 + i * stride];
+  return pack8(e);
+}
+
+// Eight consecutive head dims of one cached key as 16-bit elements of the query type. A 16-bit cache is moved as raw
+// bits; an fp8 cache is dequantised the way the reference's kernels do on load, (fp8 -> f32) * scale -> query type
+// (legacy/triton_prefix_prefill.py:154-155,:208-209; triton_unified_attention.py:434-455), so the scratch cache needs no scales.
+template <typename QT, typename KVT>
+struct CachePiece {
+  static constexpr bool kFp8 = !__is_same(QT, KVT);
+  // element (dim d0 + i) lives at off(i); `vec`: the eight are contiguous and aligned
+  template <typename OffFn>
+  static __device__ inline uint4 load(const void* cache, bool vec, float scale, OffFn off) {
+    uint16_t e[8];
+    if constexpr (!kFp8) {
+      const uint16_t* c = (const uint16_t*)cache;
+      if (vec) return *(const uint4*)(c + off(0));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = c[off(i)];
+    } else {
+      const uint8_t* c = (const uint8_t*)cache;
+      uint8_t b[8];
+      if (vec) {
+        const uint2 w = *(const uint2*)(c + off(0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { b[i] = (uint8_t)(w.x >> (8 * i)); b[4 + i] = (uint8_t)(w.y >> (8 * i)); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = c[off(i)];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float f;
+        if constexpr (__is_same(KVT, e4m3_t)) f = e4m3_to_f32(b[i]); else f = e5m2_to_f32(b[i]);
+        if constexpr (__is_same(QT, bf16_t)) e[i] = f32_to_bf16(f * scale); else e[i] = f32_to_f16(f * scale);
+      }
+    }
+    return pack8(e);
+  }
+};
+
 // grid (pages_per_seq, num_seqs), 256 threads: one scratch page (16 keys x Hk x D) of one sequence per workgroup,
-// moved as 16-byte pieces (8 head dims of one key and head). 16-bit elements are moved as raw bits.
+// moved as 16-byte pieces (8 head dims of one key and head).
+template <typename QT, typename KVT>
 __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   const mi355_attn_params& p = a.p;
   const int pg = blockIdx.x, seq = blockIdx.y;
@@ -51,10 +93,11 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   const int D = p.head_size, Hk = p.num_kv_heads, chunks = D >> 3;
   const int pieces = kRepackPage * Hk * chunks;
   const int64_t dst_page = ((int64_t)seq * a.pages_per_seq + pg) * kRepackPage * Hk * D;
-  const uint16_t* kc = (const uint16_t*)p.k_cache;
-  const uint16_t* vc = (const uint16_t*)p.v_cache;
   const uint16_t* kn = (const uint16_t*)p.k_new;
   const uint16_t* vn = (const uint16_t*)p.v_new;
+  constexpr bool kFp8 = CachePiece<QT, KVT>::kFp8;
+  const float k_scale = (kFp8 && p.k_scale) ? p.k_scale[0] : 1.0f;
+  const float v_scale = (kFp8 && p.v_scale) ? p.v_scale[0] : 1.0f;
   for (int idx = threadIdx.x; idx < pieces; idx += 256) {
     const int c = idx % chunks, h = (idx / chunks) % Hk, slot = idx / (chunks * Hk);
     const int j = j0 + slot, d0 = 8 * c;
@@ -74,19 +117,11 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
         const int o = j % p.page_size;
         const int64_t kb = (int64_t)page * p.k_stride_page + (int64_t)o * p.k_stride_slot + (int64_t)h * p.k_stride_head;
         const int64_t vb = (int64_t)page * p.v_stride_page + (int64_t)o * p.v_stride_slot + (int64_t)h * p.v_stride_head;
-        if (a.vec_k) {
-          kk = *(const uint4*)(kc + kb + (int64_t)(d0 / p.k_x) * p.k_stride_dx + (d0 % p.k_x));
-        } else {
-          uint16_t e[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int d = d0 + i;
-            e[i] = kc[kb + (int64_t)(d / p.k_x) * p.k_stride_dx + (int64_t)(d % p.k_x) * p.k_stride_d];
-          }
-          kk = uint4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
-                     (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
-        }
-        vv = a.vec_v ? *(const uint4*)(vc + vb + d0) : gather8(vc, vb + (int64_t)d0 * p.v_stride_d, p.v_stride_d);
+        kk = CachePiece<QT, KVT>::load(p.k_cache, a.vec_k, k_scale, [&](int i) {
+          const int d = d0 + i;
+          return kb + (int64_t)(d / p.k_x) * p.k_stride_dx + (int64_t)(d % p.k_x) * p.k_stride_d;
+        });
+        vv = CachePiece<QT, KVT>::load(p.v_cache, a.vec_v, v_scale, [&](int i) { return vb + (int64_t)(d0 + i) * p.v_stride_d; });
       }
     }
     const int64_t dst = dst_page + ((int64_t)slot * Hk + h) * D + d0;
@@ -94,6 +129,8 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
     *(uint4*)(a.v_dst + dst) = vv;
   }
 }
+
+bool is_fp8(int d) { return d == MI355_FP8_E4M3 || d == MI355_FP8_E5M2; }
 
 bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
@@ -127,6 +164,8 @@ mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, siz
   r.block_table = (const int32_t*)(base ? base + l.bt_off : (char*)(uintptr_t)256);
   r.block_table_stride = pages_per_seq(p);
   r.k_new = r.v_new = nullptr;
+  r.kv_dtype = p.q_dtype;                 // an fp8 cache is dequantised on the way in
+  r.k_scale = r.v_scale = nullptr;
   r.page_size = kRepackPage;
   r.k_x = p.head_size;
   r.k_stride_d = r.v_stride_d = 1;
@@ -138,9 +177,9 @@ mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, siz
 }
 
 bool repack_supported(const mi355_attn_params& p) {
-  if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) || p.kv_dtype != p.q_dtype) return false;
+  if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) || (p.kv_dtype != p.q_dtype && !is_fp8(p.kv_dtype))) return false;
   const bool flash = p.k_x == p.head_size && p.k_stride_d == 1 && p.v_stride_d == 1;
-  if (!p.k_new && flash) return false;                       // nothing to repack
+  if (!p.k_new && flash) return false;                       // nothing to repack: the kernels read that cache themselves
   if (p.only_decodes || p.max_seqlen_q <= 1 || p.max_seqlen_k <= 0) return false;
   if (p.head_size % 8 != 0 || p.page_size <= 0) return false;
   if (layout(p, 0).total > kRepackMaxBytes) return false;
@@ -159,15 +198,27 @@ int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool s
   a.v_dst = (uint16_t*)(base + l.v_off);
   a.pages_per_seq = pages_per_seq(p);
   a.skip_single = skip_single ? 1 : 0;
+  // 16-byte (16-bit cache) / 8-byte (fp8 cache) loads of eight consecutive head dims
+  const int64_t unit = is_fp8(p.kv_dtype) ? 8 : 16;
+  auto aligned = [&](const void* ptr) { return ((uintptr_t)ptr & (uintptr_t)(unit - 1)) == 0; };
   const int64_t ks[] = {p.k_stride_page, p.k_stride_slot, p.k_stride_head, p.k_stride_dx};
-  a.vec_k = p.k_stride_d == 1 && p.k_x % 8 == 0 && aligned16(p.k_cache);
+  a.vec_k = p.k_stride_d == 1 && p.k_x % 8 == 0 && aligned(p.k_cache);
   for (int64_t s : ks) a.vec_k = a.vec_k && s % 8 == 0;
   const int64_t vs[] = {p.v_stride_page, p.v_stride_slot, p.v_stride_head};
-  a.vec_v = p.v_stride_d == 1 && aligned16(p.v_cache);
+  a.vec_v = p.v_stride_d == 1 && aligned(p.v_cache);
   for (int64_t s : vs) a.vec_v = a.vec_v && s % 8 == 0;
   a.vec_new = p.k_new && aligned16(p.k_new) && aligned16(p.v_new) && p.new_stride_token % 8 == 0 && p.new_stride_head % 8 == 0;
   dim3 grid(a.pages_per_seq, p.num_seqs);
-  hipLaunchKernelGGL(repack_kernel, grid, dim3(256), 0, stream, a);
+  const bool bf = p.q_dtype == MI355_BF16;
+  if (p.kv_dtype == MI355_FP8_E4M3) {
+    if (bf) hipLaunchKernelGGL((repack_kernel<bf16_t, e4m3_t>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((repack_kernel<f16_t, e4m3_t>), grid, dim3(256), 0, stream, a);
+  } else if (p.kv_dtype == MI355_FP8_E5M2) {
+    if (bf) hipLaunchKernelGGL((repack_kernel<bf16_t, e5m2_t>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((repack_kernel<f16_t, e5m2_t>), grid, dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((repack_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, a);   // 16-bit caches move as raw bits
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("repack launch failed: %s", hipGetErrorString(e)); return MI355_ERR_HIP; }
   return MI355_OK;

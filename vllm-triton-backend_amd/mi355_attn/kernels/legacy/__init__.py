@@ -7,10 +7,11 @@ description covers the v0 layout and its optional linear "new token" K/V source 
 context_attention_fwd, so one launch replaces the reference's kernels (and the two launches of
 chunked_prefill_paged_decode). `paged_attention_2d/3d` over a 16-bit 5-D v0 cache (x = 8) with head size
 64/128/256 run on the split-KV MFMA decode kernel ("decode_*_v0": a (page, head) tile of that layout is one
-contiguous block of MFMA-shaped 16-byte pieces). `context_attention_fwd` and `chunked_prefill_paged_decode` with a
-16-bit cache gather each sequence's keys (context pages of either v0 form, new rows from the linear tensors) into a
+contiguous block of MFMA-shaped 16-byte pieces). `context_attention_fwd` and `chunked_prefill_paged_decode` (16-bit
+or fp8 cache) gather each sequence's keys (context pages of either v0 form, new rows from the linear tensors) into a
 flash-layout scratch cache in the workspace and run the matrix-core prefill kernel on it ("repack+prefill_dma..."),
-decode rows of a mixed batch going straight to the v0 decode kernel; fp8 caches run on the shape-agnostic HIP kernel.
+decode rows of a mixed batch going straight to the v0 decode kernel when it covers the cache; `paged_attention_2d/3d`
+over fp8 or 4-D caches run on the shape-agnostic HIP kernel.
 """
 
 from __future__ import annotations
