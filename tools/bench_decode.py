@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--kvdtype", default="same", choices=["same", "fp8", "fp8_e5m2"])
     ap.add_argument("--flush", default="write", choices=["write", "read", "none"])
     ap.add_argument("--legacy", action="store_true", help="legacy v0 cache layout through paged_attention_2d")
+    ap.add_argument("--generic", action="store_true", help="force the shape-agnostic kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
@@ -48,10 +49,11 @@ def main():
     out = torch.empty_like(q)
     algo_bytes = B * kv * args.hk * args.d * 2 * k.element_size() + 2 * q.numel() * q.element_size() + bt.numel() * 4 + (2 * B + 1) * 4
     if args.legacy:      # K [nb, Hk, D/8, page, 8], V [nb, Hk, D, page]
-        k = k.view(nb, page, args.hk, args.d // 8, 8).permute(0, 2, 3, 1, 4).contiguous()
+        x = 16 // k.element_size()
+        k = k.view(nb, page, args.hk, args.d // x, x).permute(0, 2, 3, 1, 4).contiguous()
         v = v.permute(0, 2, 3, 1).contiguous()
     for seg in args.segments:
-        p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, 1, sl, kv, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, None,
+        p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, 1, sl, kv, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, 9 if args.generic else None,
                                           num_segments=seg, legacy_v0_layout=args.legacy)
         for _ in range(3):
             ua_mod.launch(p, dev)

@@ -23,7 +23,8 @@ struct RepackArgs {
   uint16_t* v_dst;
   int32_t* bt_dst;
   int pages_per_seq;
-  int vec_k, vec_v, vec_new;   // 16-byte loads are legal for that source
+  int vec_k, vec_v, vec_new;   // 16-byte (fp8: 8-byte) loads of eight head dims are legal for that source
+  int v_keys_contiguous;       // V is d-major with a page's keys contiguous (v0): eight KEYS per load, turned in LDS
   int skip_single;             // sequences with query_len == 1 are not repacked (left out or served from the cache)
 };
 
@@ -56,33 +57,49 @@ struct CachePiece {
       for (int i = 0; i < 8; ++i) e[i] = c[off(i)];
     } else {
       const uint8_t* c = (const uint8_t*)cache;
-      uint8_t b[8];
+      uint2 w;
       if (vec) {
-        const uint2 w = *(const uint2*)(c + off(0));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { b[i] = (uint8_t)(w.x >> (8 * i)); b[4 + i] = (uint8_t)(w.y >> (8 * i)); }
+        w = *(const uint2*)(c + off(0));
       } else {
+        w = uint2{0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = c[off(i)];
+        for (int i = 0; i < 4; ++i) { w.x |= (uint32_t)c[off(i)] << (8 * i); w.y |= (uint32_t)c[off(4 + i)] << (8 * i); }
       }
+      // v_cvt_scalef32_pk_f32_{fp8,bf8} at scale 1: exact (every fp8 value is an f32); then the reference's f32
+      // multiply and one rounding to the query type (v_cvt_pk_{bf16,f16}_f32, round to nearest even)
+      typedef __attribute__((ext_vector_type(2))) float f2;
+      auto widen = [](uint32_t word, f2& lo, f2& hi) {
+        if constexpr (__is_same(KVT, e4m3_t)) {
+          lo = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(word, 1.0f, false);
+          hi = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(word, 1.0f, true);
+        } else {
+          lo = __builtin_amdgcn_cvt_scalef32_pk_f32_bf8(word, 1.0f, false);
+          hi = __builtin_amdgcn_cvt_scalef32_pk_f32_bf8(word, 1.0f, true);
+        }
+      };
+      f2 f[4];
+      widen(w.x, f[0], f[1]);
+      widen(w.y, f[2], f[3]);
+      uint32_t o[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float f;
-        if constexpr (__is_same(KVT, e4m3_t)) f = e4m3_to_f32(b[i]); else f = e5m2_to_f32(b[i]);
-        if constexpr (__is_same(QT, bf16_t)) e[i] = f32_to_bf16(f * scale); else e[i] = f32_to_f16(f * scale);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (__is_same(QT, bf16_t)) o[i] = pack_bf16x2(f[i].x * scale, f[i].y * scale); else o[i] = pack_f16x2(f[i].x * scale, f[i].y * scale);
       }
+      return uint4{o[0], o[1], o[2], o[3]};
     }
     return pack8(e);
   }
 };
 
-// grid (pages_per_seq, num_seqs), 256 threads: one scratch page (16 keys x Hk x D) of one sequence per workgroup,
-// moved as 16-byte pieces (8 head dims of one key and head).
+// grid (pages_per_seq, num_seqs, Hk), 256 threads: one scratch page (16 keys x D) of one sequence and KV head per
+// workgroup, moved as 16-byte pieces (8 head dims of one key). A d-major V (v0 layout: the 16 keys of a page are
+// contiguous per head dim) is read along the keys, 8 per load, and turned through LDS; reading it along d would be
+// eight 2-byte loads per piece.
 template <typename QT, typename KVT>
 __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   const mi355_attn_params& p = a.p;
-  const int pg = blockIdx.x, seq = blockIdx.y;
-  if (threadIdx.x == 0) a.bt_dst[(int64_t)seq * a.pages_per_seq + pg] = seq * a.pages_per_seq + pg;
+  const int pg = blockIdx.x, seq = blockIdx.y, h = blockIdx.z;
+  if (threadIdx.x == 0 && h == 0) a.bt_dst[(int64_t)seq * a.pages_per_seq + pg] = seq * a.pages_per_seq + pg;
   const int seq_len = p.seqused_k[seq];
   const int q_start = p.cu_seqlens_q[seq], q_len = p.cu_seqlens_q[seq + 1] - q_start;
   if (q_len <= 0 || (a.skip_single && q_len == 1)) return;
@@ -91,15 +108,33 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   const int ctx = seq_len - q_len;
   const bool use_new = p.k_new != nullptr && q_len > 1;   // generic_attn.hip: same rule
   const int D = p.head_size, Hk = p.num_kv_heads, chunks = D >> 3;
-  const int pieces = kRepackPage * Hk * chunks;
+  const int pieces = kRepackPage * chunks;
   const int64_t dst_page = ((int64_t)seq * a.pages_per_seq + pg) * kRepackPage * Hk * D;
   const uint16_t* kn = (const uint16_t*)p.k_new;
   const uint16_t* vn = (const uint16_t*)p.v_new;
   constexpr bool kFp8 = CachePiece<QT, KVT>::kFp8;
   const float k_scale = (kFp8 && p.k_scale) ? p.k_scale[0] : 1.0f;
   const float v_scale = (kFp8 && p.v_scale) ? p.v_scale[0] : 1.0f;
+
+  // V of a page that comes from the cache as a whole (no new-token rows in it), d-major source
+  __shared__ uint16_t vt[256][kRepackPage + 2];
+  const bool turn_v = a.v_keys_contiguous && !(use_new && j0 + kRepackPage > ctx);
+  if (turn_v) {
+    const int page = p.block_table[(int64_t)seq * p.block_table_stride + j0 / p.page_size];
+    const int o0 = j0 % p.page_size;
+    const int64_t vb = (int64_t)page * p.v_stride_page + (int64_t)h * p.v_stride_head + o0;
+    for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
+      const int d = idx >> 1, k0 = (idx & 1) * 8;
+      const uint4 w = CachePiece<QT, KVT>::load(p.v_cache, true, v_scale, [&](int i) { return vb + (int64_t)d * p.v_stride_d + k0 + i; });
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { vt[d][k0 + 2 * i] = (uint16_t)ww[i]; vt[d][k0 + 2 * i + 1] = (uint16_t)(ww[i] >> 16); }
+    }
+    __syncthreads();
+  }
+
   for (int idx = threadIdx.x; idx < pieces; idx += 256) {
-    const int c = idx % chunks, h = (idx / chunks) % Hk, slot = idx / (chunks * Hk);
+    const int c = idx % chunks, slot = idx / chunks;
     const int j = j0 + slot, d0 = 8 * c;
     uint4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};   // slots past the sequence end are zero-filled
     if (j < seq_len) {
@@ -116,12 +151,19 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
         const int page = p.block_table[(int64_t)seq * p.block_table_stride + j / p.page_size];
         const int o = j % p.page_size;
         const int64_t kb = (int64_t)page * p.k_stride_page + (int64_t)o * p.k_stride_slot + (int64_t)h * p.k_stride_head;
-        const int64_t vb = (int64_t)page * p.v_stride_page + (int64_t)o * p.v_stride_slot + (int64_t)h * p.v_stride_head;
         kk = CachePiece<QT, KVT>::load(p.k_cache, a.vec_k, k_scale, [&](int i) {
           const int d = d0 + i;
           return kb + (int64_t)(d / p.k_x) * p.k_stride_dx + (int64_t)(d % p.k_x) * p.k_stride_d;
         });
-        vv = CachePiece<QT, KVT>::load(p.v_cache, a.vec_v, v_scale, [&](int i) { return vb + (int64_t)(d0 + i) * p.v_stride_d; });
+        if (turn_v) {
+          uint16_t e[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) e[i] = vt[d0 + i][slot];
+          vv = pack8(e);
+        } else {
+          const int64_t vb = (int64_t)page * p.v_stride_page + (int64_t)o * p.v_stride_slot + (int64_t)h * p.v_stride_head;
+          vv = CachePiece<QT, KVT>::load(p.v_cache, a.vec_v, v_scale, [&](int i) { return vb + (int64_t)(d0 + i) * p.v_stride_d; });
+        }
       }
     }
     const int64_t dst = dst_page + ((int64_t)slot * Hk + h) * D + d0;
@@ -180,10 +222,14 @@ bool repack_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) || (p.kv_dtype != p.q_dtype && !is_fp8(p.kv_dtype))) return false;
   const bool flash = p.k_x == p.head_size && p.k_stride_d == 1 && p.v_stride_d == 1;
   if (!p.k_new && flash) return false;                       // nothing to repack: the kernels read that cache themselves
-  if (p.only_decodes || p.max_seqlen_q <= 1 || p.max_seqlen_k <= 0) return false;
+  if (p.only_decodes || p.max_seqlen_k <= 0) return false;
   if (p.head_size % 8 != 0 || p.page_size <= 0) return false;
   if (layout(p, 0).total > kRepackMaxBytes) return false;
-  return prefill_supported(repacked_params(p, nullptr, 0));
+  const mi355_attn_params r = repacked_params(p, nullptr, 0);
+  // a decode-only call is repacked only when the split-KV kernel cannot read the cache itself (fp8 or 4-D v0 caches:
+  // 1 + 2 + 2 bytes per element moved instead of 1, still several times faster than the shape-agnostic kernel)
+  if (p.max_seqlen_q <= 1) return !decode_supported(p) && decode_supported(r);
+  return prefill_supported(r);
 }
 
 size_t repack_scratch_bytes(const mi355_attn_params& p, size_t head) { return layout(p, head).total; }
@@ -208,7 +254,9 @@ int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool s
   a.vec_v = p.v_stride_d == 1 && aligned(p.v_cache);
   for (int64_t s : vs) a.vec_v = a.vec_v && s % 8 == 0;
   a.vec_new = p.k_new && aligned16(p.k_new) && aligned16(p.v_new) && p.new_stride_token % 8 == 0 && p.new_stride_head % 8 == 0;
-  dim3 grid(a.pages_per_seq, p.num_seqs);
+  a.v_keys_contiguous = p.v_stride_slot == 1 && p.v_stride_d % 8 == 0 && p.page_size % kRepackPage == 0 && p.head_size <= 256 && aligned(p.v_cache);
+  for (int64_t s : {p.v_stride_page, p.v_stride_head}) a.v_keys_contiguous = a.v_keys_contiguous && s % 8 == 0;
+  dim3 grid(a.pages_per_seq, p.num_seqs, p.num_kv_heads);
   const bool bf = p.q_dtype == MI355_BF16;
   if (p.kv_dtype == MI355_FP8_E4M3) {
     if (bf) hipLaunchKernelGGL((repack_kernel<bf16_t, e4m3_t>), grid, dim3(256), 0, stream, a);
