@@ -214,13 +214,13 @@ MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
  *       mixed batch                  -> both, prefill rows then decode rows ("<prefill kernel>+<decode kernel>", e.g. "prefill_mfma+decode_splitkv")
  *     the legacy v0 layout (16-bit, k_x == 8, head size 64/128/256) with max_seqlen_q == 1 -> the same split-KV decode
  *     kernel reading that layout directly ("decode_splitkv_v0" / "decode_single_v0")
- *     a 16-bit or fp8 cache in any layout the strides describe and/or linear k_new/v_new, max_seqlen_q > 1, max_seqlen_k a
- *     true bound (context_attention_fwd, chunked_prefill_paged_decode): every sequence's keys are first gathered into a
+ *     a 16-bit or fp8 cache in any layout the strides describe and/or linear k_new/v_new, max_seqlen_k a true bound
+ *     (context_attention_fwd, chunked_prefill_paged_decode; paged_attention_2d/3d over fp8 or 4-D v0 caches): every sequence's keys are first gathered into a
  *     flash-layout scratch cache in the workspace (num_seqs * ceil(max_seqlen_k / 16) pages of K and V), the kernels
  *     above run on that; query_len == 1 rows of a mixed batch read the caller's cache directly when the v0 decode
  *     kernel covers it ("repack+<prefill kernel>[+<decode kernel>]")
  *     (an fp8 cache is dequantised into the 16-bit scratch: (fp8 -> f32) * scale -> query type)
- *   everything else (f32, other head sizes, max_seqlen_q == 1 over fp8 or 4-D v0 caches) -> "generic".
+ *   everything else (f32, head sizes that are not a multiple of 8 or exceed 256, ...) -> "generic".
  */
 MI355_API int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);

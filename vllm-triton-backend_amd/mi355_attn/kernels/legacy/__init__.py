@@ -11,7 +11,7 @@ contiguous block of MFMA-shaped 16-byte pieces). `context_attention_fwd` and `ch
 or fp8 cache) gather each sequence's keys (context pages of either v0 form, new rows from the linear tensors) into a
 flash-layout scratch cache in the workspace and run the matrix-core prefill kernel on it ("repack+prefill_dma..."),
 decode rows of a mixed batch going straight to the v0 decode kernel when it covers the cache; `paged_attention_2d/3d`
-over fp8 or 4-D caches run on the shape-agnostic HIP kernel.
+over fp8 or 4-D caches take the same gather pass and then the split-KV kernel; fp32 runs on the shape-agnostic HIP kernel.
 """
 
 from __future__ import annotations
