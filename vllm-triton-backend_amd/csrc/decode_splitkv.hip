@@ -295,8 +295,16 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       const kv_elem_t* vp = vbase + ((uint64_t)(uint32_t)pg[h] * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
+#ifdef MI355_DECODE_PLAIN_LOADS
         KR[h][i] = *(const u32x4_t*)(kp + k_toff[i]);
         VR[h][i] = *(const u32x4_t*)(vp + v_toff[i]);
+#else
+        // every K/V byte is read once per call: streaming (nt) loads, which also keep the cache lines of the block
+        // table and the partials from being pushed out (a plain 2 GiB read stream reaches 6.2 TB/s on this chip,
+        // the same stream with nt loads 7.1: tools/probes/hbm_read.hip)
+        KR[h][i] = __builtin_nontemporal_load((const u32x4_t*)(kp + k_toff[i]));
+        VR[h][i] = __builtin_nontemporal_load((const u32x4_t*)(vp + v_toff[i]));
+#endif
       }
     }
   };

@@ -28,6 +28,19 @@ struct RepackArgs {
   int skip_single;             // sequences with query_len == 1 are not repacked (left out or served from the cache)
 };
 
+typedef __attribute__((ext_vector_type(4))) unsigned int ru32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int ru32x2_t;
+
+// cache pages are read once by this pass: streaming (nt) loads, see decode_splitkv.hip
+__device__ inline uint4 load16_stream(const void* ptr) {
+  const ru32x4_t v = __builtin_nontemporal_load((const ru32x4_t*)ptr);
+  return uint4{v.x, v.y, v.z, v.w};
+}
+__device__ inline uint2 load8_stream(const void* ptr) {
+  const ru32x2_t v = __builtin_nontemporal_load((const ru32x2_t*)ptr);
+  return uint2{v.x, v.y};
+}
+
 __device__ inline uint4 pack8(const uint16_t (&e)[8]) {
   return uint4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
                (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
@@ -52,14 +65,14 @@ struct CachePiece {
     uint16_t e[8];
     if constexpr (!kFp8) {
       const uint16_t* c = (const uint16_t*)cache;
-      if (vec) return *(const uint4*)(c + off(0));
+      if (vec) return load16_stream(c + off(0));
 #pragma unroll
       for (int i = 0; i < 8; ++i) e[i] = c[off(i)];
     } else {
       const uint8_t* c = (const uint8_t*)cache;
       uint2 w;
       if (vec) {
-        w = *(const uint2*)(c + off(0));
+        w = load8_stream(c + off(0));
       } else {
         w = uint2{0u, 0u};
 #pragma unroll
