@@ -701,9 +701,14 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
     want = p.num_segments;
   } else {
     const long base = std::max(1L, decode_units(p) * p.num_kv_heads);  // waves with one split each
-    // One wave per resident slot (8 waves/CU x 256 CUs): a second round of waves only adds partials and a tail
-    // (sweep at the C3 shape, 8192 keys: batch 64 -> 4 splits 367 us vs 8 splits 378; batch 128 -> 2 vs 4: 697 vs 711).
-    const long target = 256L * 8;
+    // Work items in flight. With streaming loads a 16-bit cache runs best with 4 per CU: more only add partials and
+    // a tail (8192 keys: batch 64 -> 2 splits 322 us, 4 splits 332, 8 splits 344; batch 16 -> 8 splits 90, 16: 95;
+    // batch 4 at 32768 keys: 92 vs 94). The fp8 kernel spends its time widening, not waiting: it wants 8 per CU
+    // (batch 64: 204 us vs 261 with half of them; 16 x 32768 keys, Hq 64: 211 vs 474).
+    // MI355_DECODE_TARGET_WAVES overrides the number for sweeps (tools/bench_decode.py).
+    static const long target_env = [] { const char* e = getenv("MI355_DECODE_TARGET_WAVES"); return e ? atol(e) : 0L; }();
+    const bool fp8_kv = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
+    const long target = target_env > 0 ? target_env : 256L * (fp8_kv ? 8 : 4);
     want = (int)((target + base - 1) / base);
     // The in-kernel merge (one launch instead of two) serves up to `one_trip` splits: take it while that still gives
     // every second slot a wave (batch 16: 8 splits 100 us, 16 splits 103, 32 splits 107).
