@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kvdtype", default="same", choices=["same", "fp8", "fp8_e5m2"])
     ap.add_argument("--legacy", action="store_true", help="context_attention_fwd: v0 cache layout for the first --ctx keys, the rest from linear k/v")
-    ap.add_argument("--ctx", type=int, default=0, help="with --legacy: context keys per sequence (query length = seq - ctx)")
+    ap.add_argument("--ctx", type=int, default=0, help="context keys per sequence already in the cache (query length = seq - ctx)")
     ap.add_argument("--generic", action="store_true", help="with --legacy: force the shape-agnostic kernel (the path before the repack)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -46,6 +46,13 @@ def main():
     out = torch.empty_like(q)
     flops = 4 * L * L * args.d * args.hq / 2 * B
     p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, None)
+    if args.ctx and not args.legacy:     # chunked prefill through unified_attention: the last seq - ctx tokens are the queries
+        QL = L - args.ctx
+        q = q[: B * QL].contiguous()
+        out = torch.empty_like(q)
+        cu = (torch.arange(B + 1, dtype=torch.int32, device=dev) * QL).to(torch.int32)
+        flops = 4 * args.d * args.hq * (QL * args.ctx + QL * (QL + 1) / 2) * B
+        p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, QL, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, None)
     if args.legacy:
         QL = L - args.ctx
         q = q[: B * QL].contiguous()

@@ -150,7 +150,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   constexpr bool FP8 = !__is_same(T, KVT);
   // tiles in flight HBM -> VGPR per wave: an fp8 tile is half the bytes of a 16-bit one, so two of
   // them are kept in flight to put the same number of bytes on the wire per CU
+#ifdef MI355_DECODE_PF
+  constexpr int PF = MI355_DECODE_PF;
+#else
   constexpr int PF = (FP8 && D <= 128) ? 2 : 1;
+#endif
   constexpr int KVB = FP8 ? 1 : 2;                  // bytes per cache element
   constexpr int PPR = D * KVB / 16;                 // 16-byte pieces per key row in HBM
   constexpr int NLD = (16 * PPR) / 64;              // row-shaped loads per 16-key group per lane
