@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--hq", type=int, default=32)
     ap.add_argument("--hk", type=int, default=8)
     ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--segments", type=int, nargs="+", default=[0], help="forced split counts (0 = the library's plan)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt, page = torch.bfloat16, 16
@@ -58,38 +59,40 @@ def main():
             cu = torch.arange(B + 1, dtype=torch.int32, device=dev)
             sl = torch.full((B,), L, dtype=torch.int32, device=dev)
             out = torch.empty_like(q)
-            p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, 1, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, None, None, None, None)
-            for _ in range(20):
-                ua_mod.launch(p, dev)
-            torch.cuda.synchronize()
-            n = 200
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(n):
-                ua_mod.launch(p, dev)
-            e1.record()
-            torch.cuda.synchronize()
-            stream_us = e0.elapsed_time(e1) * 1e3 / n
-            g = torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream()
-            with torch.cuda.stream(s):
-                ua_mod.launch(p, dev)
-                torch.cuda.synchronize()
-                with torch.cuda.graph(g, stream=s):
-                    for _ in range(50):
-                        ua_mod.launch(p, dev)
-            for _ in range(3):
-                g.replay()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(10):
-                g.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            graph_us = e0.elapsed_time(e1) * 1e3 / 500
-            nbytes = 2 * B * L * args.hk * args.d * 2
-            print(f"B={B} kv={L:6d} kernel={_lib.last_kernel():16s} stream {stream_us:7.1f} us/call   graph {graph_us:7.1f} us/call   "
-                  f"({nbytes / graph_us / 1e3:7.1f} GB/s)", flush=True)
+            for seg in args.segments:
+              p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, 1, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, None, None, None, None,
+                                                num_segments=seg)
+              for _ in range(20):
+                  ua_mod.launch(p, dev)
+              torch.cuda.synchronize()
+              n = 200
+              e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+              e0.record()
+              for _ in range(n):
+                  ua_mod.launch(p, dev)
+              e1.record()
+              torch.cuda.synchronize()
+              stream_us = e0.elapsed_time(e1) * 1e3 / n
+              g = torch.cuda.CUDAGraph()
+              s = torch.cuda.Stream()
+              with torch.cuda.stream(s):
+                  ua_mod.launch(p, dev)
+                  torch.cuda.synchronize()
+                  with torch.cuda.graph(g, stream=s):
+                      for _ in range(50):
+                          ua_mod.launch(p, dev)
+              for _ in range(3):
+                  g.replay()
+              torch.cuda.synchronize()
+              e0.record()
+              for _ in range(10):
+                  g.replay()
+              e1.record()
+              torch.cuda.synchronize()
+              graph_us = e0.elapsed_time(e1) * 1e3 / 500
+              nbytes = 2 * B * L * args.hk * args.d * 2
+              print(f"B={B} kv={L:6d} seg={seg:2d} kernel={_lib.last_kernel():16s} stream {stream_us:7.1f} us/call   graph {graph_us:7.1f} us/call   "
+                    f"({nbytes / graph_us / 1e3:7.1f} GB/s)", flush=True)
 
 
 if __name__ == "__main__":

@@ -47,7 +47,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 constexpr int kTileKeys = 32;
-constexpr int kMaxSplits = 64;
+constexpr int kMaxSplits = 128;
 constexpr int kSlotPad = 32;   // floats appended to a D-float partial (m, l, padding to a 128-byte multiple)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -587,11 +587,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 // 256-thread workgroup per (unit, query head): thread (r, col) owns the 16-byte column chunk `col`
 // of split rows r, r + R, ...; all of a thread's loads are issued before the first is consumed, so
 // the kernel is ONE memory round trip however many splits there are, then an LDS fold of R rows.
-template <typename T, bool FP8, int D>
+// MAXS = the split count the instantiation covers (32 / 64 / 128): a launch with few splits does not pay for the loads
+// of many.
+template <typename T, bool FP8, int D, int MAXS>
 __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) {
   constexpr int LPS = D / 4;               // lanes per split row (16, 32 or 64)
   constexpr int R = 256 / LPS;             // split rows per pass
-  constexpr int NI = kMaxSplits / R;       // passes
+  constexpr int NI = MAXS / R;             // passes
+  static_assert(MAXS % R == 0 && MAXS <= kMaxSplits, "split rows come in whole passes");
   constexpr int SLOT = D + kSlotPad;
   __shared__ __attribute__((aligned(16))) float red[R][D + 4];   // folded columns, then (m, l)
 
@@ -714,13 +717,10 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
     const bool fp8_kv = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
     const long target = target_env > 0 ? target_env : 256L * (fp8_kv ? 8 : 4);
     want = (int)((target + base - 1) / base);
-    // The in-kernel merge (one launch instead of two) serves up to `one_trip` splits: take it while that still gives
-    // every second slot a wave (batch 16: 8 splits 100 us, 16 splits 103, 32 splits 107).
-    const int G = p.num_q_heads / p.num_kv_heads, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));
-    const int dpad = padded_head_size(p.head_size, p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2);
-    const int one_trip = (16 / std::min(Gp, 16)) * (dpad >= 128 ? 2 : 4);
-    if (want > one_trip && base * one_trip >= target / 2) want = one_trip;
-    want = std::min(want, std::max(1, max_tiles / 4));                  // keep each split >= 4 tiles (128 keys)
+    // No floor on the tiles per split and no preference for the in-kernel merge's split count: one wave walks its
+    // tiles one memory round trip (~1.3 us) at a time, so below the target the extra items win even when they cost
+    // the second launch (graph replay, 8192 keys: batch 8 -> 8 splits merged in the kernel 54 us, 16 splits + reduce
+    // launch 45; batch 1 at 512 / 2048 keys: 12.4 -> 7.5 us / 12.0 -> 7.8 us with one tile per split).
   }
   want = std::max(1, std::min(want, std::min(max_tiles, kMaxSplits)));
   const int tps = (max_tiles + want - 1) / want;
@@ -798,7 +798,10 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
   if (rc != MI355_OK) return rc;
   if (sp.num_splits > 1 && !a.fused_merge) {
-    hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D>), dim3((unsigned)units, p.num_q_heads), dim3(256), 0, stream, a);
+    const dim3 rgrid((unsigned)units, p.num_q_heads);
+    if (sp.num_splits <= 32) hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 32>), rgrid, dim3(256), 0, stream, a);
+    else if (sp.num_splits <= 64) hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 64>), rgrid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 128>), rgrid, dim3(256), 0, stream, a);
     rc = check_hip(hipGetLastError(), "reduce_splits_kernel launch");
   }
   if (rc == MI355_OK)
