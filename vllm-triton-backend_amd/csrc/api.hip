@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 void set_kernel_name(const char* name) { g_kernel = name; }
+const char* mi355_last_kernel_name() { return g_kernel; }
 
 static bool is_q_dtype(int d) { return d == MI355_F32 || d == MI355_F16 || d == MI355_BF16; }
 static bool is_fp8(int d) { return d == MI355_FP8_E4M3 || d == MI355_FP8_E5M2; }
@@ -83,10 +84,13 @@ static Path choose(const mi355_attn_params& p) {
 static size_t plain_workspace_bytes(const mi355_attn_params& p) {
   switch (choose(p)) {
     case Path::Decode: return decode_workspace_bytes(p);
-    case Path::PrefillPlusDecode: {
-      mi355_attn_params pd = p;
+    case Path::Prefill: return prefill_workspace_bytes(p);
+    case Path::PrefillPlusDecode: {          // the two run one after the other on the stream and share the bytes
+      mi355_attn_params pp = p, pd = p;
+      pp.skip_decodes = 1;
       pd.only_decodes = 1;
-      return decode_workspace_bytes(pd);
+      const size_t a = prefill_workspace_bytes(pp), b = decode_workspace_bytes(pd);
+      return a > b ? a : b;
     }
     default: return 0;
   }
@@ -98,13 +102,14 @@ static int dispatch_plain(const mi355_attn_params& p, void* workspace, size_t wo
     case Path::Decode:
       return launch_decode(p, workspace, workspace_bytes, s);
     case Path::Prefill:
-      return launch_prefill(p, s);
+      return launch_prefill_ws(p, workspace, workspace_bytes, s);
     case Path::PrefillPlusDecode: {
       mi355_attn_params pp = p, pd = p;
       pp.skip_decodes = 1;
       pd.only_decodes = 1;
-      rc = launch_prefill(pp, s);
-      const char* prefill_name = g_kernel;
+      rc = launch_prefill_ws(pp, workspace, workspace_bytes, s);
+      static thread_local char prefill_name[64];
+      snprintf(prefill_name, sizeof(prefill_name), "%s", g_kernel);
       if (rc == MI355_OK) rc = launch_decode(pd, workspace, workspace_bytes, s);
       if (rc == MI355_OK) {                      // "<prefill kernel>+<decode kernel>"
         static thread_local char both[96];

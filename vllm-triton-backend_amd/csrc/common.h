@@ -300,6 +300,9 @@ int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStre
 
 bool prefill_supported(const mi355_attn_params& p);
 int launch_prefill(const mi355_attn_params& p, hipStream_t stream);
+size_t prefill_workspace_bytes(const mi355_attn_params& p);                                   // key-split partials, 0 if none
+int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream);
+const char* mi355_last_kernel_name();
 // legacy layouts / linear new-token source -> flash-layout scratch cache (repack.hip)
 bool repack_supported(const mi355_attn_params& p);
 size_t repack_scratch_bytes(const mi355_attn_params& p, size_t head);

@@ -50,6 +50,11 @@ struct PrefillArgs {
   int page_shift; // log2(page_size)
   int d_valid;    // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
   int kv_same_strides;  // K and V cache strides are equal (two views of one tensor)
+  // key-split launch of prefill_mfma_kernel (grid.y = key_splits): workgroup (x, s) attends key tiles
+  // [s * tiles_per_key_split, (s + 1) * tiles_per_key_split) only and writes its normalised output and lse to the
+  // partial buffers p.out + s * out_split_stride / p.lse + s * lse_split_stride; merge_key_splits_kernel folds them
+  int key_splits, tiles_per_key_split;
+  int64_t out_split_stride, lse_split_stride;
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
 };
 
@@ -154,8 +159,17 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   const bool wave_has_rows = w_tok_lo <= w_tok_hi;
   int first_key_wg = 0;
   if (FEAT && p.sliding_window > 0) first_key_wg = max(0, ctx_len + tok0 - p.sliding_window + 1);
-  const int tile_lo = first_key_wg / kTileN;
-  const int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
+  int tile_lo = first_key_wg / kTileN;
+  int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
+  // key-split launch: this workgroup's share of the key tiles (possibly empty: it then writes 0 / -inf, which the merge
+  // weighs with 0). Masks are functions of absolute positions, so nothing else changes.
+  const int ksplit = a.key_splits > 1 ? (int)blockIdx.y : 0;
+  if (a.key_splits > 1) {
+    tile_lo = max(tile_lo, ksplit * a.tiles_per_key_split);
+    tile_hi = min(tile_hi, (ksplit + 1) * a.tiles_per_key_split);
+  }
+  uint16_t* const out_base = (uint16_t*)p.out + (int64_t)ksplit * a.out_split_stride;
+  float* const lse_base = p.lse ? p.lse + (int64_t)ksplit * a.lse_split_stride : nullptr;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane (qr, half) holds Q[row][16ks + 8half .. +7] ----
   ps16x8_t qf[KSTEPS];
@@ -444,12 +458,12 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
 
   // ---- epilogue: O = O^T / l, lane (qr, half) register r of block b <-> d = 32b + (r&3) + 8(r>>2) + 4half
   l_run += lane_xor32(l_run);
-  if (p.lse && row_ok && half == 0)    // m_run: row max of the scaled scores in the log2 domain
-    p.lse[(int64_t)(q_start + tok_local) * p.lse_stride_token + hq] = l_run > 0.0f ? (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f : -INFINITY;
+  if (lse_base && row_ok && half == 0)    // m_run: row max of the scaled scores in the log2 domain
+    lse_base[(int64_t)(q_start + tok_local) * p.lse_stride_token + hq] = l_run > 0.0f ? (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f : -INFINITY;
   const float inv = (row_ok && l_run > 0.0f) ? v_scale / l_run : 0.0f;
   // O leaves through LDS as whole rows, 16 bytes per lane, nontemporal (see prefill_dma_kernel's epilogue); the
   // 8-byte pieces of the accumulator layout go out directly only when the output rows are not 16-byte aligned.
-  const bool wide_store = (((uintptr_t)p.out & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
+  const bool wide_store = (((uintptr_t)out_base & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
   if (wide_store) {
     constexpr int ORS = D * 2 + 16;                      // padded row stride of the parked rows
     constexpr int CPR = D / 8, RPI = 64 / CPR;           // 16-byte chunks per row, rows per store instruction
@@ -471,11 +485,11 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
       const int tok = tok0 + m / G;
       const pu32x4_t v = *(const pu32x4_t*)(ost + r * ORS + och * 16);
       if (m < BQ * G && tok < q_len && och * 8 < a.d_valid)
-        __builtin_nontemporal_store(v, (pu32x4_t*)((uint16_t*)p.out + (int64_t)(q_start + tok) * p.out_stride_token +
+        __builtin_nontemporal_store(v, (pu32x4_t*)(out_base + (int64_t)(q_start + tok) * p.out_stride_token +
                                                    (int64_t)(head * G + m % G) * p.out_stride_head + och * 8));
     }
   } else if (row_ok) {
-    uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
+    uint16_t* op = out_base + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
 #pragma unroll
@@ -1073,6 +1087,113 @@ bool prefill_supported(const mi355_attn_params& p) {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Key-split prefill: few Q blocks over a long context (one sequence's 512-token chunk against 8k keys gives 128
+// workgroups for 256 CUs, each walking 128 tiles). The key tiles are then dealt to `splits` workgroups per Q block
+// (grid.y), each writes a normalised partial output (query type) and its lse (f32) to the workspace, and
+// merge_key_splits_kernel folds them: out = sum_s out_s * exp(lse_s - lse), lse = log sum_s exp(lse_s) - the merge
+// of reduce_segments (:804-828) on normalised partials. Served by the register-staged kernel (any feature set,
+// fp8 KV, head sizes 64..256), chosen from host-known sizes only.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxKeySplits = 8;
+constexpr size_t kWsCounterBytes = (size_t)256 << 10;   // head of every workspace: the decode kernels' counters
+
+struct KeySplitPlan { int splits, tiles_per_split; };
+
+static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
+  static const char* env = getenv("MI355_PREFILL_KEY_SPLITS");   // measurements: force a split count (1 = never split)
+  const int G = p.num_q_heads / p.num_kv_heads, block_q = kBlockM / G;
+  const long wgs = ((long)p.num_tokens / block_q + p.num_seqs) * p.num_kv_heads;
+  const int tiles = (std::max(p.max_seqlen_k, 1) + kTileN - 1) / kTileN;
+  int splits = 1;
+  if (env) splits = atoi(env);
+  else if (wgs < 256 && tiles >= 32) splits = (int)std::min<long>(512 / wgs, tiles / 8);   // two workgroups per CU, >= 8 tiles each
+  splits = std::max(1, std::min(std::min(splits, kMaxKeySplits), tiles));
+  const int tps = (tiles + splits - 1) / splits;
+  return {(tiles + tps - 1) / tps, tps};
+}
+
+struct KeySplitLayout { size_t out_off, lse_off, total; int64_t out_split_stride, lse_split_stride; };
+static KeySplitLayout key_split_layout(const mi355_attn_params& p, int splits) {
+  KeySplitLayout l;
+  l.out_split_stride = (int64_t)p.num_tokens * p.num_q_heads * p.head_size;   // elements
+  l.lse_split_stride = (int64_t)p.num_tokens * p.num_q_heads;
+  l.out_off = kWsCounterBytes;
+  l.lse_off = l.out_off + (((size_t)splits * l.out_split_stride * 2 + 255) & ~(size_t)255);
+  l.total = l.lse_off + (size_t)splits * l.lse_split_stride * sizeof(float);
+  return l;
+}
+
+size_t prefill_workspace_bytes(const mi355_attn_params& p) {
+  if (!prefill_supported(p)) return 0;
+  const int splits = plan_key_splits(p).splits;
+  return splits > 1 ? key_split_layout(p, splits).total : 0;
+}
+
+struct MergeArgs {
+  mi355_attn_params p;          // out / lse / strides of the caller
+  const uint16_t* part_out;     // [splits][T][Hq][D]
+  const float* part_lse;        // [splits][T][Hq]
+  int splits;
+};
+
+// one thread per 8 output elements of one (token, query head) row
+template <typename T>
+__global__ __launch_bounds__(256) void merge_key_splits_kernel(const MergeArgs a) {
+  const mi355_attn_params& p = a.p;
+  const int chunks = p.head_size >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t rows = (int64_t)p.num_tokens * p.num_q_heads;
+  if (idx >= rows * chunks) return;
+  const int64_t row = idx / chunks;
+  const int c = (int)(idx % chunks);
+  const int64_t tok = row / p.num_q_heads;
+  const int hq = (int)(row % p.num_q_heads);
+  if (tok >= p.cu_seqlens_q[p.num_seqs]) return;   // padding tokens past the last sequence belong to nobody
+  if (p.skip_decodes) {      // rows of query_len == 1 sequences were not computed and must stay untouched
+    const int seq = find_seq_by_token(p.cu_seqlens_q, p.num_seqs, (int)tok);
+    if (p.cu_seqlens_q[seq + 1] - p.cu_seqlens_q[seq] == 1) return;
+  }
+  float lse[kMaxKeySplits], m = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < kMaxKeySplits; ++s) {
+    lse[s] = s < a.splits ? a.part_lse[(int64_t)s * rows + row] : -INFINITY;
+    m = fmaxf(m, lse[s]);
+  }
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, den = 0.0f;
+#pragma unroll
+  for (int s = 0; s < kMaxKeySplits; ++s) {
+    if (s < a.splits && lse[s] > -INFINITY) {
+      const float w = __expf(lse[s] - m);
+      den += w;
+      const pu32x4_t v = *(const pu32x4_t*)(a.part_out + ((int64_t)s * rows + row) * p.head_size + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo, hi;
+        if constexpr (__is_same(T, bf16_t)) { lo = bf16_to_f32((uint16_t)(v[e] & 0xffff)); hi = bf16_to_f32((uint16_t)(v[e] >> 16)); }
+        else { lo = f16_to_f32((uint16_t)(v[e] & 0xffff)); hi = f16_to_f32((uint16_t)(v[e] >> 16)); }
+        acc[2 * e] += w * lo;
+        acc[2 * e + 1] += w * hi;
+      }
+    }
+  }
+  const float inv = den > 0.0f ? 1.0f / den : 0.0f;        // a row no split saw a key for: 0 (and lse -inf)
+  pu32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pmma<T>::pack2(acc[2 * e] * inv, acc[2 * e + 1] * inv);
+  uint16_t* op = (uint16_t*)p.out + tok * p.out_stride_token + (int64_t)hq * p.out_stride_head + 8 * c;
+  if ((((uintptr_t)op) & 15) == 0) {
+    *(pu32x4_t*)op = o;
+  } else {                                                  // out is 8-byte aligned at least (prefill_supported)
+    *(pu32x2_t*)op = pu32x2_t{o[0], o[1]};
+    *(pu32x2_t*)(op + 4) = pu32x2_t{o[2], o[3]};
+  }
+  if (p.lse && c == 0) p.lse[tok * p.lse_stride_token + hq] = den > 0.0f ? m + __logf(den) : -INFINITY;
+}
+
+static thread_local const KeySplitPlan* g_key_split = nullptr;          // set around the split launch below
+static thread_local const KeySplitLayout* g_key_split_layout = nullptr;
+
 // cache element type as a function of the query type
 template <typename T> using kv_same = T;
 template <typename T> using kv_e4m3 = e4m3_t;
@@ -1090,6 +1211,10 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;  // static upper bound (:886-889,:935-943)
+  a.key_splits = g_key_split ? g_key_split->splits : 1;
+  a.tiles_per_key_split = g_key_split ? g_key_split->tiles_per_split : 0;
+  a.out_split_stride = g_key_split ? g_key_split_layout->out_split_stride : 0;
+  a.lse_split_stride = g_key_split ? g_key_split_layout->lse_split_stride : 0;
   constexpr size_t lds = 2 * (size_t)kTileN * ((D * 2 + 16) + (D * 2 + 64));
   static bool attr_set = false;   // >64 KiB of dynamic LDS needs an opt-in, once per kernel
   if (!attr_set) {
@@ -1098,7 +1223,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
     if (rc0 != MI355_OK) return rc0;
     attr_set = true;
   }
-  hipLaunchKernelGGL((prefill_mfma_kernel<T, KVT, D, FEAT>), dim3(qblocks * p.num_kv_heads), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((prefill_mfma_kernel<T, KVT, D, FEAT>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(256), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_mfma_kernel launch");
   if (rc == MI355_OK) set_kernel_name(!__is_same(T, KVT) ? (FEAT ? "prefill_mfma_fp8_feat" : "prefill_mfma_fp8") : (FEAT ? "prefill_mfma_feat" : "prefill_mfma"));
   return rc;
@@ -1123,6 +1248,7 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
+  a.key_splits = 1; a.tiles_per_key_split = 0; a.out_split_stride = a.lse_split_stride = 0;
   size_t lds = (size_t)NST * 2 * kTileN * 256;   // NST stages of K + V tiles, unpadded
   if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix (the caller checked that it fits)
   static bool attr_set = false;
@@ -1148,7 +1274,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), w64 (64 rows/wave, one wave per SIMD); default = LDS-DMA, 32 rows/wave
   static const char* variant = getenv("MI355_PREFILL");
-  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', w64 = variant && variant[0] == 'w';
+  const bool v1 = (variant && variant[0] == 'v' && variant[1] == '1') || g_key_split != nullptr, w64 = !g_key_split && variant && variant[0] == 'w';
   if (w64 && prefill_w64_applicable(p) && !p.lse) return launch_prefill_w64(p, stream);   // the experimental kernel has no lse output
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
@@ -1189,6 +1315,49 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
 #undef MI355_PREFILL_CASE
   set_error("prefill: head_size %d not built", p.head_size);
   return MI355_ERR_UNSUPPORTED;
+}
+
+// Prefill with the caller's workspace at hand: key-split launch + merge when the plan says so, the plain launch otherwise.
+int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!prefill_supported(p)) {
+    set_error("prefill kernel does not support this configuration");
+    return MI355_ERR_UNSUPPORTED;
+  }
+  const KeySplitPlan plan = plan_key_splits(p);
+  if (plan.splits <= 1) return launch_prefill(p, stream);
+  const KeySplitLayout lay = key_split_layout(p, plan.splits);
+  if (!ws || ws_bytes < lay.total) {
+    set_error("workspace of %zu bytes is smaller than the %zu the key-split prefill needs (mi355_attn_workspace_bytes)", ws_bytes, lay.total);
+    return MI355_ERR_WORKSPACE;
+  }
+  mi355_attn_params pp = p;                         // partial outputs: contiguous [T, Hq, D] / [T, Hq] per split
+  pp.out = (char*)ws + lay.out_off;
+  pp.out_stride_token = (int64_t)p.num_q_heads * p.head_size;
+  pp.out_stride_head = p.head_size;
+  pp.lse = (float*)((char*)ws + lay.lse_off);
+  pp.lse_stride_token = p.num_q_heads;
+  g_key_split = &plan;
+  g_key_split_layout = &lay;
+  int rc = launch_prefill(pp, stream);
+  g_key_split = nullptr;
+  g_key_split_layout = nullptr;
+  if (rc != MI355_OK) return rc;
+  MergeArgs m;
+  m.p = p;
+  m.part_out = (const uint16_t*)((char*)ws + lay.out_off);
+  m.part_lse = (const float*)((char*)ws + lay.lse_off);
+  m.splits = plan.splits;
+  const int64_t work = (int64_t)p.num_tokens * p.num_q_heads * (p.head_size / 8);
+  const dim3 grid((unsigned)((work + 255) / 256));
+  if (p.q_dtype == MI355_BF16) hipLaunchKernelGGL(merge_key_splits_kernel<bf16_t>, grid, dim3(256), 0, stream, m);
+  else hipLaunchKernelGGL(merge_key_splits_kernel<f16_t>, grid, dim3(256), 0, stream, m);
+  rc = check_hip(hipGetLastError(), "merge_key_splits_kernel launch");
+  if (rc == MI355_OK) {
+    static thread_local char name[64];
+    snprintf(name, sizeof(name), "%s_ksplit", mi355_last_kernel_name());
+    set_kernel_name(name);
+  }
+  return rc;
 }
 
 }  // namespace mi355
