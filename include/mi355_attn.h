@@ -187,7 +187,8 @@ MI355_API const char* mi355_last_kernel(void);
 /*
  * Bytes of scratch mi355_unified_attention needs for these parameters (host-side arithmetic only;
  * depends on sizes and upper bounds, never on device data, so it is capture-stable).
- * Replaces the three per-call torch.empty scratch tensors at triton_unified_attention.py:950-971.
+ * Replaces the three per-call torch.empty scratch tensors at triton_unified_attention.py:950-971
+ * (decode partials; here also the partials of a key-split prefill and the scratch cache of the repack path).
  * The workspace must be ZERO-FILLED ONCE by its owner after allocation: its first 256 KiB hold the
  * arrival counters of the in-kernel split merge, which every call leaves at zero again (a call
  * that was aborted mid-kernel does not: zero-fill again after a device error). One workspace
@@ -210,7 +211,9 @@ MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
  *     scales, page size a power of two >= 16, head size any multiple of 8 (16 with an fp8 cache) up to 256 (run on
  *     the next of 64/128/256; the reference pads to the next power of two, :353,:912; fp8 prefill up to 128):
  *       max_seqlen_q == 1            -> split-KV decode ("decode_splitkv[_fp8]" / "decode_single[_fp8]")
- *       every sequence a prefill     -> Q-block prefill ("prefill_mfma[_fp8][_feat]")
+ *       every sequence a prefill     -> Q-block prefill ("prefill_mfma[_fp8][_feat]"; "..._ksplit" when few Q blocks
+ *                                       face a long context: key tiles dealt to several workgroups, partials merged
+ *                                       by lse through the workspace)
  *       mixed batch                  -> both, prefill rows then decode rows ("<prefill kernel>+<decode kernel>", e.g. "prefill_mfma+decode_splitkv")
  *     the legacy v0 layout (16-bit, k_x == 8, head size 64/128/256) with max_seqlen_q == 1 -> the same split-KV decode
  *     kernel reading that layout directly ("decode_splitkv_v0" / "decode_single_v0")
