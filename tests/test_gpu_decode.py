@@ -229,10 +229,11 @@ def test_mixed_batch_splits_into_prefill_and_decode_launches():
                                        inp["scale"], mode="2d", block_n=64)
     d = gpu_util.to_dev(inp)
     out, kernel = gpu_util.run_unified(d, inp["scale"])
-    assert kernel in ("prefill_mfma+decode_splitkv", "prefill_mfma+decode_single"), kernel
+    # (the prefill half may be the key-split launch: few Q blocks, and the longest sequence of the batch has 2048 keys)
+    assert kernel in ("prefill_mfma+decode_splitkv", "prefill_mfma+decode_single", "prefill_mfma_ksplit+decode_splitkv"), kernel
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
     # and the single-kernel 2D path gives the same answer
     out2, kernel2 = gpu_util.run_unified(d, inp["scale"], force=2)
-    assert kernel2 == "prefill_mfma"
+    assert kernel2.startswith("prefill_mfma") and "+" not in kernel2, kernel2
     torch.testing.assert_close(out2.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)

@@ -50,8 +50,8 @@ struct PrefillArgs {
   int page_shift; // log2(page_size)
   int d_valid;    // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
   int kv_same_strides;  // K and V cache strides are equal (two views of one tensor)
-  // key-split launch of prefill_mfma_kernel (grid.y = key_splits): workgroup (x, s) attends key tiles
-  // [s * tiles_per_key_split, (s + 1) * tiles_per_key_split) only and writes its normalised output and lse to the
+  // key-split launch of prefill_mfma_kernel (grid.y = key_splits): workgroup (x, s) attends the s-th of key_splits
+  // even shares of its Q block's key tiles only and writes its normalised output and lse to the
   // partial buffers p.out + s * out_split_stride / p.lse + s * lse_split_stride; merge_key_splits_kernel folds them
   int key_splits, tiles_per_key_split;
   int64_t out_split_stride, lse_split_stride;
@@ -164,9 +164,10 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   // key-split launch: this workgroup's share of the key tiles (possibly empty: it then writes 0 / -inf, which the merge
   // weighs with 0). Masks are functions of absolute positions, so nothing else changes.
   const int ksplit = a.key_splits > 1 ? (int)blockIdx.y : 0;
-  if (a.key_splits > 1) {
-    tile_lo = max(tile_lo, ksplit * a.tiles_per_key_split);
-    tile_hi = min(tile_hi, (ksplit + 1) * a.tiles_per_key_split);
+  if (a.key_splits > 1) {     // an even share of THIS Q block's tiles (the host only knows the longest sequence)
+    const int tps = (max(tile_hi - tile_lo, 0) + a.key_splits - 1) / a.key_splits;
+    tile_lo = min(tile_lo + ksplit * tps, tile_hi);
+    tile_hi = min(tile_hi, tile_lo + tps);
   }
   uint16_t* const out_base = (uint16_t*)p.out + (int64_t)ksplit * a.out_split_stride;
   float* const lse_base = p.lse ? p.lse + (int64_t)ksplit * a.lse_split_stride : nullptr;
