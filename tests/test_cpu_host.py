@@ -107,6 +107,54 @@ def test_workspace_bytes_is_host_arithmetic(lib):
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0          # generic kernel needs none
 
 
+def _c3_like_params(lib, addr):
+    p = lib.AttnParams()
+    for f in ("q", "out", "k_cache", "v_cache", "block_table", "cu_seqlens_q", "seqused_k"):
+        setattr(p, f, addr)
+    p.q_dtype = p.kv_dtype = lib.BF16
+    p.num_q_heads, p.num_kv_heads, p.head_size, p.page_size = 32, 8, 128, 16
+    p.q_stride_token, p.q_stride_head, p.out_stride_token, p.out_stride_head = 4096, 128, 4096, 128
+    p.k_stride_page, p.k_stride_slot, p.k_stride_head, p.k_stride_d, p.k_x = 16384, 1024, 128, 1, 128
+    p.v_stride_page, p.v_stride_slot, p.v_stride_head, p.v_stride_d = 16384, 1024, 128, 1
+    p.block_table_stride = 2048
+    return p
+
+
+def test_workspace_bytes_of_the_prefill_paths(lib):
+    """Host arithmetic of the two prefill cases that need scratch: the key-split launch (few Q blocks, long context)
+    and the repack pass of the legacy ops (v0 layout / linear new-token K/V)."""
+    h = lib.load()
+    buf = np.zeros(64, dtype=np.uint8)
+    addr = (buf.ctypes.data + 15) & ~15
+    counters = 256 << 10
+    # C2: one 4096-token prefill fills the chip by itself -> no scratch
+    p = _c3_like_params(lib, addr)
+    p.num_tokens, p.num_seqs, p.max_seqlen_q, p.max_seqlen_k = 4096, 1, 4096, 4096
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+    # a 512-token chunk against 8192 keys: (512/32 + 1) * 8 = 136 workgroups -> 4 key splits of partial out (bf16) + lse (f32)
+    p.num_tokens, p.max_seqlen_q, p.max_seqlen_k = 512, 512, 8192
+    n = h.mi355_attn_workspace_bytes(C.byref(p))
+    rows = 512 * 32
+    assert n == counters + 4 * rows * 128 * 2 + 4 * rows * 4
+    # the same chunk with short contexts only: no split
+    p.max_seqlen_k = 1024
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+    # legacy op: v0 layout (K [nb, Hk, D/8, 16, 8], V [nb, Hk, D, 16]) + linear new keys, 2 sequences, bound 4096 keys:
+    # counters, identity block table, K and V scratch of 2 * 256 pages
+    p = _c3_like_params(lib, addr)
+    p.num_tokens, p.num_seqs, p.max_seqlen_q, p.max_seqlen_k = 4096, 2, 2048, 4096
+    p.k_new = p.v_new = addr
+    p.new_stride_token, p.new_stride_head = 1024, 128
+    p.k_x, p.k_stride_page, p.k_stride_head, p.k_stride_dx, p.k_stride_slot, p.k_stride_d = 8, 16384, 2048, 128, 8, 1
+    p.v_stride_page, p.v_stride_head, p.v_stride_d, p.v_stride_slot = 16384, 2048, 16, 1
+    p.skip_decodes = 1
+    n = h.mi355_attn_workspace_bytes(C.byref(p))
+    pages = 2 * 256
+    assert n == counters + pages * 4 + 2 * pages * 16 * 8 * 128 * 2
+    p.max_seqlen_k = 0                                                # no key-length bound: not repacked (generic kernel, no scratch)
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+
+
 def test_no_cpu_fallback():
     from mi355_attn.kernels import reshape_and_cache_flash, unified_attention
 
