@@ -629,7 +629,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   const int n_keys_wg = max(0, min(ctx_len + wg_tok_hi + 1, seq_len));
   const int wave_keys = min(ctx_len + w_tok_hi + 1, seq_len);
   const bool wave_has_rows = w_tok_lo <= w_tok_hi;
-  const int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
+  int tile_lo = 0;
+  int tile_hi = (n_keys_wg + kTileN - 1) / kTileN;
+  // key-split launch (see prefill_mfma_kernel): an even share of this Q block's tiles, partial output and lse
+  const int ksplit = a.key_splits > 1 ? (int)blockIdx.y : 0;
+  if (a.key_splits > 1) {
+    const int tps = (tile_hi + a.key_splits - 1) / a.key_splits;
+    tile_lo = min(ksplit * tps, tile_hi);
+    tile_hi = min(tile_hi, tile_lo + tps);
+  }
+  uint16_t* const out_base = (uint16_t*)p.out + (int64_t)ksplit * a.out_split_stride;
+  float* const lse_base = p.lse ? p.lse + (int64_t)ksplit * a.lse_split_stride : nullptr;
 
   const float scale2 = p.scale * kLog2eP;
   // ---- Q rows: the longest round trip of the prologue (cold HBM), issued as soon as the row is known ----
@@ -665,6 +675,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   //   NST >= 3: the whole prefix is staged once in LDS behind the tile stages by LDS-DMA. A VGPR chunk
   //             is a compiler-visible load carried round the loop: hipcc waits for it with vmcnt(0) at
   //             every copy, which would also drain the tile that is meant to stay in flight.
+  if constexpr (!BT_IN_LDS) {
+    if (tile_lo > 0) {      // key-split launch: this share starts deep in the table, not in the chunks fetched at the top
+      bt_chunk = ((min(tile_lo * 4, last_group) << 4) >> a.page_shift) >> 6;
+      bt_cur = bt[min(bt_chunk * 64 + lane, bt_last_any)];
+      bt_nxt = bt[min((bt_chunk + 1) * 64 + lane, bt_last_any)];
+    }
+  }
   if constexpr (BT_IN_LDS) {
     // the first tiles' addresses come out of this table; the KSTEPS Q loads issued after it stay in flight
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KSTEPS) : "memory");
@@ -752,7 +769,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   MI355_WG_STAMP(wg_tb);   // block table staged
 #pragma unroll
   for (int t = 0; t < PD; ++t)
-    if (t < tile_hi) issue_dma(t, smem + t * STAGE);
+    if (tile_lo + t < tile_hi) issue_dma(tile_lo + t, smem + t * STAGE);
   // Q fragments, pre-scaled into the log2 domain (the compiler's wait for the Q loads lands here: they
   // are older than the DMA, so it does not wait for the tiles)
   ps16x8_t qf[KSTEPS];
@@ -774,7 +791,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   }
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
-  wait_next_tile(max(0, min(PD - 1, tile_hi - 1)));                        // tile 0 has landed
+  wait_next_tile(max(0, min(PD - 1, tile_hi - tile_lo - 1)));              // the first tile has landed
   __syncthreads();
   MI355_WG_STAMP(wg_t1);
 #ifdef MI355_PROFILE_PHASES
@@ -944,7 +961,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   };
 
   // tile loop, NST tiles per trip so that the LDS stage is a compile-time offset
-  for (int tile = 0; tile < tile_hi; tile += NST) {
+  for (int tile = tile_lo; tile < tile_hi; tile += NST) {
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
       const int t = tile + u;
@@ -985,14 +1002,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   }
 #endif
   l_run += lane_xor32(l_run);
-  if (p.lse && row_ok && half == 0)    // P = exp2(score - m_ref): the sum is relative to the reference max
-    p.lse[(int64_t)(q_start + tok_local) * p.lse_stride_token + hq] = l_run > 0.0f ? (m_ref + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f : -INFINITY;
+  if (lse_base && row_ok && half == 0)    // P = exp2(score - m_ref): the sum is relative to the reference max
+    lse_base[(int64_t)(q_start + tok_local) * p.lse_stride_token + hq] = l_run > 0.0f ? (m_ref + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f : -INFINITY;
   const float inv = (row_ok && l_run > 0.0f) ? 1.0f / l_run : 0.0f;
   // O leaves through LDS: a lane owns 8-byte pieces of one row (the accumulator layout), which as global stores
   // touch 32 rows per instruction. Each wave parks its 32 rows in its own corner of the (now idle) stages and
   // writes them out as whole 256-byte rows, 16 bytes per lane. (Nontemporal stores of the 8-byte pieces were
   // measured 16 % slower over the whole kernel: no write-combining.) Needs 16-byte aligned output rows.
-  const bool wide_store = (((uintptr_t)p.out & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
+  const bool wide_store = (((uintptr_t)out_base & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
   if (wide_store) {
     constexpr int ORS = ROWB + 16;                       // padded row stride of the parked rows
     char* ost = smem + wave * (32 * ORS);
@@ -1014,7 +1031,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
       const pu32x4_t v = *(const pu32x4_t*)(ost + r * ORS + och * 16);
       if (m < BQ * G && tok < q_len)
       {
-        pu32x4_t* dst = (pu32x4_t*)((uint16_t*)p.out + (int64_t)(q_start + tok) * p.out_stride_token + (int64_t)(head * G + m % G) * p.out_stride_head + och * 8);
+        pu32x4_t* dst = (pu32x4_t*)(out_base + (int64_t)(q_start + tok) * p.out_stride_token + (int64_t)(head * G + m % G) * p.out_stride_head + och * 8);
         // nontemporal: O is written once and never read here; keeping it out of L2 leaves the cache to K/V and
         // nothing to write back when the kernel ends (+1.7 % at 1 x 4096 and 16 x 4096 over plain stores; sc1
         // write-through the same; the 8-byte pieces of the narrow path must NOT be nontemporal, -16 %)
@@ -1022,7 +1039,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
       }
     }
   } else if (row_ok) {
-    uint16_t* op = (uint16_t*)p.out + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
+    uint16_t* op = out_base + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
 #pragma unroll
@@ -1093,8 +1110,8 @@ bool prefill_supported(const mi355_attn_params& p) {
 // workgroups for 256 CUs, each walking 128 tiles). The key tiles are then dealt to `splits` workgroups per Q block
 // (grid.y), each writes a normalised partial output (query type) and its lse (f32) to the workspace, and
 // merge_key_splits_kernel folds them: out = sum_s out_s * exp(lse_s - lse), lse = log sum_s exp(lse_s) - the merge
-// of reduce_segments (:804-828) on normalised partials. Served by the register-staged kernel (any feature set,
-// fp8 KV, head sizes 64..256), chosen from host-known sizes only.
+// of reduce_segments (:804-828) on normalised partials. Both kernels below take it (any feature set, fp8 KV, head
+// sizes 64..256); whether and how far to split is chosen from host-known sizes only.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxKeySplits = 8;
 constexpr size_t kWsCounterBytes = (size_t)256 << 10;   // head of every workspace: the decode kernels' counters
@@ -1108,8 +1125,8 @@ static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
   const int tiles = (std::max(p.max_seqlen_k, 1) + kTileN - 1) / kTileN;
   int splits = 1;
   if (env) splits = atoi(env);
-  // two workgroups per CU, >= 8 tiles each (one sequence, Hq 32 / Hk 8: 512-token chunk at 8k keys 167 -> 89 us with 4
-  // splits, at 32k keys 655 -> 310; two such chunks 112 -> 89 with 2; a 1024-token chunk at 32k keys 652 -> 600 with 2)
+  // two workgroups per CU, >= 8 tiles each (one sequence, Hq 32 / Hk 8: 512-token chunk at 8k keys 167 -> 79 us with 4
+  // splits, at 32k keys 655 -> 275; two such chunks 112 -> 79 with 2; a 1024-token chunk at 32k keys 652 -> 534 with 2)
   else if (wgs < 384 && tiles >= 32) splits = (int)std::min<long>((512 + wgs - 1) / wgs, tiles / 8);
   splits = std::max(1, std::min(std::min(splits, kMaxKeySplits), tiles));
   const int tps = (tiles + splits - 1) / splits;
@@ -1251,7 +1268,10 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
-  a.key_splits = 1; a.tiles_per_key_split = 0; a.out_split_stride = a.lse_split_stride = 0;
+  a.key_splits = g_key_split ? g_key_split->splits : 1;
+  a.tiles_per_key_split = g_key_split ? g_key_split->tiles_per_split : 0;
+  a.out_split_stride = g_key_split ? g_key_split_layout->out_split_stride : 0;
+  a.lse_split_stride = g_key_split ? g_key_split_layout->lse_split_stride : 0;
   size_t lds = (size_t)NST * 2 * kTileN * 256;   // NST stages of K + V tiles, unpadded
   if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix (the caller checked that it fits)
   static bool attr_set = false;
@@ -1262,7 +1282,7 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
     if (rc0 != MI355_OK) return rc0;
     attr_set = true;
   }
-  hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST>), dim3(qblocks * p.num_kv_heads), dim3(NW * 64), lds, stream, a);
+  hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(NW * 64), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_dma_kernel launch");
   if (rc == MI355_OK) set_kernel_name("prefill_mfma");
   return rc;
@@ -1277,7 +1297,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), w64 (64 rows/wave, one wave per SIMD); default = LDS-DMA, 32 rows/wave
   static const char* variant = getenv("MI355_PREFILL");
-  const bool v1 = (variant && variant[0] == 'v' && variant[1] == '1') || g_key_split != nullptr, w64 = !g_key_split && variant && variant[0] == 'w';
+  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', w64 = !g_key_split && variant && variant[0] == 'w';
   if (w64 && prefill_w64_applicable(p) && !p.lse) return launch_prefill_w64(p, stream);   // the experimental kernel has no lse output
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
