@@ -1127,7 +1127,8 @@ static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
   if (env) splits = atoi(env);
   // two workgroups per CU, >= 8 tiles each (one sequence, Hq 32 / Hk 8: 512-token chunk at 8k keys 167 -> 79 us with 4
   // splits, at 32k keys 655 -> 275; two such chunks 112 -> 79 with 2; a 1024-token chunk at 32k keys 652 -> 534 with 2)
-  else if (wgs < 384 && tiles >= 32) splits = (int)std::min<long>((512 + wgs - 1) / wgs, tiles / 8);
+  // (392 / 408 workgroups: +10 % / +8 % with 2 splits; 520: nothing; 1040: -14 %)
+  else if (wgs < 512 && tiles >= 32) splits = (int)std::min<long>((512 + wgs - 1) / wgs, tiles / 8);
   splits = std::max(1, std::min(std::min(splits, kMaxKeySplits), tiles));
   const int tps = (tiles + splits - 1) / splits;
   return {(tiles + tps - 1) / tps, tps};
