@@ -1116,7 +1116,14 @@ bool prefill_supported(const mi355_attn_params& p) {
 constexpr int kMaxKeySplits = 8;
 constexpr size_t kWsCounterBytes = (size_t)256 << 10;   // head of every workspace: the decode kernels' counters
 
-struct KeySplitPlan { int splits, tiles_per_split; };
+// LDS bytes of the staged block-table prefix (8-wave kernel): one int per page of the longest sequence, in 256-byte rows
+static constexpr size_t bt_lds_max_bytes(int nst) { return (size_t)(160 - 4 - 32 * nst) << 10; }   // what the stages leave of 160 KiB
+static size_t prefill_bt_lds_bytes(const mi355_attn_params& p) {
+  const size_t entries = ((size_t)std::max(p.max_seqlen_k, 1) + p.page_size - 1) / p.page_size;
+  return ((entries + 63) / 64) * 256;
+}
+
+struct KeySplitPlan { int splits, tiles_per_split; bool wide; };   // wide: on the 8-wave / 256-row LDS-DMA kernel
 
 static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
   static const char* env = getenv("MI355_PREFILL_KEY_SPLITS");   // measurements: force a split count (1 = never split)
@@ -1124,14 +1131,33 @@ static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
   const long wgs = ((long)p.num_tokens / block_q + p.num_seqs) * p.num_kv_heads;
   const int tiles = (std::max(p.max_seqlen_k, 1) + kTileN - 1) / kTileN;
   int splits = 1;
-  if (env) splits = atoi(env);
+  bool wide = false;
+  // The 8-wave kernel holds one workgroup per CU and is the faster one once it has >= 512 of them (launch_prefill);
+  // with fewer, over >= 4096 keys, key splits give it the items instead of handing the call to the 4-wave kernel:
+  // shares of >= 32 tiles, as many as bring the grid to 512 (one sequence, Hq 32 / Hk 8, sustained TFLOP/s, 4-wave kernel
+  // with its own split plan -> this: 2048-token chunk at 32k keys 1054 -> 1176; 3072: 991 -> 1113; 1024: 1035 -> 1165;
+  // 1024-token chunk at 8k keys 919 -> 988; 512: 858 -> 954).
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+  const long wgs8 = ((long)p.num_tokens * G / 256 + p.num_seqs) * p.num_kv_heads;
+  if (env) {
+    splits = atoi(env);
+  } else if (!feat && p.head_size == 128 && p.kv_dtype == p.q_dtype && wgs8 < 512 && tiles >= 64 &&
+             prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3)) {
+    splits = (int)std::min<long>(std::min<long>((512 + wgs8 - 1) / wgs8, tiles / 32), kMaxKeySplits);
+    wide = splits > 1;
+  }
+  if (wide) {
+    const int tps8 = (tiles + splits - 1) / splits;
+    return {(tiles + tps8 - 1) / tps8, tps8, true};
+  }
+  // the 4-wave kernel (and the register-staged one: features, fp8 KV, other head sizes):
   // two workgroups per CU, >= 8 tiles each (one sequence, Hq 32 / Hk 8: 512-token chunk at 8k keys 167 -> 79 us with 4
   // splits, at 32k keys 655 -> 275; two such chunks 112 -> 79 with 2; a 1024-token chunk at 32k keys 652 -> 534 with 2)
   // (392 / 408 workgroups: +10 % / +8 % with 2 splits; 520: nothing; 1040: -14 %)
-  else if (wgs < 512 && tiles >= 32) splits = (int)std::min<long>((512 + wgs - 1) / wgs, tiles / 8);
+  if (!env && wgs < 512 && tiles >= 32) splits = (int)std::min<long>((512 + wgs - 1) / wgs, tiles / 8);
   splits = std::max(1, std::min(std::min(splits, kMaxKeySplits), tiles));
   const int tps = (tiles + splits - 1) / splits;
-  return {(tiles + tps - 1) / tps, tps};
+  return {(tiles + tps - 1) / tps, tps, false};
 }
 
 struct KeySplitLayout { size_t out_off, lse_off, total; int64_t out_split_stride, lse_split_stride; };
@@ -1250,13 +1276,6 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   return rc;
 }
 
-// LDS bytes of the staged block-table prefix (8-wave kernel): one int per page of the longest sequence, in 256-byte rows
-static constexpr size_t bt_lds_max_bytes(int nst) { return (size_t)(160 - 4 - 32 * nst) << 10; }   // what the stages leave of 160 KiB
-static size_t prefill_bt_lds_bytes(const mi355_attn_params& p) {
-  const size_t entries = ((size_t)std::max(p.max_seqlen_k, 1) + p.page_size - 1) / p.page_size;
-  return ((entries + 63) / 64) * 256;
-}
-
 template <typename T, int NW, int NST>
 static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   PrefillArgs a;
@@ -1309,6 +1328,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
     // MI355_PREFILL=d4 | d8 pins one of the two for measurements.
     const long wgs8 = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 256 + p.num_seqs) * p.num_kv_heads;
     bool wide = wgs8 >= 2 * 256 && p.max_seqlen_k >= 2048;
+    if (g_key_split) wide = g_key_split->wide;
     if (variant && variant[0] == 'd') wide = variant[1] == '8';
     if (wide && prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3))
       return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream) : launch_prefill_dma<f16_t, 8, 3>(p, stream);
