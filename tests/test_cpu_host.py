@@ -139,6 +139,14 @@ def test_workspace_bytes_of_the_prefill_paths(lib):
     # the same chunk with short contexts only: no split
     p.max_seqlen_k = 1024
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+    # a 2048-token chunk against 32k keys: (2048*4/256 + 1) * 8 = 264 Q blocks of the 8-wave kernel -> 2 splits bring it to 512
+    p.num_tokens, p.max_seqlen_q, p.max_seqlen_k = 2048, 2048, 32768
+    rows = 2048 * 32
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters + 2 * rows * 128 * 2 + 2 * rows * 4
+    # with a sliding window the register-staged kernel serves it: (2048/32 + 1) * 8 = 520 workgroups -> no split
+    p.sliding_window = 1024
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+    p.sliding_window = 0
     # legacy op: v0 layout (K [nb, Hk, D/8, 16, 8], V [nb, Hk, D, 16]) + linear new keys, 2 sequences, bound 4096 keys:
     # counters, identity block table, K and V scratch of 2 * 256 pages
     p = _c3_like_params(lib, addr)
