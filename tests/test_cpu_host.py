@@ -296,3 +296,14 @@ def test_sequence_assignment_is_balanced_and_deterministic():
     loads = [sum(parallel.attention_cost(qlens[i], kvs[i]) for i in o) for o in owned]
     assert max(loads) / (sum(loads) / 8) < 1.05
     assert owned == parallel.assign_sequences(qlens, kvs, 8)
+
+
+def test_tools_and_bench_compile():
+    """The measurement scripts are part of the evidence chain: they must at least parse."""
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        compile(open(f).read(), f, "exec")          # syntax only: nothing is executed, no bytecode written
