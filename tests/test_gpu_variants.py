@@ -43,8 +43,8 @@ def test_prefill_register_staged_kernel_for_plain_head_size_128():
          keyword="(mixed and 128 and (8-2 or 32-1)) or c2_full")
 
 
-def test_prefill_64_rows_per_wave_experimental_kernel():
-    _run({"MI355_PREFILL": "w64"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"],
+def test_prefill_64_rows_per_wave_kernel_on_small_shapes():
+    _run({"MI355_PREFILL": "pw"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"],
          keyword="(mixed and 128 and (8-2 or 32-1)) or c2_full")
 
 

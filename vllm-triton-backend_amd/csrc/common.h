@@ -308,8 +308,8 @@ bool repack_supported(const mi355_attn_params& p);
 size_t repack_scratch_bytes(const mi355_attn_params& p, size_t head);
 mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, size_t head);
 int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool skip_single, hipStream_t stream);
-bool prefill_w64_applicable(const mi355_attn_params& p);   // beyond prefill_supported()
-int launch_prefill_w64(const mi355_attn_params& p, hipStream_t stream);
+bool prefill_pw_applicable(const mi355_attn_params& p);    // beyond prefill_supported()
+int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, hipStream_t stream);
 
 inline int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return MI355_OK;

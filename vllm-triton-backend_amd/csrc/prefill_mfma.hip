@@ -1317,8 +1317,10 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), w64 (64 rows/wave, one wave per SIMD); default = LDS-DMA, 32 rows/wave
   static const char* variant = getenv("MI355_PREFILL");
-  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', w64 = !g_key_split && variant && variant[0] == 'w';
-  if (w64 && prefill_w64_applicable(p) && !p.lse) return launch_prefill_w64(p, stream);   // the experimental kernel has no lse output
+  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', pw = variant && variant[0] == 'p';
+  if (pw && prefill_pw_applicable(p) && (!g_key_split || g_key_split->wide))
+    return launch_prefill_pw(p, g_key_split ? g_key_split->splits : 1, g_key_split ? g_key_split_layout->out_split_stride : 0,
+                             g_key_split ? g_key_split_layout->lse_split_stride : 0, stream);
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped

@@ -1,0 +1,583 @@
+// prefill_pw_kernel: the D = 128 prefill fast path. Four waves, 64 query rows each, one wave per SIMD.
+//
+// Replaces kernel_unified_attention_2d (LIB/kernels/triton_unified_attention.py:275-523) for the plain
+// (no soft-cap / ALiBi / window) 16-bit case; same semantics as prefill_mfma.hip's kernels.
+//
+// Why this shape. prefill_dma_kernel (eight waves of 32 rows, two per SIMD) issues 169 VALU + 106 SALU + 50 LDS
+// instructions per 32 MFMAs and keeps the matrix pipes 43 % busy. Here
+//   * a wave owns TWO 32-row sub-blocks (A, B): every K fragment and every transposed V fragment read from
+//     LDS feeds two MFMAs, and the wave issues HALF the LDS reads, LDS-DMA and barriers per MFMA;
+//   * the two sub-blocks run half a tile apart ("ping-pong" inside one wave): while the matrix pipe computes
+//     S_A = K.Q_A^T the VALU finishes sub-block B's softmax, then O_B += V^T.P_B runs beside A's row maxima
+//     and exponentials, and so on - every MFMA has a few independent VALU instructions in its shadow and no
+//     phase of the loop is VALU-only or MFMA-only. One wave per SIMD has nobody to hide its bubbles, so the
+//     interleave is written out gap by gap (the work that follows each MFMA is fixed in the source);
+//   * the whole 512-entry register file: O (128), Q (64) and the current K tile (64) live in accumulator
+//     registers that only MFMA / ds_read touch (literal a[..] operands, never seen by the register allocator);
+//     S, P, V fragments and the softmax state are ordinary VGPRs;
+//   * K/V tiles arrive by LDS-DMA with a SCALAR page base + one constant per-lane offset (global_load_lds with
+//     an SGPR address): wave w fetches the 16-key group w of every tile, i.e. one block-table entry per tile and
+//     matrix, no per-lane 64-bit address arithmetic; three-slot rings, K two tiles ahead, V one; counted vmcnt.
+//
+// MFMA orientation, the in-register softmax, the deferred running maximum (C operand = -m_ref) and the LDS
+// swizzles are those of prefill_dma_kernel (prefill_mfma.hip).
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace mi355 {
+
+typedef __attribute__((ext_vector_type(16))) float wf32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int wu32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int wu32x2_t;
+
+constexpr int kPwTile = 64;          // keys per KV tile
+constexpr int kPwRows = 256;         // Q-block rows per workgroup
+constexpr float kPwLog2e = 1.4426950408889634f;
+constexpr float kPwDeferThr = 8.0f;  // log2 units a row's tile maximum may exceed its reference before the reference moves
+
+// accumulator-register map (owned by the asm statements below)
+constexpr int kAO = 0;     // O^T[sb][b]  : kAO + 64 sb + 16 b   (16 registers)
+constexpr int kAQ = 128;   // Q'[sb][ks]  : kAQ + 32 sb + 4 ks   (4 registers)
+constexpr int kAK = 192;   // K[kb][ks]   : kAK + 32 kb + 4 ks   (4 registers)
+// LDS map: K ring (3 x 16 KiB), V ring (3 x 16 KiB), block-table prefix
+constexpr int kSlotBytes = 16384, kLdsK = 0, kLdsV = 3 * kSlotBytes, kLdsBT = 6 * kSlotBytes;
+
+struct PwArgs {
+  mi355_attn_params p;
+  int group;       // G
+  int block_q;     // tokens per Q block = 256 / G
+  int page_shift;  // log2(page_size)
+  int key_splits;  // grid.y: workgroup (x, s) attends the s-th even share of its Q block's key tiles (prefill_mfma.hip)
+  int64_t out_split_stride, lse_split_stride;
+  uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
+};
+
+template <int N> using ic = std::integral_constant<int, N>;
+template <typename F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// ---- single instructions the loop is built from. asm volatile: they stay in source order, which IS the schedule.
+// hipcc neither pads nor counts anything inside (cdna_hip_programming.md 5.7); the placement rules are in the kernel.
+__device__ __forceinline__ float a_exp2(float x) { float r; asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ float a_add(float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float a_max(float x, float y) { float r; asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float a_mov(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ float a_max3(float x, float y, float z) { float r; asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; }
+
+template <typename T> struct pw_ops;
+#define MI355_DEF_PW_OPS(TAG, MFMA, CVT)                                                                          \
+  template <> struct pw_ops<TAG> {                                                                                \
+    /* S(VGPR) += K(AGPR) . Q(AGPR) */                                                                             \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_acc(wf32x16_t& s) {                       \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3)); \
+    }                                                                                                             \
+    /* O(AGPR) += V(VGPR) . P(VGPR) */                                                                             \
+    template <int OA> static __device__ __forceinline__ void pv(const wu32x4_t& v, const wu32x4_t& pf) {          \
+      asm volatile(MFMA " a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pf), "n"(OA), "n"(OA + 15));              \
+    }                                                                                                             \
+    static __device__ __forceinline__ uint32_t cvt(float lo, float hi) {                                          \
+      uint32_t r; asm volatile(CVT " %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r;                          \
+    }                                                                                                             \
+  };
+MI355_DEF_PW_OPS(bf16_t, "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
+MI355_DEF_PW_OPS(f16_t, "v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32")
+#undef MI355_DEF_PW_OPS
+
+template <typename T> __device__ __forceinline__ float pw_lo(uint32_t w);
+template <typename T> __device__ __forceinline__ float pw_hi(uint32_t w);
+template <> __device__ __forceinline__ float pw_lo<bf16_t>(uint32_t w) { return bf16_to_f32((uint16_t)(w & 0xffff)); }
+template <> __device__ __forceinline__ float pw_hi<bf16_t>(uint32_t w) { return bf16_to_f32((uint16_t)(w >> 16)); }
+template <> __device__ __forceinline__ float pw_lo<f16_t>(uint32_t w) { return f16_to_f32((uint16_t)(w & 0xffff)); }
+template <> __device__ __forceinline__ float pw_hi<f16_t>(uint32_t w) { return f16_to_f32((uint16_t)(w >> 16)); }
+template <typename T> __device__ __forceinline__ uint32_t pw_pack(float lo, float hi) {
+  if constexpr (__is_same(T, bf16_t)) return pack_bf16x2(lo, hi); else return pack_f16x2(lo, hi);
+}
+
+template <int IDX> __device__ __forceinline__ void acc_write(uint32_t v) { asm volatile("v_accvgpr_write_b32 a%c0, %1" :: "n"(IDX), "v"(v)); }
+template <int IDX> __device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "n"(IDX)); }
+template <int IDX> __device__ __forceinline__ float acc_read() { float r; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "n"(IDX)); return r; }
+
+// LDS -> accumulator registers (K fragments), LDS -> VGPR transposed (V fragments). "memory": LDS accesses the
+// compiler emits itself (block-table lookups) stay on their side of these.
+template <int AG, int OFF> __device__ __forceinline__ void lds_to_acc_b128(uint32_t addr) {
+  asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" :: "v"(addr), "n"(AG), "n"(AG + 3), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ wu32x2_t lds_tr_b64(uint32_t addr) {
+  wu32x2_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+// One LDS-DMA piece with a scalar base: lane l's 16 bytes from sbase + voff land at LDS lds_dst + 16 l.
+__device__ __forceinline__ void pw_glds16(uint32_t voff, uint64_t sbase, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int num_seqs, int qblock, int block_q) {
+  int left = 0, right = num_seqs;     // largest i with cu[i] / block_q + i <= qblock (find_seq_idx, :32-52)
+  while (left < right) {
+    const int mid = (left + right) >> 1;
+    if (cu[mid] / block_q + mid <= qblock) left = mid + 1; else right = mid;
+  }
+  return left - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
+  using ops = pw_ops<T>;
+  constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  asm volatile("" ::: "a255");                 // the kernel owns all 256 accumulator registers
+  const mi355_attn_params& p = a.p;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = a.group, BQ = a.block_q;
+
+  const int head = (int)(blockIdx.x % p.num_kv_heads);     // KV head fastest: one head per XCD at Hk = 8
+  const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);   // heaviest first
+  const int seq = pw_find_seq(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
+  if (seq < 0) return;
+  // block-table prefix of the sequence -> LDS, fetched as soon as the sequence is known (bounded by max_seqlen_k)
+  const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
+  const int bt_last_any = ((max(p.max_seqlen_k, 1) + p.page_size - 1) >> a.page_shift) - 1;
+  const int* bt_lds = (const int*)(smem + kLdsBT);
+  for (int c = wave; c * 64 <= bt_last_any; c += 4) glds4(bt + min(c * 64 + lane, bt_last_any), lds_addr(bt_lds) + c * 256);
+  const int q_start = p.cu_seqlens_q[seq];
+  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
+  const int qb_local = qblock - (q_start / BQ + seq);
+  const int seq_len = p.seqused_k[seq];
+  if (qb_local * BQ >= q_len || (p.skip_decodes && q_len == 1) || (p.only_decodes && q_len != 1)) {
+    glds_wait_all();                           // never leave with a DMA into this workgroup's LDS in flight
+    return;
+  }
+  const int ctx_len = seq_len - q_len;
+  const int tok0 = qb_local * BQ;
+
+  // ---- this lane's two query rows (sub-blocks A = 0, B = 1) -----------------------------------------
+  const int qr = lane & 31, half = lane >> 5;
+  int tok_local[2], hq[2], lim[2];
+  bool row_ok[2];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const int m_row = wave * 64 + sb * 32 + qr;
+    tok_local[sb] = tok0 + m_row / G;
+    hq[sb] = head * G + m_row % G;
+    row_ok[sb] = (m_row < BQ * G) && (tok_local[sb] < q_len);
+    lim[sb] = row_ok[sb] ? min(ctx_len + tok_local[sb], seq_len - 1) : -1;   // last visible key
+  }
+  const int w_tok_lo = tok0 + (wave * 64) / G;
+  const int wg_tok_hi = min(tok0 + BQ - 1, q_len - 1);
+  const int n_keys_wg = max(0, min(ctx_len + wg_tok_hi + 1, seq_len));
+  int tile_lo = 0;
+  int tile_hi = (n_keys_wg + kPwTile - 1) / kPwTile;
+  const int ksplit = a.key_splits > 1 ? (int)blockIdx.y : 0;
+  if (a.key_splits > 1) {                      // key-split launch: an even share of this Q block's tiles
+    const int tps = (tile_hi + a.key_splits - 1) / a.key_splits;
+    tile_lo = min(ksplit * tps, tile_hi);
+    tile_hi = min(tile_hi, tile_lo + tps);
+  }
+  uint16_t* const out_base = (uint16_t*)p.out + (int64_t)ksplit * a.out_split_stride;
+  float* const lse_base = p.lse ? p.lse + (int64_t)ksplit * a.lse_split_stride : nullptr;
+
+  // ---- Q rows -> registers (padding rows read the sequence's last query row and are zeroed below) ----
+  wu32x4_t qraw[2][8];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)(q_start + min(tok_local[sb], q_len - 1)) * p.q_stride_token + (int64_t)hq[sb] * p.q_stride_head + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qraw[sb][ks] = *(const wu32x4_t*)(qp + 16 * ks);
+  }
+
+  // ---- LDS-DMA constants: wave w stages key rows 16 w .. 16 w + 15 of every tile, four rows per instruction -
+  const char* kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
+  const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
+  const int staged_keys = (bt_last_any + 1) << a.page_shift;          // keys the staged block-table prefix covers
+  const int last_group = (max(min(n_keys_wg, staged_keys), 1) - 1) >> 4;
+  const int page_mask = p.page_size - 1;
+  const uint32_t ksb = a.k_slot_stride * 2, vsb = a.v_slot_stride * 2;   // bytes between key rows of a page
+  const uint32_t kpb = a.k_page_stride * 2, vpb = a.v_page_stride * 2;   // bytes between pages
+  const int r4 = lane >> 4, c16 = lane & 15;
+  // LDS row R = 4 i + r4 of the group, chunk position c16 holds logical chunk c16 ^ f(R) (swizzle on the source side)
+  auto k_src_off = [&](int i, int maxr) -> uint32_t {
+    const int R = 4 * i + r4;
+    return (uint32_t)(min(R, maxr) * (int)ksb + ((c16 ^ R) << 4));
+  };
+  auto v_src_off = [&](int i, int maxr) -> uint32_t {
+    const int R = 4 * i + r4;
+    return (uint32_t)(min(R, maxr) * (int)vsb + ((c16 ^ (((R & 3) << 2) | ((R >> 2) & 3))) << 4));
+  };
+  uint32_t koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { koff[i] = k_src_off(i, 15); voff[i] = v_src_off(i, 15); }
+  const uint32_t lds_wave = (uint32_t)(wave * 4096);
+
+  // scalar side of one (tile, matrix): block-table entry of the wave's 16-key group -> 64-bit base of its first row.
+  // Tiles past the share re-fetch its last tile (never read; keeps the DMA count per iteration fixed).
+  auto dma_setup = [&](int tile, auto ISV, uint64_t& base, int& maxr) {
+    constexpr bool isv = decltype(ISV)::value != 0;
+    const int g = min(min(tile, tile_hi - 1) * 4 + wave, last_group);
+    const int key0 = g << 4;
+    const int page = __builtin_amdgcn_readfirstlane(bt_lds[key0 >> a.page_shift]);
+    const uint32_t slot0 = (uint32_t)(key0 & page_mask);
+    const uint64_t b = (uint64_t)(isv ? vbase : kbase) + (uint64_t)(uint32_t)page * (isv ? vpb : kpb) + (uint64_t)slot0 * (isv ? vsb : ksb);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    base = ((uint64_t)hi << 32) | lo;
+    maxr = seq_len - 1 - key0;                 // rows past it are beyond the sequence: they re-read row maxr (finite data)
+  };
+  auto dma_piece = [&](auto ISV, int i, uint32_t off_const, uint64_t base, int maxr, uint32_t lds_dst) {
+    constexpr bool isv = decltype(ISV)::value != 0;
+    uint32_t off = off_const;
+    if (maxr < 15) off = isv ? v_src_off(i, max(maxr, 0)) : k_src_off(i, max(maxr, 0));   // wave-uniform, last group only
+    pw_glds16(off, base, lds_dst + lds_wave + i * 1024);
+  };
+  auto dma_group = [&](int tile, auto ISV, uint32_t lds_dst) {
+    constexpr bool isv = decltype(ISV)::value != 0;
+    uint64_t base; int maxr;
+    dma_setup(tile, ISV, base, maxr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(ISV, i, isv ? voff[i] : koff[i], base, maxr, lds_dst);
+  };
+
+  // ---- per-lane LDS read addresses (swizzle folded in) ----------------------------------------------
+  // K fragment ks of 32-key block kb: row 32 kb + qr, logical chunk 2 ks + half
+  uint32_t k_rd[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_rd[ks] = (uint32_t)(kLdsK + qr * ROWB + (((2 * ks + half) ^ (qr & 15)) << 4));
+  // V transposed read of k-step sk (16 keys), output block b: row 16 sk + 4 half + q4 (+8), logical byte column
+  // 64 b + 32 g1 + 8 pp -> chunk 4 b + 2 g1 + (pp >> 1), sub-offset 8 (pp & 1)
+  const int gq1 = (lane >> 4) & 1, li = lane & 15, q4 = li >> 2, pp = li & 3;
+  uint32_t v_rd0[4], v_rd1[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int lc = 4 * b + 2 * gq1 + (pp >> 1);
+    const int r0 = 4 * half + q4, r1 = r0 + 8;
+    const int f0 = ((r0 & 3) << 2) | ((r0 >> 2) & 3), f1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3);
+    v_rd0[b] = (uint32_t)(kLdsV + r0 * ROWB + ((lc ^ f0) << 4) + 8 * (pp & 1));
+    v_rd1[b] = (uint32_t)(kLdsV + r1 * ROWB + ((lc ^ f1) << 4) + 8 * (pp & 1));
+  }
+
+  // ---- the block table has landed; first tiles on their way ------------------------------------------
+  glds_wait_all();
+  __syncthreads();
+  if (tile_hi > tile_lo) {
+    // issue order fixes the counted waits below: K0 K1 V0 | K2 V1
+    dma_group(tile_lo, ic<0>{}, kLdsK);
+    dma_group(tile_lo + 1, ic<0>{}, kLdsK + kSlotBytes);
+    dma_group(tile_lo, ic<1>{}, kLdsV);
+    dma_group(tile_lo + 2, ic<0>{}, kLdsK + 2 * kSlotBytes);
+    dma_group(tile_lo + 1, ic<1>{}, kLdsV + kSlotBytes);
+  }
+
+  // ---- Q' = Q * scale * log2(e), packed, into accumulator registers -----------------------------------
+  const float scale2 = p.scale * kPwLog2e;
+  sfor<2>([&](auto SB) {
+    sfor<8>([&](auto KS) {
+      constexpr int sb = decltype(SB)::value, ks = decltype(KS)::value;
+      const wu32x4_t v = row_ok[sb] ? qraw[sb][ks] : wu32x4_t{0, 0, 0, 0};
+      sfor<4>([&](auto E) {
+        constexpr int e = decltype(E)::value;
+        acc_write<kAQ + 32 * sb + 4 * ks + e>(pw_pack<T>(pw_lo<T>(v[e]) * scale2, pw_hi<T>(v[e]) * scale2));
+      });
+    });
+  });
+  sfor<128>([&](auto I) { acc_zero<kAO + decltype(I)::value>(); });
+
+  // ---- state -------------------------------------------------------------------------------------------
+  wf32x16_t S[2][2];          // [sub-block][32-key block]: S^T - m_ref of the tile in flight
+  float cneg[2] = {0.0f, 0.0f};   // -m_ref: every S register starts from it (the MFMA chain accumulates on top)
+  uint32_t pw[2][16];         // P^T as packed pairs; dwords 4 sk .. 4 sk + 3 = B operand of k-step sk
+  wu32x4_t vfr[4][4];         // transposed V fragments [output block b][k-step sk]
+  float e0[2][16], e1[2][16], tmax[2][2][8];
+  float ps0[2] = {0.0f, 0.0f}, ps1[2] = {0.0f, 0.0f};   // running row sums (two chains), relative to m_ref
+  float m_ref[2] = {0.0f, 0.0f};
+  bool started[2] = {!row_ok[0], !row_ok[1]};           // padding rows never see a key: keep them off the slow path
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S[x][0][r] = x == 0 ? 0.0f : -INFINITY; S[x][1][r] = -INFINITY; pw[x][r] = 0u; e0[x][r] = 0.0f; e1[x][r] = 0.0f; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int o = 0; o < 8; ++o) tmax[x][kb][o] = -INFINITY;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
+
+  // ---- the pieces of an iteration ------------------------------------------------------------------------
+  // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7
+  auto qk = [&](auto X, auto GC) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value, g = decltype(GC)::value, kb = g >> 3, ks = g & 7;
+    ops::template qk_acc<kAK + 32 * kb + 4 * ks, kAQ + 32 * x + 4 * ks>(S[x][kb]);
+  };
+  // S_x[kb][r] = -m_ref ahead of its MFMA chain (the registers are free: the previous tile's exponentials are done)
+  auto sinit = [&](auto X, auto KB, auto RC) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value, kb = decltype(KB)::value, r = decltype(RC)::value;
+    S[x][kb][r] = a_mov(cneg[x]);
+  };
+  // MFMA g of O_x += V^T.P_x^T: output block g >> 2, k-step g & 3
+  auto pv = [&](auto X, auto GC) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value, g = decltype(GC)::value, b = g >> 2, sk = g & 3;
+    ops::template pv<kAO + 64 * x + 16 * b>(vfr[b][sk], wu32x4_t{pw[x][4 * sk], pw[x][4 * sk + 1], pw[x][4 * sk + 2], pw[x][4 * sk + 3]});
+  };
+  // row maximum of S_x[kb], 8 instructions o = 0 .. 7 (issue >= 2 MFMAs after the chain's last MFMA: its
+  // result needs 12 issue slots to become readable and hipcc pads nothing around an asm MFMA)
+  auto maxop = [&](auto X, auto KB, auto OC) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value, kb = decltype(KB)::value, o = decltype(OC)::value;
+    const wf32x16_t& s = S[x][kb];
+    float* tm = tmax[x][kb];
+    if constexpr (o < 5) tm[o] = a_max3(s[3 * o], s[3 * o + 1], s[3 * o + 2]);
+    else if constexpr (o == 5) tm[5] = a_max3(tm[0], tm[1], s[15]);
+    else if constexpr (o == 6) tm[6] = a_max3(tm[2], tm[3], tm[4]);
+    else tm[7] = a_max(tm[5], tm[6]);
+  };
+  // exponentials, row sums and packing of sub-block x: 80 instructions (16 pairs x {exp, exp, add, add, cvt}) dealt
+  // evenly over a window of 28 MFMA gaps. A transcendental's result is never read by the next instruction.
+  auto estream = [&](auto X, auto WC) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value, w = decltype(WC)::value;
+    constexpr int n0 = w * 80 / 28, n1 = (w + 1) * 80 / 28;
+    sfor<n1 - n0>([&](auto NC) __attribute__((always_inline)) {
+      constexpr int n = n0 + decltype(NC)::value, j = n / 5, k = n % 5, kb = j >> 3, r = 2 * (j & 7);
+      if constexpr (k == 0) e0[x][j] = a_exp2(S[x][kb][r]);
+      else if constexpr (k == 1) e1[x][j] = a_exp2(S[x][kb][r + 1]);
+      else if constexpr (k == 2) ps0[x] = a_add(ps0[x], e0[x][j]);
+      else if constexpr (k == 3) ps1[x] = a_add(ps1[x], e1[x][j]);
+      else pw[x][j] = ops::cvt(e0[x][j], e1[x][j]);
+    });
+  };
+  // after both 32-key maxima: does every row of sub-block x keep its reference maximum? (almost always: yes)
+  auto decide = [&](auto X, int t, bool need_mask) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value;
+    float mx = a_max(tmax[x][0][7], tmax[x][1][7]);
+    asm volatile("s_nop 1" : "+v"(mx));          // VALU write -> v_permlane read
+    mx = fmaxf(mx, lane_xor32(mx));              // the other half-wave holds the row's other 32 keys
+    bool calm = started[x] && mx <= kPwDeferThr;
+    if (need_mask || !__all(calm)) {
+      const int key_base = t * kPwTile;
+      if (need_mask) {                           // tile straddles the causal diagonal or the sequence end
+        float m2 = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            S[x][kb][r] = key <= lim[x] ? S[x][kb][r] : -INFINITY;
+            m2 = fmaxf(m2, S[x][kb][r]);
+          }
+        mx = fmaxf(m2, lane_xor32(m2));
+        calm = started[x] && mx <= kPwDeferThr;
+      }
+      if (!__all(calm)) {                        // move the reference of the rows that need it
+        const float upd = (!calm && mx > -INFINITY) ? mx : 0.0f;
+        started[x] = started[x] || (mx > -INFINITY);
+        m_ref[x] += upd;
+        const float alpha = __builtin_amdgcn_exp2f(-upd);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[x][kb][r] -= upd;
+        cneg[x] = -m_ref[x];
+        ps0[x] *= alpha;
+        ps1[x] *= alpha;
+        if (t != tile_lo) {                      // O_x is idle here: its last MFMA retired half an iteration ago
+          sfor<64>([&](auto I) __attribute__((always_inline)) {
+            constexpr int idx = kAO + 64 * x + decltype(I)::value;
+            const float o = acc_read<idx>() * alpha;
+            acc_write<idx>(__builtin_bit_cast(uint32_t, o));
+          });
+        }
+      }
+    }
+  };
+  // LDS reads. V(t)[b][sk]: two transposed 8-byte reads into one 4-register fragment
+  auto vread = [&](auto B, auto SK, auto SLOT) __attribute__((always_inline)) {
+    constexpr int b = decltype(B)::value, sk = decltype(SK)::value, off = decltype(SLOT)::value + sk * 16 * ROWB;
+    const wu32x2_t v0 = lds_tr_b64<off>(v_rd0[b]);
+    const wu32x2_t v1 = lds_tr_b64<off>(v_rd1[b]);
+    vfr[b][sk] = wu32x4_t{v0[0], v0[1], v1[0], v1[1]};
+  };
+  auto kread = [&](auto NC, auto SLOT) __attribute__((always_inline)) {
+    constexpr int n = decltype(NC)::value, kb = n >> 3, ks = n & 7;
+    lds_to_acc_b128<kAK + 32 * kb + 4 * ks, decltype(SLOT)::value + kb * 32 * ROWB>(k_rd[ks]);
+  };
+
+  // One iteration = one KV tile t. Matrix pipe: S_A(t) | O_B += P_B(t-1) | S_B(t) | O_A += P_A(t); beside it, per gap:
+  //   seg 1: B(t-1) exponentials (second half) . A's first 32-key maximum . LDS-DMA of K(t+3), V(t+2)
+  //   seg 2: A's second maximum, decision, A exponentials . V(t) fragment reads as V(t-1)'s registers retire
+  //   seg 3: A exponentials (second half) . B's first maximum . K(t+1) fragment reads as K(t)'s registers retire
+  //   seg 4: B's second maximum, decision, B exponentials
+  // IT = (t - tile_lo) % 3 picks the ring slots at compile time.
+  auto iteration = [&](auto ITC, int t) __attribute__((always_inline)) {
+    constexpr int it = decltype(ITC)::value;
+    constexpr int KR = ((it + 1) % 3) * kSlotBytes;            // K(t+1) is read from here
+    constexpr int VR = (it % 3) * kSlotBytes;                  // V(t)
+    constexpr int KD = kLdsK + (it % 3) * kSlotBytes;          // K(t+3) goes where K(t) was
+    constexpr int VD = kLdsV + ((it + 2) % 3) * kSlotBytes;    // V(t+2) goes where V(t-1) was
+    const bool need_mask = (t * kPwTile + kPwTile - 1 > ctx_len + w_tok_lo) || (t * kPwTile + kPwTile > seq_len);
+    uint64_t kb64 = 0, vb64 = 0;
+    int kmaxr = 15, vmaxr = 15;
+    // ---- segment 1 -------------------------------------------------------------------------------------
+    sfor<16>([&](auto GC) __attribute__((always_inline)) {
+      constexpr int g = decltype(GC)::value;
+      qk(ic<0>{}, GC);
+      if constexpr (g < 8) { sinit(ic<0>{}, ic<1>{}, ic<2 * g>{}); sinit(ic<0>{}, ic<1>{}, ic<2 * g + 1>{}); }
+      estream(ic<1>{}, ic<12 + g>{});
+      if constexpr (g >= 10 && g < 14) { maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10)>{}); maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10) + 1>{}); }
+      if constexpr (g == 0) { dma_setup(t + 3, ic<0>{}, kb64, kmaxr); dma_setup(t + 2, ic<1>{}, vb64, vmaxr); }
+      if constexpr (g >= 3 && g < 7) dma_piece(ic<0>{}, g - 3, koff[g - 3], kb64, kmaxr, KD);
+      if constexpr (g >= 7 && g < 11) dma_piece(ic<1>{}, g - 7, voff[g - 7], vb64, vmaxr, VD);
+    });
+    // ---- segment 2 -------------------------------------------------------------------------------------
+    sfor<16>([&](auto GC) __attribute__((always_inline)) {
+      constexpr int g = decltype(GC)::value;
+      pv(ic<1>{}, GC);
+      sinit(ic<1>{}, ic<0>{}, GC);
+      if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<0>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
+      if constexpr (g == 3) decide(ic<0>{}, t, need_mask);
+      if constexpr (g >= 4) { estream(ic<0>{}, ic<g - 4>{}); vread(ic<((g - 4) >> 2)>{}, ic<((g - 4) & 3)>{}, ic<VR>{}); }
+    });
+    // ---- segment 3 -------------------------------------------------------------------------------------
+    sfor<16>([&](auto GC) __attribute__((always_inline)) {
+      constexpr int g = decltype(GC)::value;
+      qk(ic<1>{}, GC);
+      if constexpr (g < 8) { sinit(ic<1>{}, ic<1>{}, ic<2 * g>{}); sinit(ic<1>{}, ic<1>{}, ic<2 * g + 1>{}); }
+      estream(ic<0>{}, ic<12 + g>{});
+      if constexpr (g >= 10 && g < 14) { maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10)>{}); maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10) + 1>{}); }
+      if constexpr (g < 4) vread(ic<3>{}, GC, ic<VR>{});
+      if constexpr (g >= 1) kread(ic<g - 1>{}, ic<KR>{});
+    });
+    // ---- segment 4 -------------------------------------------------------------------------------------
+    // every V(t) fragment has landed: at most the 8 youngest LDS reads (K fragments) may still be out
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(vfr[0][0]), "+v"(vfr[0][1]), "+v"(vfr[0][2]), "+v"(vfr[0][3]), "+v"(vfr[1][0]), "+v"(vfr[1][1]), "+v"(vfr[1][2]), "+v"(vfr[1][3]),
+                   "+v"(vfr[2][0]), "+v"(vfr[2][1]), "+v"(vfr[2][2]), "+v"(vfr[2][3]), "+v"(vfr[3][0]), "+v"(vfr[3][1]), "+v"(vfr[3][2]), "+v"(vfr[3][3]));
+    sfor<16>([&](auto GC) __attribute__((always_inline)) {
+      constexpr int g = decltype(GC)::value;
+      pv(ic<0>{}, GC);
+      sinit(ic<0>{}, ic<0>{}, GC);
+      if constexpr (g == 0) kread(ic<15>{}, ic<KR>{});
+      if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<1>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
+      if constexpr (g == 3) decide(ic<1>{}, t, need_mask);
+      if constexpr (g >= 4) estream(ic<1>{}, ic<g - 4>{});
+    });
+    // K(t+1) is in its registers; K(t+2) and V(t+1) (issued one iteration ago) have landed, this iteration's 8
+    // pieces may stay in flight; everyone is done reading K(t+1)'s and V(t)'s slots
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  };
+
+  if (tile_hi > tile_lo) {
+    // K(tile_lo), K(tile_lo + 1), V(tile_lo) have landed (K2 and V1, 8 pieces, may still fly)
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    sfor<16>([&](auto NC) __attribute__((always_inline)) { kread(NC, ic<0>{}); });
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 0 is re-filled (K(tile_lo + 3)) in the first iteration
+    int t = tile_lo;
+    while (true) {
+      iteration(ic<0>{}, t);
+      if (++t >= tile_hi) break;
+      iteration(ic<1>{}, t);
+      if (++t >= tile_hi) break;
+      iteration(ic<2>{}, t);
+      if (++t >= tile_hi) break;
+    }
+    // drain: sub-block B of the last tile
+    sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
+    asm volatile("s_nop 1");
+    sfor<16>([&](auto GC) __attribute__((always_inline)) { pv(ic<1>{}, GC); });
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA results readable; no DMA into LDS in flight
+  __syncthreads();                                                          // every wave is done with the rings
+  constexpr int ORS = ROWB + 16;                                            // padded row stride of the parked O rows
+  char* ost = smem + wave * (64 * ORS);
+  const bool wide_store = (((uintptr_t)out_base & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
+  sfor<2>([&](auto SB) __attribute__((always_inline)) {
+    constexpr int sb = decltype(SB)::value;
+    float l = ps0[sb] + ps1[sb];
+    l += lane_xor32(l);
+    if (lse_base && row_ok[sb] && half == 0)    // P = exp2(score - m_ref): the sum is relative to the reference maximum
+      lse_base[(int64_t)(q_start + tok_local[sb]) * p.lse_stride_token + hq[sb]] = l > 0.0f ? (m_ref[sb] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+    const float inv = (row_ok[sb] && l > 0.0f) ? 1.0f / l : 0.0f;
+    uint16_t* op = out_base + (int64_t)(q_start + tok_local[sb]) * p.out_stride_token + (int64_t)hq[sb] * p.out_stride_head + 4 * half;
+    sfor<4>([&](auto B) __attribute__((always_inline)) {
+      sfor<4>([&](auto C) __attribute__((always_inline)) {
+        constexpr int b = decltype(B)::value, c = decltype(C)::value, base = kAO + 64 * sb + 16 * b + 4 * c;
+        const wu32x2_t w = {pw_pack<T>(acc_read<base>() * inv, acc_read<base + 1>() * inv), pw_pack<T>(acc_read<base + 2>() * inv, acc_read<base + 3>() * inv)};
+        if (wide_store) *(wu32x2_t*)(ost + (sb * 32 + qr) * ORS + (32 * b + 8 * c + 4 * half) * 2) = w;
+        else if (row_ok[sb]) *(wu32x2_t*)(op + 32 * b + 8 * c) = w;
+      });
+    });
+  });
+  if (wide_store) {
+    // O leaves as whole 256-byte rows, 16 bytes per lane (a lane's own 8-byte pieces touch 32 rows per store)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads other lanes' pieces back: LDS is in order per wave
+    const int orow = lane >> 4, och = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int r = 4 * j + orow;
+      const int m = wave * 64 + r;
+      const int tok = tok0 + m / G;
+      const wu32x4_t v = *(const wu32x4_t*)(ost + r * ORS + och * 16);
+      if (m < BQ * G && tok < q_len) {
+        wu32x4_t* dst = (wu32x4_t*)(out_base + (int64_t)(q_start + tok) * p.out_stride_token + (int64_t)(head * G + m % G) * p.out_stride_head + och * 8);
+        __builtin_nontemporal_store(v, dst);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static size_t pw_bt_lds_bytes(const mi355_attn_params& p) {
+  const size_t entries = ((size_t)std::max(p.max_seqlen_k, 1) + p.page_size - 1) / p.page_size;
+  return ((entries + 63) / 64) * 256;
+}
+constexpr size_t kPwLdsMax = (size_t)160 << 10;
+
+// Preconditions beyond prefill_supported(): head size 128, no soft-cap / ALiBi / sliding window, 16-bit cache,
+// G <= 256, the staged block-table prefix fits behind the rings.
+bool prefill_pw_applicable(const mi355_attn_params& p) {
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+  const int G = p.num_q_heads / p.num_kv_heads;
+  return !feat && p.head_size == 128 && G <= kPwRows && p.kv_dtype == p.q_dtype && kLdsBT + pw_bt_lds_bytes(p) <= kPwLdsMax;
+}
+
+template <typename T>
+static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, hipStream_t stream) {
+  PwArgs a;
+  a.p = p;
+  a.group = p.num_q_heads / p.num_kv_heads;
+  a.block_q = kPwRows / a.group;
+  a.page_shift = __builtin_ctz((unsigned)p.page_size);
+  a.key_splits = key_splits;
+  a.out_split_stride = out_split_stride;
+  a.lse_split_stride = lse_split_stride;
+  a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
+  a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
+  const int qblocks = p.num_tokens / a.block_q + p.num_seqs;   // static upper bound, as the reference (:886-889,:935-943)
+  const size_t lds = kLdsBT + pw_bt_lds_bytes(p);
+  // > 64 KiB of dynamic LDS needs the opt-in; set on every call (the attribute is per device and the call is cheap)
+  const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_pw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwLdsMax),
+                            "hipFuncSetAttribute(prefill_pw)");
+  if (rc0 != MI355_OK) return rc0;
+  hipLaunchKernelGGL((prefill_pw_kernel<T>), dim3(qblocks * p.num_kv_heads, key_splits), dim3(256), lds, stream, a);
+  const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");
+  if (rc == MI355_OK) set_kernel_name("prefill_mfma");
+  return rc;
+}
+
+int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, hipStream_t stream) {
+  return p.q_dtype == MI355_BF16 ? launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, stream)
+                                 : launch_pw_t<f16_t>(p, key_splits, out_split_stride, lse_split_stride, stream);
+}
+
+}  // namespace mi355
