@@ -17,7 +17,12 @@
 //     S, P, V fragments and the softmax state are ordinary VGPRs;
 //   * K/V tiles arrive by LDS-DMA with a SCALAR page base + one constant per-lane offset (global_load_lds with
 //     an SGPR address): wave w fetches the 16-key group w of every tile, i.e. one block-table entry per tile and
-//     matrix, no per-lane 64-bit address arithmetic; three-slot rings, K two tiles ahead, V one; counted vmcnt.
+//     matrix - read through the scalar cache one iteration before it is needed - and no per-lane 64-bit address
+//     arithmetic; three-slot rings, K two tiles ahead, V one; counted vmcnt;
+//   * a single wave issues in order, so every instruction of the loop costs issue time nobody else fills: the
+//     reference maximum starts at ZERO (bf16: P = 2^s is exact enough for |s| <= 32 and the accumulators are f32),
+//     so S^T starts from the inline constant 0 instead of from -m_ref in registers, and the per-tile check is one
+//     compare on a half-row maximum; rows that leave the range move their reference on a slow path as before.
 //
 // MFMA orientation, the in-register softmax, the deferred running maximum (C operand = -m_ref) and the LDS
 // swizzles are those of prefill_dma_kernel (prefill_mfma.hip).
@@ -42,8 +47,8 @@ constexpr float kPwDeferThr = 8.0f;  // log2 units a row's tile maximum may exce
 constexpr int kAO = 0;     // O^T[sb][b]  : kAO + 64 sb + 16 b   (16 registers)
 constexpr int kAQ = 128;   // Q'[sb][ks]  : kAQ + 32 sb + 4 ks   (4 registers)
 constexpr int kAK = 192;   // K[kb][ks]   : kAK + 32 kb + 4 ks   (4 registers)
-// LDS map: K ring (3 x 16 KiB), V ring (3 x 16 KiB), block-table prefix
-constexpr int kSlotBytes = 16384, kLdsK = 0, kLdsV = 3 * kSlotBytes, kLdsBT = 6 * kSlotBytes;
+// LDS map: K ring (3 x 16 KiB), V ring (3 x 16 KiB)
+constexpr int kSlotBytes = 16384, kLdsK = 0, kLdsV = 3 * kSlotBytes, kPwLds = 6 * kSlotBytes;
 
 struct PwArgs {
   mi355_attn_params p;
@@ -72,6 +77,10 @@ __device__ __forceinline__ float a_max3(float x, float y, float z) { float r; as
 template <typename T> struct pw_ops;
 #define MI355_DEF_PW_OPS(TAG, MFMA, CVT)                                                                          \
   template <> struct pw_ops<TAG> {                                                                                \
+    /* S(VGPR) = K(AGPR) . Q(AGPR) */                                                                              \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_zero(wf32x16_t& s) {                      \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));  \
+    }                                                                                                             \
     /* S(VGPR) += K(AGPR) . Q(AGPR) */                                                                             \
     template <int KA, int QA> static __device__ __forceinline__ void qk_acc(wf32x16_t& s) {                       \
       asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3)); \
@@ -113,10 +122,20 @@ template <int OFF> __device__ __forceinline__ wu32x2_t lds_tr_b64(uint32_t addr)
   return r;
 }
 // One LDS-DMA piece with a scalar base: lane l's 16 bytes from sbase + voff land at LDS lds_dst + 16 l.
+// (M0 is not saved: nothing else in this kernel uses it - tools/isa_audit.py checks the compiler's side.)
 __device__ __forceinline__ void pw_glds16(uint32_t voff, uint64_t sbase, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// 16-byte global load the compiler does not count: its own vmcnt waits would otherwise also wait for the LDS-DMA
+// issued behind it. The caller retires it with a counted s_waitcnt that names the destination.
+__device__ __forceinline__ wu32x4_t pw_gload16(const void* ptr) {
+  wu32x4_t r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+// one block-table entry through the scalar cache; lands before the iteration-end s_waitcnt lgkmcnt(0) that names it
+__device__ __forceinline__ void pw_sload(int& dst, uint64_t base, int byte_off) {
+  asm volatile("s_load_dword %0, %1, %2" : "=s"(dst) : "s"(base), "s"(byte_off) : "memory");
 }
 
 __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int num_seqs, int qblock, int block_q) {
@@ -132,6 +151,12 @@ template <typename T>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   using ops = pw_ops<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
+  // Reference maxima. bf16: a row keeps the reference 0 while its tile maxima stay in [-kLo, kHi] (log2 units):
+  // P = 2^s <= 2^32 is a bf16 with full relative precision and the f32 sums have 2^90 of headroom above it.
+  // f16 (P <= 65504, 2^-14 normal): the reference is the first tile's maximum and may be exceeded by 2^8, as in
+  // prefill_dma_kernel.
+  constexpr bool kAutoStart = __is_same(T, bf16_t);
+  constexpr float kHi = kAutoStart ? 32.0f : kPwDeferThr, kLo = 32.0f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   asm volatile("" ::: "a255");                 // the kernel owns all 256 accumulator registers
   const mi355_attn_params& p = a.p;
@@ -144,19 +169,11 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);   // heaviest first
   const int seq = pw_find_seq(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
   if (seq < 0) return;
-  // block-table prefix of the sequence -> LDS, fetched as soon as the sequence is known (bounded by max_seqlen_k)
-  const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
-  const int bt_last_any = ((max(p.max_seqlen_k, 1) + p.page_size - 1) >> a.page_shift) - 1;
-  const int* bt_lds = (const int*)(smem + kLdsBT);
-  for (int c = wave; c * 64 <= bt_last_any; c += 4) glds4(bt + min(c * 64 + lane, bt_last_any), lds_addr(bt_lds) + c * 256);
   const int q_start = p.cu_seqlens_q[seq];
   const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
   const int qb_local = qblock - (q_start / BQ + seq);
   const int seq_len = p.seqused_k[seq];
-  if (qb_local * BQ >= q_len || (p.skip_decodes && q_len == 1) || (p.only_decodes && q_len != 1)) {
-    glds_wait_all();                           // never leave with a DMA into this workgroup's LDS in flight
-    return;
-  }
+  if (qb_local * BQ >= q_len || (p.skip_decodes && q_len == 1) || (p.only_decodes && q_len != 1)) return;
   const int ctx_len = seq_len - q_len;
   const int tok0 = qb_local * BQ;
 
@@ -192,57 +209,57 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   for (int sb = 0; sb < 2; ++sb) {
     const uint16_t* qp = (const uint16_t*)p.q + (int64_t)(q_start + min(tok_local[sb], q_len - 1)) * p.q_stride_token + (int64_t)hq[sb] * p.q_stride_head + 8 * half;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qraw[sb][ks] = *(const wu32x4_t*)(qp + 16 * ks);
+    for (int ks = 0; ks < 8; ++ks) qraw[sb][ks] = pw_gload16(qp + 16 * ks);
   }
 
   // ---- LDS-DMA constants: wave w stages key rows 16 w .. 16 w + 15 of every tile, four rows per instruction -
   const char* kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
   const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
-  const int staged_keys = (bt_last_any + 1) << a.page_shift;          // keys the staged block-table prefix covers
-  const int last_group = (max(min(n_keys_wg, staged_keys), 1) - 1) >> 4;
+  const int last_group = (max(n_keys_wg, 1) - 1) >> 4;                   // last 16-key group this Q block can see
   const int page_mask = p.page_size - 1;
   const uint32_t ksb = a.k_slot_stride * 2, vsb = a.v_slot_stride * 2;   // bytes between key rows of a page
   const uint32_t kpb = a.k_page_stride * 2, vpb = a.v_page_stride * 2;   // bytes between pages
   const int r4 = lane >> 4, c16 = lane & 15;
-  // LDS row R = 4 i + r4 of the group, chunk position c16 holds logical chunk c16 ^ f(R) (swizzle on the source side)
-  auto k_src_off = [&](int i, int maxr) -> uint32_t {
-    const int R = 4 * i + r4;
-    return (uint32_t)(min(R, maxr) * (int)ksb + ((c16 ^ R) << 4));
-  };
-  auto v_src_off = [&](int i, int maxr) -> uint32_t {
-    const int R = 4 * i + r4;
-    return (uint32_t)(min(R, maxr) * (int)vsb + ((c16 ^ (((R & 3) << 2) | ((R >> 2) & 3))) << 4));
-  };
+  // LDS row R = 4 i + r4 of the group, chunk position c16 holds logical chunk c16 ^ f(R) (swizzle on the source side);
+  // rows past the sequence (R > maxr, last group only) re-read row maxr: finite data under a zero probability
   uint32_t koff[4], voff[4];
+  auto set_k_offsets = [&](int maxr) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { koff[i] = k_src_off(i, 15); voff[i] = v_src_off(i, 15); }
+    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + ((c16 ^ R) << 4)); }
+  };
+  auto set_v_offsets = [&](int maxr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + ((c16 ^ (((R & 3) << 2) | ((R >> 2) & 3))) << 4)); }
+  };
+  set_k_offsets(15);
+  set_v_offsets(15);
+  bool k_tail = false, v_tail = false;           // offsets already clamped for the sequence's last, partial group
   const uint32_t lds_wave = (uint32_t)(wave * 4096);
-
-  // scalar side of one (tile, matrix): block-table entry of the wave's 16-key group -> 64-bit base of its first row.
-  // Tiles past the share re-fetch its last tile (never read; keeps the DMA count per iteration fixed).
-  auto dma_setup = [&](int tile, auto ISV, uint64_t& base, int& maxr) {
+  uint64_t bt64;
+  {
+    const uint64_t b = (uint64_t)(p.block_table + (int64_t)seq * p.block_table_stride);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    bt64 = ((uint64_t)hi << 32) | lo;
+  }
+  // 16-key group of wave w in `tile` (tiles past the share repeat its last tile: never read, keeps the DMA count
+  // per iteration fixed), its first key, the byte offset of its block-table entry
+  auto group_key0 = [&](int tile) { return min(min(tile, tile_hi - 1) * 4 + wave, last_group) << 4; };
+  auto entry_off = [&](int tile) { return __builtin_amdgcn_readfirstlane((group_key0(tile) >> a.page_shift) << 2); };
+  // block-table entry -> 64-bit address of the group's first key row
+  auto group_base = [&](int tile, int page, auto ISV) {
     constexpr bool isv = decltype(ISV)::value != 0;
-    const int g = min(min(tile, tile_hi - 1) * 4 + wave, last_group);
-    const int key0 = g << 4;
-    const int page = __builtin_amdgcn_readfirstlane(bt_lds[key0 >> a.page_shift]);
-    const uint32_t slot0 = (uint32_t)(key0 & page_mask);
+    const uint32_t slot0 = (uint32_t)(group_key0(tile) & page_mask);
     const uint64_t b = (uint64_t)(isv ? vbase : kbase) + (uint64_t)(uint32_t)page * (isv ? vpb : kpb) + (uint64_t)slot0 * (isv ? vsb : ksb);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-    base = ((uint64_t)hi << 32) | lo;
-    maxr = seq_len - 1 - key0;                 // rows past it are beyond the sequence: they re-read row maxr (finite data)
+    return ((uint64_t)hi << 32) | lo;
   };
-  auto dma_piece = [&](auto ISV, int i, uint32_t off_const, uint64_t base, int maxr, uint32_t lds_dst) {
+  // the sequence ends inside this group (only ever its last one, and every later fetch repeats it): clamp the rows once
+  auto tail_check = [&](int tile, auto ISV) {
     constexpr bool isv = decltype(ISV)::value != 0;
-    uint32_t off = off_const;
-    if (maxr < 15) off = isv ? v_src_off(i, max(maxr, 0)) : k_src_off(i, max(maxr, 0));   // wave-uniform, last group only
-    pw_glds16(off, base, lds_dst + lds_wave + i * 1024);
-  };
-  auto dma_group = [&](int tile, auto ISV, uint32_t lds_dst) {
-    constexpr bool isv = decltype(ISV)::value != 0;
-    uint64_t base; int maxr;
-    dma_setup(tile, ISV, base, maxr);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(ISV, i, isv ? voff[i] : koff[i], base, maxr, lds_dst);
+    const int maxr = seq_len - 1 - group_key0(tile);
+    if (maxr < 15 && !(isv ? v_tail : k_tail)) {
+      if (isv) { set_v_offsets(maxr); v_tail = true; } else { set_k_offsets(maxr); k_tail = true; }
+    }
   };
 
   // ---- per-lane LDS read addresses (swizzle folded in) ----------------------------------------------
@@ -263,19 +280,33 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     v_rd1[b] = (uint32_t)(kLdsV + r1 * ROWB + ((lc ^ f1) << 4) + 8 * (pp & 1));
   }
 
-  // ---- the block table has landed; first tiles on their way ------------------------------------------
-  glds_wait_all();
-  __syncthreads();
+  // ---- first tiles on their way: K0 K1 V0 | K2 V1 (the issue order fixes the counted waits below) -----
+  int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration
   if (tile_hi > tile_lo) {
-    // issue order fixes the counted waits below: K0 K1 V0 | K2 V1
-    dma_group(tile_lo, ic<0>{}, kLdsK);
-    dma_group(tile_lo + 1, ic<0>{}, kLdsK + kSlotBytes);
-    dma_group(tile_lo, ic<1>{}, kLdsV);
-    dma_group(tile_lo + 2, ic<0>{}, kLdsK + 2 * kSlotBytes);
-    dma_group(tile_lo + 1, ic<1>{}, kLdsV + kSlotBytes);
+    int pk0, pk1, pk2, pv0, pv1, unused;
+    scalar_load4((const int32_t*)bt64, entry_off(tile_lo) >> 2, entry_off(tile_lo + 1) >> 2, entry_off(tile_lo + 2) >> 2, entry_off(tile_lo + 3) >> 2, pk0, pk1, pk2, pg_k);
+    pv0 = pk0; pv1 = pk1; pg_v = pk2; unused = 0; (void)unused;     // K and V share the block table
+    auto group = [&](int tile, int page, auto ISV, uint32_t lds_dst) {
+      constexpr bool isv = decltype(ISV)::value != 0;
+      tail_check(tile, ISV);
+      const uint64_t base = group_base(tile, page, ISV);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pw_glds16(isv ? voff[i] : koff[i], base, lds_dst + lds_wave + i * 1024);
+    };
+    group(tile_lo, pk0, ic<0>{}, kLdsK);
+    group(tile_lo + 1, pk1, ic<0>{}, kLdsK + kSlotBytes);
+    group(tile_lo, pv0, ic<1>{}, kLdsV);
+    group(tile_lo + 2, pk2, ic<0>{}, kLdsK + 2 * kSlotBytes);
+    group(tile_lo + 1, pv1, ic<1>{}, kLdsV + kSlotBytes);
   }
+  sfor<128>([&](auto I) { acc_zero<kAO + decltype(I)::value>(); });
 
   // ---- Q' = Q * scale * log2(e), packed, into accumulator registers -----------------------------------
+  // the 16 Q loads are older than the (at most 20) LDS-DMA pieces behind them
+  asm volatile("s_waitcnt vmcnt(20)"
+               : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[0][4]), "+v"(qraw[0][5]), "+v"(qraw[0][6]), "+v"(qraw[0][7]),
+                 "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]), "+v"(qraw[1][4]), "+v"(qraw[1][5]), "+v"(qraw[1][6]), "+v"(qraw[1][7])
+               :: "memory");
   const float scale2 = p.scale * kPwLog2e;
   sfor<2>([&](auto SB) {
     sfor<8>([&](auto KS) {
@@ -287,11 +318,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       });
     });
   });
-  sfor<128>([&](auto I) { acc_zero<kAO + decltype(I)::value>(); });
 
   // ---- state -------------------------------------------------------------------------------------------
   wf32x16_t S[2][2];          // [sub-block][32-key block]: S^T - m_ref of the tile in flight
-  float cneg[2] = {0.0f, 0.0f};   // -m_ref: every S register starts from it (the MFMA chain accumulates on top)
+  float cneg[2] = {0.0f, 0.0f};   // -m_ref of this lane's rows
+  bool zmode[2] = {true, true};   // wave-uniform: every row of the sub-block still has the reference 0 -> S^T starts from the constant 0
+  bool all_started[2] = {false, false};   // wave-uniform: every row has a reference (first tile done)
   uint32_t pw[2][16];         // P^T as packed pairs; dwords 4 sk .. 4 sk + 3 = B operand of k-step sk
   wu32x4_t vfr[4][4];         // transposed V fragments [output block b][k-step sk]
   float e0[2][16], e1[2][16], tmax[2][2][8];
@@ -301,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { S[x][0][r] = x == 0 ? 0.0f : -INFINITY; S[x][1][r] = -INFINITY; pw[x][r] = 0u; e0[x][r] = 0.0f; e1[x][r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) { S[x][0][r] = -INFINITY; S[x][1][r] = -INFINITY; pw[x][r] = 0u; e0[x][r] = 0.0f; e1[x][r] = 0.0f; }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -313,15 +345,22 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
 
   // ---- the pieces of an iteration ------------------------------------------------------------------------
-  // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7
+  // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7. A chain starts from the constant 0 when every row of
+  // the sub-block has the reference 0, else from -m_ref moved into the (free) S registers first.
   auto qk = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kb = g >> 3, ks = g & 7;
-    ops::template qk_acc<kAK + 32 * kb + 4 * ks, kAQ + 32 * x + 4 * ks>(S[x][kb]);
-  };
-  // S_x[kb][r] = -m_ref ahead of its MFMA chain (the registers are free: the previous tile's exponentials are done)
-  auto sinit = [&](auto X, auto KB, auto RC) __attribute__((always_inline)) {
-    constexpr int x = decltype(X)::value, kb = decltype(KB)::value, r = decltype(RC)::value;
-    S[x][kb][r] = a_mov(cneg[x]);
+    constexpr int KA = kAK + 32 * kb + 4 * ks, QA = kAQ + 32 * x + 4 * ks;
+    if constexpr (ks == 0) {
+      if (zmode[x]) {
+        ops::template qk_zero<KA, QA>(S[x][kb]);
+      } else {
+        sfor<16>([&](auto RC) __attribute__((always_inline)) { S[x][kb][decltype(RC)::value] = a_mov(cneg[x]); });
+        asm volatile("s_nop 1");
+        ops::template qk_acc<KA, QA>(S[x][kb]);
+      }
+    } else {
+      ops::template qk_acc<KA, QA>(S[x][kb]);
+    }
   };
   // MFMA g of O_x += V^T.P_x^T: output block g >> 2, k-step g & 3
   auto pv = [&](auto X, auto GC) __attribute__((always_inline)) {
@@ -353,17 +392,16 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       else pw[x][j] = ops::cvt(e0[x][j], e1[x][j]);
     });
   };
-  // after both 32-key maxima: does every row of sub-block x keep its reference maximum? (almost always: yes)
+  // after both 32-key maxima: may every row of sub-block x keep its reference? (almost always: one compare on this
+  // half-wave's maximum; the other half of the row sits in the other half-wave and is covered by the wave-wide vote)
   auto decide = [&](auto X, int t, bool need_mask) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value;
-    float mx = a_max(tmax[x][0][7], tmax[x][1][7]);
-    asm volatile("s_nop 1" : "+v"(mx));          // VALU write -> v_permlane read
-    mx = fmaxf(mx, lane_xor32(mx));              // the other half-wave holds the row's other 32 keys
-    bool calm = started[x] && mx <= kPwDeferThr;
-    if (need_mask || !__all(calm)) {
+    const float mxh = a_max(tmax[x][0][7], tmax[x][1][7]);
+    if (need_mask || !all_started[x] || !__all(mxh <= kHi)) {
       const int key_base = t * kPwTile;
+      float m2 = mxh;
       if (need_mask) {                           // tile straddles the causal diagonal or the sequence end
-        float m2 = -INFINITY;
+        m2 = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -372,12 +410,15 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
             S[x][kb][r] = key <= lim[x] ? S[x][kb][r] : -INFINITY;
             m2 = fmaxf(m2, S[x][kb][r]);
           }
-        mx = fmaxf(m2, lane_xor32(m2));
-        calm = started[x] && mx <= kPwDeferThr;
       }
+      const float mx = fmaxf(m2, lane_xor32(m2));   // the other half-wave holds the row's other 32 keys
+      const bool seen = mx > -INFINITY;
+      // the reference stays: started rows below the ceiling; bf16 rows that start inside [-kLo, kHi] keep 0
+      const bool calm = mx <= kHi && (started[x] || !seen || (kAutoStart && mx >= -kLo));
+      started[x] = started[x] || seen;
+      all_started[x] = __all(started[x]);
       if (!__all(calm)) {                        // move the reference of the rows that need it
-        const float upd = (!calm && mx > -INFINITY) ? mx : 0.0f;
-        started[x] = started[x] || (mx > -INFINITY);
+        const float upd = (!calm && seen) ? mx : 0.0f;
         m_ref[x] += upd;
         const float alpha = __builtin_amdgcn_exp2f(-upd);
 #pragma unroll
@@ -385,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) S[x][kb][r] -= upd;
         cneg[x] = -m_ref[x];
+        zmode[x] = __all(m_ref[x] == 0.0f);
         ps0[x] *= alpha;
         ps1[x] *= alpha;
         if (t != tile_lo) {                      // O_x is idle here: its last MFMA retired half an iteration ago
@@ -422,24 +464,26 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     constexpr int KD = kLdsK + (it % 3) * kSlotBytes;          // K(t+3) goes where K(t) was
     constexpr int VD = kLdsV + ((it + 2) % 3) * kSlotBytes;    // V(t+2) goes where V(t-1) was
     const bool need_mask = (t * kPwTile + kPwTile - 1 > ctx_len + w_tok_lo) || (t * kPwTile + kPwTile > seq_len);
-    uint64_t kb64 = 0, vb64 = 0;
-    int kmaxr = 15, vmaxr = 15;
+    // scalar side of this iteration's LDS-DMA (entries fetched during the previous iteration), and the fetch of the
+    // next iteration's entries (they land before the wait that ends this one)
+    tail_check(t + 3, ic<0>{});
+    tail_check(t + 2, ic<1>{});
+    const uint64_t kb64 = group_base(t + 3, pg_k, ic<0>{}), vb64 = group_base(t + 2, pg_v, ic<1>{});
+    pw_sload(pg_k, bt64, entry_off(t + 4));
+    pw_sload(pg_v, bt64, entry_off(t + 3));
     // ---- segment 1 -------------------------------------------------------------------------------------
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       qk(ic<0>{}, GC);
-      if constexpr (g < 8) { sinit(ic<0>{}, ic<1>{}, ic<2 * g>{}); sinit(ic<0>{}, ic<1>{}, ic<2 * g + 1>{}); }
       estream(ic<1>{}, ic<12 + g>{});
       if constexpr (g >= 10 && g < 14) { maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10)>{}); maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10) + 1>{}); }
-      if constexpr (g == 0) { dma_setup(t + 3, ic<0>{}, kb64, kmaxr); dma_setup(t + 2, ic<1>{}, vb64, vmaxr); }
-      if constexpr (g >= 3 && g < 7) dma_piece(ic<0>{}, g - 3, koff[g - 3], kb64, kmaxr, KD);
-      if constexpr (g >= 7 && g < 11) dma_piece(ic<1>{}, g - 7, voff[g - 7], vb64, vmaxr, VD);
+      if constexpr (g >= 2 && g < 6) pw_glds16(koff[g - 2], kb64, KD + lds_wave + (g - 2) * 1024);
+      if constexpr (g >= 6 && g < 10) pw_glds16(voff[g - 6], vb64, VD + lds_wave + (g - 6) * 1024);
     });
     // ---- segment 2 -------------------------------------------------------------------------------------
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       pv(ic<1>{}, GC);
-      sinit(ic<1>{}, ic<0>{}, GC);
       if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<0>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
       if constexpr (g == 3) decide(ic<0>{}, t, need_mask);
       if constexpr (g >= 4) { estream(ic<0>{}, ic<g - 4>{}); vread(ic<((g - 4) >> 2)>{}, ic<((g - 4) & 3)>{}, ic<VR>{}); }
@@ -448,7 +492,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       qk(ic<1>{}, GC);
-      if constexpr (g < 8) { sinit(ic<1>{}, ic<1>{}, ic<2 * g>{}); sinit(ic<1>{}, ic<1>{}, ic<2 * g + 1>{}); }
       estream(ic<0>{}, ic<12 + g>{});
       if constexpr (g >= 10 && g < 14) { maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10)>{}); maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10) + 1>{}); }
       if constexpr (g < 4) vread(ic<3>{}, GC, ic<VR>{});
@@ -462,15 +505,14 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       pv(ic<0>{}, GC);
-      sinit(ic<0>{}, ic<0>{}, GC);
       if constexpr (g == 0) kread(ic<15>{}, ic<KR>{});
       if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<1>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
       if constexpr (g == 3) decide(ic<1>{}, t, need_mask);
       if constexpr (g >= 4) estream(ic<1>{}, ic<g - 4>{});
     });
-    // K(t+1) is in its registers; K(t+2) and V(t+1) (issued one iteration ago) have landed, this iteration's 8
-    // pieces may stay in flight; everyone is done reading K(t+1)'s and V(t)'s slots
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    // K(t+1) is in its registers and the next block-table entries in theirs; K(t+2) and V(t+1) (issued one iteration
+    // ago) have landed, this iteration's 8 pieces may stay in flight; everyone is done reading K(t+1)'s and V(t)'s slots
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k), "+s"(pg_v) :: "memory");
   };
 
   if (tile_hi > tile_lo) {
@@ -537,18 +579,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static size_t pw_bt_lds_bytes(const mi355_attn_params& p) {
-  const size_t entries = ((size_t)std::max(p.max_seqlen_k, 1) + p.page_size - 1) / p.page_size;
-  return ((entries + 63) / 64) * 256;
-}
-constexpr size_t kPwLdsMax = (size_t)160 << 10;
 
-// Preconditions beyond prefill_supported(): head size 128, no soft-cap / ALiBi / sliding window, 16-bit cache,
-// G <= 256, the staged block-table prefix fits behind the rings.
+// Preconditions beyond prefill_supported(): head size 128, no soft-cap / ALiBi / sliding window, 16-bit cache, G <= 256.
 bool prefill_pw_applicable(const mi355_attn_params& p) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  return !feat && p.head_size == 128 && G <= kPwRows && p.kv_dtype == p.q_dtype && kLdsBT + pw_bt_lds_bytes(p) <= kPwLdsMax;
+  return !feat && p.head_size == 128 && G <= kPwRows && p.kv_dtype == p.q_dtype;
 }
 
 template <typename T>
@@ -564,9 +600,9 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;   // static upper bound, as the reference (:886-889,:935-943)
-  const size_t lds = kLdsBT + pw_bt_lds_bytes(p);
+  const size_t lds = kPwLds;
   // > 64 KiB of dynamic LDS needs the opt-in; set on every call (the attribute is per device and the call is cheap)
-  const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_pw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwLdsMax),
+  const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_pw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwLds),
                             "hipFuncSetAttribute(prefill_pw)");
   if (rc0 != MI355_OK) return rc0;
   hipLaunchKernelGGL((prefill_pw_kernel<T>), dim3(qblocks * p.num_kv_heads, key_splits), dim3(256), lds, stream, a);
