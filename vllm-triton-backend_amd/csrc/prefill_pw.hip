@@ -147,6 +147,19 @@ __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int n
   return left - 1;
 }
 
+// Diagnostic build only (-DMI355_PW_STAMP, tools/pw_clock.py): shader-cycle sums of the tile loop's segments.
+#ifdef MI355_PW_STAMP
+#define PW_SEG_STAMP(idx)                                                                   \
+  do {                                                                                      \
+    unsigned long long st_now;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now) :: "memory");        \
+    st_sum[idx] += (unsigned)st_now - st_last;                                              \
+    st_last = (unsigned)st_now;                                                             \
+  } while (0)
+#else
+#define PW_SEG_STAMP(idx) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   using ops = pw_ops<T>;
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto tail_check = [&](int tile, auto ISV) {
     constexpr bool isv = decltype(ISV)::value != 0;
     const int maxr = seq_len - 1 - group_key0(tile);
-    if (maxr < 15 && !(isv ? v_tail : k_tail)) {
+    if (__builtin_expect(maxr < 15 && !(isv ? v_tail : k_tail), 0)) {
       if (isv) { set_v_offsets(maxr); v_tail = true; } else { set_k_offsets(maxr); k_tail = true; }
     }
   };
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   }
 
   // ---- first tiles on their way: K0 K1 V0 | K2 V1 (the issue order fixes the counted waits below) -----
-  int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration
+  int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration (V's = K's of one iteration earlier)
   if (tile_hi > tile_lo) {
     int pk0, pk1, pk2, pv0, pv1, unused;
     scalar_load4((const int32_t*)bt64, entry_off(tile_lo) >> 2, entry_off(tile_lo + 1) >> 2, entry_off(tile_lo + 2) >> 2, entry_off(tile_lo + 3) >> 2, pk0, pk1, pk2, pg_k);
@@ -345,17 +358,29 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
 
   // ---- the pieces of an iteration ------------------------------------------------------------------------
+  // S_x[kb] before its MFMA chain, when it cannot start from the constant 0: -m_ref of the row, or -inf for the keys
+  // the row must not see (tiles on the causal diagonal / at the sequence end). S is never modified after its chain.
+  auto s_init = [&](auto X, auto KB, int t, bool need_mask) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value, kb = decltype(KB)::value;
+    if (need_mask) {
+      const int rel = lim[x] - t * kPwTile - 32 * kb - 4 * half;     // visible: (r & 3) + 8 (r >> 2) <= rel
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[x][kb][r] = ((r & 3) + 8 * (r >> 2) <= rel) ? cneg[x] : -INFINITY;
+    } else {
+      sfor<16>([&](auto RC) __attribute__((always_inline)) { S[x][kb][decltype(RC)::value] = a_mov(cneg[x]); });
+    }
+    asm volatile("s_nop 1");      // VALU write -> MFMA read
+  };
   // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7. A chain starts from the constant 0 when every row of
-  // the sub-block has the reference 0, else from -m_ref moved into the (free) S registers first.
-  auto qk = [&](auto X, auto GC) __attribute__((always_inline)) {
+  // the sub-block has the reference 0 and sees every key of the tile, else from s_init.
+  auto qk = [&](auto X, auto GC, int t, bool need_mask) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kb = g >> 3, ks = g & 7;
     constexpr int KA = kAK + 32 * kb + 4 * ks, QA = kAQ + 32 * x + 4 * ks;
     if constexpr (ks == 0) {
-      if (zmode[x]) {
+      if (__builtin_expect(zmode[x] && !need_mask, 1)) {
         ops::template qk_zero<KA, QA>(S[x][kb]);
       } else {
-        sfor<16>([&](auto RC) __attribute__((always_inline)) { S[x][kb][decltype(RC)::value] = a_mov(cneg[x]); });
-        asm volatile("s_nop 1");
+        s_init(X, ic<kb>{}, t, need_mask);
         ops::template qk_acc<KA, QA>(S[x][kb]);
       }
     } else {
@@ -371,6 +396,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // result needs 12 issue slots to become readable and hipcc pads nothing around an asm MFMA)
   auto maxop = [&](auto X, auto KB, auto OC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, kb = decltype(KB)::value, o = decltype(OC)::value;
+#ifdef PW_ABL_MAX
+    return;
+#endif
     const wf32x16_t& s = S[x][kb];
     float* tm = tmax[x][kb];
     if constexpr (o < 5) tm[o] = a_max3(s[3 * o], s[3 * o + 1], s[3 * o + 2]);
@@ -378,40 +406,36 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     else if constexpr (o == 6) tm[6] = a_max3(tm[2], tm[3], tm[4]);
     else tm[7] = a_max(tm[5], tm[6]);
   };
-  // exponentials, row sums and packing of sub-block x: 80 instructions (16 pairs x {exp, exp, add, add, cvt}) dealt
-  // evenly over a window of 28 MFMA gaps. A transcendental's result is never read by the next instruction.
+  // exponentials, row sums and packing of sub-block x: 80 instructions (8 x {4 exp, then per pair add, add, cvt}) dealt
+  // evenly over a window of 28 MFMA gaps. Every result is read at least three instructions after it is written:
+  // hipcc pads an asm statement that reads a register the previous two statements wrote (and a transcendental's
+  // result must not be read by the next instruction anyway).
   auto estream = [&](auto X, auto WC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, w = decltype(WC)::value;
     constexpr int n0 = w * 80 / 28, n1 = (w + 1) * 80 / 28;
+#ifdef PW_ABL_E
+    return;
+#endif
     sfor<n1 - n0>([&](auto NC) __attribute__((always_inline)) {
-      constexpr int n = n0 + decltype(NC)::value, j = n / 5, k = n % 5, kb = j >> 3, r = 2 * (j & 7);
-      if constexpr (k == 0) e0[x][j] = a_exp2(S[x][kb][r]);
-      else if constexpr (k == 1) e1[x][j] = a_exp2(S[x][kb][r + 1]);
-      else if constexpr (k == 2) ps0[x] = a_add(ps0[x], e0[x][j]);
-      else if constexpr (k == 3) ps1[x] = a_add(ps1[x], e1[x][j]);
+      constexpr int n = n0 + decltype(NC)::value, q = n / 10, k = n % 10;
+      constexpr int j = 2 * q + (k < 4 ? (k >> 1) : (k >= 7 ? 1 : 0)), kb = j >> 3, r = 2 * (j & 7);
+      if constexpr (k == 0 || k == 2) e0[x][j] = a_exp2(S[x][kb][r]);
+      else if constexpr (k == 1 || k == 3) e1[x][j] = a_exp2(S[x][kb][r + 1]);
+      else if constexpr (k == 4 || k == 7) ps0[x] = a_add(ps0[x], e0[x][j]);
+      else if constexpr (k == 5 || k == 8) ps1[x] = a_add(ps1[x], e1[x][j]);
       else pw[x][j] = ops::cvt(e0[x][j], e1[x][j]);
     });
   };
   // after both 32-key maxima: may every row of sub-block x keep its reference? (almost always: one compare on this
   // half-wave's maximum; the other half of the row sits in the other half-wave and is covered by the wave-wide vote)
+  // If a reference has to move, S_x(t) is COMPUTED AGAIN from K(t), which is still in its registers, on top of the new
+  // -m_ref: nothing the fast path keeps in registers is modified in place (an in-place fix would put copies of all of S
+  // on the fast path: hipcc cannot merge the two versions otherwise).
   auto decide = [&](auto X, int t, bool need_mask) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value;
     const float mxh = a_max(tmax[x][0][7], tmax[x][1][7]);
-    if (need_mask || !all_started[x] || !__all(mxh <= kHi)) {
-      const int key_base = t * kPwTile;
-      float m2 = mxh;
-      if (need_mask) {                           // tile straddles the causal diagonal or the sequence end
-        m2 = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-            S[x][kb][r] = key <= lim[x] ? S[x][kb][r] : -INFINITY;
-            m2 = fmaxf(m2, S[x][kb][r]);
-          }
-      }
-      const float mx = fmaxf(m2, lane_xor32(m2));   // the other half-wave holds the row's other 32 keys
+    if (__builtin_expect(!all_started[x] || !__all(mxh <= kHi), 0)) {
+      const float mx = fmaxf(mxh, lane_xor32(mxh));   // the other half-wave holds the row's other 32 keys
       const bool seen = mx > -INFINITY;
       // the reference stays: started rows below the ceiling; bf16 rows that start inside [-kLo, kHi] keep 0
       const bool calm = mx <= kHi && (started[x] || !seen || (kAutoStart && mx >= -kLo));
@@ -421,10 +445,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         const float upd = (!calm && seen) ? mx : 0.0f;
         m_ref[x] += upd;
         const float alpha = __builtin_amdgcn_exp2f(-upd);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) S[x][kb][r] -= upd;
         cneg[x] = -m_ref[x];
         zmode[x] = __all(m_ref[x] == 0.0f);
         ps0[x] *= alpha;
@@ -436,26 +456,44 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
             acc_write<idx>(__builtin_bit_cast(uint32_t, o));
           });
         }
+        sfor<2>([&](auto KB) __attribute__((always_inline)) {
+          constexpr int kb = decltype(KB)::value;
+          s_init(X, KB, t, need_mask);
+          sfor<8>([&](auto KS) __attribute__((always_inline)) {
+            constexpr int ks = decltype(KS)::value;
+            ops::template qk_acc<kAK + 32 * kb + 4 * ks, kAQ + 32 * x + 4 * ks>(S[x][kb]);
+          });
+        });
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S[x][0]), "+v"(S[x][1]));   // MFMA result -> VALU read
       }
     }
   };
   // LDS reads. V(t)[b][sk]: two transposed 8-byte reads into one 4-register fragment
   auto vread = [&](auto B, auto SK, auto SLOT) __attribute__((always_inline)) {
     constexpr int b = decltype(B)::value, sk = decltype(SK)::value, off = decltype(SLOT)::value + sk * 16 * ROWB;
+#ifdef PW_ABL_LDS
+    return;
+#endif
     const wu32x2_t v0 = lds_tr_b64<off>(v_rd0[b]);
     const wu32x2_t v1 = lds_tr_b64<off>(v_rd1[b]);
     vfr[b][sk] = wu32x4_t{v0[0], v0[1], v1[0], v1[1]};
   };
   auto kread = [&](auto NC, auto SLOT) __attribute__((always_inline)) {
     constexpr int n = decltype(NC)::value, kb = n >> 3, ks = n & 7;
+#ifdef PW_ABL_LDS
+    return;
+#endif
     lds_to_acc_b128<kAK + 32 * kb + 4 * ks, decltype(SLOT)::value + kb * 32 * ROWB>(k_rd[ks]);
   };
 
+#ifdef MI355_PW_STAMP
+  unsigned st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
+#endif
   // One iteration = one KV tile t. Matrix pipe: S_A(t) | O_B += P_B(t-1) | S_B(t) | O_A += P_A(t); beside it, per gap:
   //   seg 1: B(t-1) exponentials (second half) . A's first 32-key maximum . LDS-DMA of K(t+3), V(t+2)
   //   seg 2: A's second maximum, decision, A exponentials . V(t) fragment reads as V(t-1)'s registers retire
-  //   seg 3: A exponentials (second half) . B's first maximum . K(t+1) fragment reads as K(t)'s registers retire
-  //   seg 4: B's second maximum, decision, B exponentials
+  //   seg 3: A exponentials (second half) . B's first maximum
+  //   seg 4: B's second maximum, decision, B exponentials . K(t+1) fragment reads (K(t) is kept until B's decision)
   // IT = (t - tile_lo) % 3 picks the ring slots at compile time.
   auto iteration = [&](auto ITC, int t) __attribute__((always_inline)) {
     constexpr int it = decltype(ITC)::value;
@@ -469,50 +507,68 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     tail_check(t + 3, ic<0>{});
     tail_check(t + 2, ic<1>{});
     const uint64_t kb64 = group_base(t + 3, pg_k, ic<0>{}), vb64 = group_base(t + 2, pg_v, ic<1>{});
+    pg_v = pg_k;                                 // V(t+3) lives in the page of K(t+3)
     pw_sload(pg_k, bt64, entry_off(t + 4));
-    pw_sload(pg_v, bt64, entry_off(t + 3));
     // ---- segment 1 -------------------------------------------------------------------------------------
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
-      qk(ic<0>{}, GC);
+      qk(ic<0>{}, GC, t, need_mask);
+      if constexpr (g >= 10 && g < 14) maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10)>{});
       estream(ic<1>{}, ic<12 + g>{});
-      if constexpr (g >= 10 && g < 14) { maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10)>{}); maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10) + 1>{}); }
+      if constexpr (g >= 10 && g < 14) maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10) + 1>{});
+#ifndef PW_ABL_DMA
       if constexpr (g >= 2 && g < 6) pw_glds16(koff[g - 2], kb64, KD + lds_wave + (g - 2) * 1024);
       if constexpr (g >= 6 && g < 10) pw_glds16(voff[g - 6], vb64, VD + lds_wave + (g - 6) * 1024);
+#endif
     });
+    PW_SEG_STAMP(1);
     // ---- segment 2 -------------------------------------------------------------------------------------
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       pv(ic<1>{}, GC);
       if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<0>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
+#ifndef PW_ABL_MAX
       if constexpr (g == 3) decide(ic<0>{}, t, need_mask);
+#endif
       if constexpr (g >= 4) { estream(ic<0>{}, ic<g - 4>{}); vread(ic<((g - 4) >> 2)>{}, ic<((g - 4) & 3)>{}, ic<VR>{}); }
     });
+    PW_SEG_STAMP(2);
     // ---- segment 3 -------------------------------------------------------------------------------------
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
-      qk(ic<1>{}, GC);
+      qk(ic<1>{}, GC, t, need_mask);
+      if constexpr (g >= 10 && g < 14) maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10)>{});
       estream(ic<0>{}, ic<12 + g>{});
-      if constexpr (g >= 10 && g < 14) { maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10)>{}); maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10) + 1>{}); }
+      if constexpr (g >= 10 && g < 14) maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10) + 1>{});
       if constexpr (g < 4) vread(ic<3>{}, GC, ic<VR>{});
-      if constexpr (g >= 1) kread(ic<g - 1>{}, ic<KR>{});
     });
+    PW_SEG_STAMP(3);
     // ---- segment 4 -------------------------------------------------------------------------------------
-    // every V(t) fragment has landed: at most the 8 youngest LDS reads (K fragments) may still be out
-    asm volatile("s_waitcnt lgkmcnt(8)"
+    // every V(t) fragment has landed (the last ones were issued twelve gaps ago)
+    asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(vfr[0][0]), "+v"(vfr[0][1]), "+v"(vfr[0][2]), "+v"(vfr[0][3]), "+v"(vfr[1][0]), "+v"(vfr[1][1]), "+v"(vfr[1][2]), "+v"(vfr[1][3]),
                    "+v"(vfr[2][0]), "+v"(vfr[2][1]), "+v"(vfr[2][2]), "+v"(vfr[2][3]), "+v"(vfr[3][0]), "+v"(vfr[3][1]), "+v"(vfr[3][2]), "+v"(vfr[3][3]));
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       pv(ic<0>{}, GC);
-      if constexpr (g == 0) kread(ic<15>{}, ic<KR>{});
+      // K(t+1) into K(t)'s registers once B's decision is taken (a moved reference recomputes S_B(t) from K(t))
+      // (two per gap, the last one four gaps before the wait that ends the iteration)
+      if constexpr (g >= 4 && g < 12) { kread(ic<2 * (g - 4)>{}, ic<KR>{}); kread(ic<2 * (g - 4) + 1>{}, ic<KR>{}); }
       if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<1>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
+#ifndef PW_ABL_MAX
       if constexpr (g == 3) decide(ic<1>{}, t, need_mask);
+#endif
       if constexpr (g >= 4) estream(ic<1>{}, ic<g - 4>{});
     });
+    PW_SEG_STAMP(4);
     // K(t+1) is in its registers and the next block-table entries in theirs; K(t+2) and V(t+1) (issued one iteration
     // ago) have landed, this iteration's 8 pieces may stay in flight; everyone is done reading K(t+1)'s and V(t)'s slots
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k), "+s"(pg_v) :: "memory");
+#ifdef PW_ABL_DMA
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(pg_k) :: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k) :: "memory");
+#endif
+    PW_SEG_STAMP(5);
   };
 
   if (tile_hi > tile_lo) {
@@ -521,6 +577,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto NC) __attribute__((always_inline)) { kread(NC, ic<0>{}); });
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 0 is re-filled (K(tile_lo + 3)) in the first iteration
     int t = tile_lo;
+#ifdef MI355_PW_STAMP
+    // diagnostic build only (tools/pw_clock.py): shader cycles and 100 MHz ticks around the tile loop
+    unsigned long long st_c0, st_r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
+    st_last = (unsigned)st_c0;
+#endif
     while (true) {
       iteration(ic<0>{}, t);
       if (++t >= tile_hi) break;
@@ -529,6 +591,18 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       iteration(ic<2>{}, t);
       if (++t >= tile_hi) break;
     }
+#ifdef MI355_PW_STAMP
+    {
+      unsigned long long st_c1, st_r1;
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1) :: "memory");
+      unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
+      if (dbg && tid == 0) {
+        unsigned long long* rec = dbg + 8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
+        rec[0] = st_c1 - st_c0; rec[1] = st_r1 - st_r0; rec[2] = (unsigned long long)(tile_hi - tile_lo);
+        for (int i = 1; i < 6; ++i) rec[2 + i] = st_sum[i];
+      }
+    }
+#endif
     // drain: sub-block B of the last tile
     sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
     asm volatile("s_nop 1");
