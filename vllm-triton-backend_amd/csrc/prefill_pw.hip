@@ -71,6 +71,12 @@ __device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std
 __device__ __forceinline__ float a_exp2(float x) { float r; asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 __device__ __forceinline__ float a_add(float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ float a_max(float x, float y) { float r; asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ void a_exp2x2(float& r0, float& r1, float x0, float x1) {
+  asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
+}
+__device__ __forceinline__ void a_max3x2(float& r0, float& r1, float a0, float a1, float a2, float b0, float b1, float b2) {
+  asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %5, %6, %7" : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2));
+}
 __device__ __forceinline__ float a_mov(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 __device__ __forceinline__ float a_max3(float x, float y, float z) { float r; asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; }
 
@@ -91,6 +97,11 @@ template <typename T> struct pw_ops;
     }                                                                                                             \
     static __device__ __forceinline__ uint32_t cvt(float lo, float hi) {                                          \
       uint32_t r; asm volatile(CVT " %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r;                          \
+    }                                                                                                             \
+    /* two row sums and one packed pair in ONE statement (hipcc pads between statements, never inside one) */     \
+    static __device__ __forceinline__ void sum_pack(float& s0, float& s1, uint32_t& pk, float lo, float hi) {     \
+      asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\t" CVT " %2, %3, %4"                           \
+                   : "+v"(s0), "+v"(s1), "=&v"(pk) : "v"(lo), "v"(hi));                                             \
     }                                                                                                             \
   };
 MI355_DEF_PW_OPS(bf16_t, "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
@@ -392,38 +403,40 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, b = g >> 2, sk = g & 3;
     ops::template pv<kAO + 64 * x + 16 * b>(vfr[b][sk], wu32x4_t{pw[x][4 * sk], pw[x][4 * sk + 1], pw[x][4 * sk + 2], pw[x][4 * sk + 3]});
   };
-  // row maximum of S_x[kb], 8 instructions o = 0 .. 7 (issue >= 2 MFMAs after the chain's last MFMA: its
-  // result needs 12 issue slots to become readable and hipcc pads nothing around an asm MFMA)
-  auto maxop = [&](auto X, auto KB, auto OC) __attribute__((always_inline)) {
-    constexpr int x = decltype(X)::value, kb = decltype(KB)::value, o = decltype(OC)::value;
+  // row maximum of S_x[kb]: 8 instructions in 4 two-instruction statements i = 0 .. 3 (issue >= 2 MFMAs after the
+  // chain's last MFMA: its result needs 12 issue slots to become readable and hipcc pads nothing around an asm MFMA)
+  auto maxpair = [&](auto X, auto KB, auto IC) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value, kb = decltype(KB)::value, i = decltype(IC)::value;
 #ifdef PW_ABL_MAX
     return;
 #endif
     const wf32x16_t& s = S[x][kb];
     float* tm = tmax[x][kb];
-    if constexpr (o < 5) tm[o] = a_max3(s[3 * o], s[3 * o + 1], s[3 * o + 2]);
-    else if constexpr (o == 5) tm[5] = a_max3(tm[0], tm[1], s[15]);
-    else if constexpr (o == 6) tm[6] = a_max3(tm[2], tm[3], tm[4]);
-    else tm[7] = a_max(tm[5], tm[6]);
+    if constexpr (i == 0) a_max3x2(tm[0], tm[1], s[0], s[1], s[2], s[3], s[4], s[5]);
+    else if constexpr (i == 1) a_max3x2(tm[2], tm[3], s[6], s[7], s[8], s[9], s[10], s[11]);
+    else if constexpr (i == 2) a_max3x2(tm[4], tm[5], s[12], s[13], s[14], tm[0], tm[1], s[15]);
+    else asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_max_f32 %1, %5, %0" : "=&v"(tm[6]), "=&v"(tm[7]) : "v"(tm[2]), "v"(tm[3]), "v"(tm[4]), "v"(tm[5]));
   };
-  // exponentials, row sums and packing of sub-block x: 80 instructions (8 x {4 exp, then per pair add, add, cvt}) dealt
-  // evenly over a window of 28 MFMA gaps. Every result is read at least three instructions after it is written:
-  // hipcc pads an asm statement that reads a register the previous two statements wrote (and a transcendental's
-  // result must not be read by the next instruction anyway).
+  // exponentials, row sums and packing of sub-block x: 32 two- or three-instruction statements (per P word: exp exp,
+  // and a few blocks later add add cvt) dealt over a window of 28 MFMA gaps. One statement per block: hipcc pads
+  // BETWEEN asm statements (a statement that reads a register an earlier one wrote, with none of the compiler's own
+  // instructions between them), never inside one; a transcendental's result is read at least a gap after it was
+  // written. (Exponentials as plain builtins would draw no padding, but hipcc then moves them next to the asm MFMA
+  // whose result they read - it does not know the 12 issue slots that result needs - and measured slower as well.)
   auto estream = [&](auto X, auto WC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, w = decltype(WC)::value;
-    constexpr int n0 = w * 80 / 28, n1 = (w + 1) * 80 / 28;
+    constexpr int n0 = w * 32 / 28, n1 = (w + 1) * 32 / 28;
 #ifdef PW_ABL_E
     return;
 #endif
     sfor<n1 - n0>([&](auto NC) __attribute__((always_inline)) {
-      constexpr int n = n0 + decltype(NC)::value, q = n / 10, k = n % 10;
-      constexpr int j = 2 * q + (k < 4 ? (k >> 1) : (k >= 7 ? 1 : 0)), kb = j >> 3, r = 2 * (j & 7);
-      if constexpr (k == 0 || k == 2) e0[x][j] = a_exp2(S[x][kb][r]);
-      else if constexpr (k == 1 || k == 3) e1[x][j] = a_exp2(S[x][kb][r + 1]);
-      else if constexpr (k == 4 || k == 7) ps0[x] = a_add(ps0[x], e0[x][j]);
-      else if constexpr (k == 5 || k == 8) ps1[x] = a_add(ps1[x], e1[x][j]);
-      else pw[x][j] = ops::cvt(e0[x][j], e1[x][j]);
+      constexpr int n = n0 + decltype(NC)::value;
+      // block n: X X | X P X P ... X P | P P   (X = exponentials of a word, P = sum + pack of a word)
+      constexpr bool is_x = n < 2 || (n < 30 && ((n - 2) & 1) == 0);
+      constexpr int j = n < 2 ? n : n >= 30 ? 14 + (n - 30) : is_x ? 2 * (1 + (n - 2) / 4) + (((n - 2) >> 1) & 1) : 2 * ((n - 2) / 4) + (((n - 2) >> 1) & 1);
+      constexpr int kb = j >> 3, r = 2 * (j & 7);
+      if constexpr (is_x) a_exp2x2(e0[x][j], e1[x][j], S[x][kb][r], S[x][kb][r + 1]);
+      else ops::sum_pack(ps0[x], ps1[x], pw[x][j], e0[x][j], e1[x][j]);
     });
   };
   // after both 32-key maxima: may every row of sub-block x keep its reference? (almost always: one compare on this
@@ -513,9 +526,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       qk(ic<0>{}, GC, t, need_mask);
-      if constexpr (g >= 10 && g < 14) maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10)>{});
       estream(ic<1>{}, ic<12 + g>{});
-      if constexpr (g >= 10 && g < 14) maxop(ic<0>{}, ic<0>{}, ic<2 * (g - 10) + 1>{});
+      if constexpr (g >= 10 && g < 14) maxpair(ic<0>{}, ic<0>{}, ic<g - 10>{});
 #ifndef PW_ABL_DMA
       if constexpr (g >= 2 && g < 6) pw_glds16(koff[g - 2], kb64, KD + lds_wave + (g - 2) * 1024);
       if constexpr (g >= 6 && g < 10) pw_glds16(voff[g - 6], vb64, VD + lds_wave + (g - 6) * 1024);
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       pv(ic<1>{}, GC);
-      if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<0>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
+      if constexpr (g == 1 || g == 2) { maxpair(ic<0>{}, ic<1>{}, ic<2 * (g - 1)>{}); maxpair(ic<0>{}, ic<1>{}, ic<2 * (g - 1) + 1>{}); }
 #ifndef PW_ABL_MAX
       if constexpr (g == 3) decide(ic<0>{}, t, need_mask);
 #endif
@@ -537,9 +549,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       qk(ic<1>{}, GC, t, need_mask);
-      if constexpr (g >= 10 && g < 14) maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10)>{});
       estream(ic<0>{}, ic<12 + g>{});
-      if constexpr (g >= 10 && g < 14) maxop(ic<1>{}, ic<0>{}, ic<2 * (g - 10) + 1>{});
+      if constexpr (g >= 10 && g < 14) maxpair(ic<1>{}, ic<0>{}, ic<g - 10>{});
       if constexpr (g < 4) vread(ic<3>{}, GC, ic<VR>{});
     });
     PW_SEG_STAMP(3);
@@ -554,7 +565,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       // K(t+1) into K(t)'s registers once B's decision is taken (a moved reference recomputes S_B(t) from K(t))
       // (two per gap, the last one four gaps before the wait that ends the iteration)
       if constexpr (g >= 4 && g < 12) { kread(ic<2 * (g - 4)>{}, ic<KR>{}); kread(ic<2 * (g - 4) + 1>{}, ic<KR>{}); }
-      if constexpr (g == 1 || g == 2) sfor<4>([&](auto O) __attribute__((always_inline)) { maxop(ic<1>{}, ic<1>{}, ic<4 * (g - 1) + decltype(O)::value>{}); });
+      if constexpr (g == 1 || g == 2) { maxpair(ic<1>{}, ic<1>{}, ic<2 * (g - 1)>{}); maxpair(ic<1>{}, ic<1>{}, ic<2 * (g - 1) + 1>{}); }
 #ifndef PW_ABL_MAX
       if constexpr (g == 3) decide(ic<1>{}, t, need_mask);
 #endif
