@@ -8,8 +8,8 @@
 //   * a wave owns TWO 32-row sub-blocks (A, B): every K fragment and every transposed V fragment read from
 //     LDS feeds two MFMAs, and the wave issues HALF the LDS reads, LDS-DMA and barriers per MFMA;
 //   * the two sub-blocks run half a tile apart ("ping-pong" inside one wave): while the matrix pipe computes
-//     S_A = K.Q_A^T the VALU finishes sub-block B's softmax, then O_B += V^T.P_B runs beside A's row maxima
-//     and exponentials, and so on - every MFMA has a few independent VALU instructions in its shadow and no
+//     S_A = K.Q_A^T the VALU finishes sub-block B's exponentials, then O_B += V^T.P_B runs beside A's
+//     exponentials, and so on - every MFMA has a few independent VALU instructions in its shadow and no
 //     phase of the loop is VALU-only or MFMA-only. One wave per SIMD has nobody to hide its bubbles, so the
 //     interleave is written out gap by gap (the work that follows each MFMA is fixed in the source);
 //   * the whole 512-entry register file: O (128), Q (64) and the current K tile (64) live in accumulator
@@ -19,13 +19,17 @@
 //     an SGPR address): wave w fetches the 16-key group w of every tile, i.e. one block-table entry per tile and
 //     matrix - read through the scalar cache one iteration before it is needed - and no per-lane 64-bit address
 //     arithmetic; three-slot rings, K two tiles ahead, V one; counted vmcnt;
-//   * a single wave issues in order, so every instruction of the loop costs issue time nobody else fills: the
-//     reference maximum starts at ZERO (bf16: P = 2^s is exact enough for |s| <= 32 and the accumulators are f32),
-//     so S^T starts from the inline constant 0 instead of from -m_ref in registers, and the per-tile check is one
-//     compare on a half-row maximum; rows that leave the range move their reference on a slow path as before.
+//   * a single wave issues in order, so every instruction of the loop costs issue time nobody else fills. bf16
+//     only, and NO running maximum in the loop: P = 2^s with the fixed reference 0 has the same relative precision
+//     as 2^(s - max) (bf16 and f32 are floating point), S^T starts from the inline constant 0, and neither maxima
+//     nor rescaling are computed per tile. What a running maximum protects against - P or a sum leaving the range
+//     of the format - is CHECKED once per row when the block is done (2^-64 <= l <= 2^100, O finite); a row that
+//     fails (scores beyond +-90 or so in log2 units: not attention as models produce it) is computed again by a
+//     slow, plain online-softmax routine in the same launch (pw_row_fallback). f16 (P <= 65504) cannot do this and
+//     stays on prefill_dma_kernel.
 //
-// MFMA orientation, the in-register softmax, the deferred running maximum (C operand = -m_ref) and the LDS
-// swizzles are those of prefill_dma_kernel (prefill_mfma.hip).
+// MFMA orientation, the in-register softmax layout and the LDS swizzles are those of prefill_dma_kernel
+// (prefill_mfma.hip).
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -41,7 +45,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int wu32x2_t;
 constexpr int kPwTile = 64;          // keys per KV tile
 constexpr int kPwRows = 256;         // Q-block rows per workgroup
 constexpr float kPwLog2e = 1.4426950408889634f;
-constexpr float kPwDeferThr = 8.0f;  // log2 units a row's tile maximum may exceed its reference before the reference moves
+constexpr float kPwSumLo = 5.421010862427522e-20f;   // 2^-64: below it a row's largest P may be close to the subnormals
+constexpr float kPwSumHi = 1.2676506002282294e30f;   // 2^100: above it a P or a partial sum may have overflowed
 
 // accumulator-register map (owned by the asm statements below)
 constexpr int kAO = 0;     // O^T[sb][b]  : kAO + 64 sb + 16 b   (16 registers)
@@ -70,15 +75,9 @@ __device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std
 // hipcc neither pads nor counts anything inside (cdna_hip_programming.md 5.7); the placement rules are in the kernel.
 __device__ __forceinline__ float a_exp2(float x) { float r; asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 __device__ __forceinline__ float a_add(float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
-__device__ __forceinline__ float a_max(float x, float y) { float r; asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ void a_exp2x2(float& r0, float& r1, float x0, float x1) {
   asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
 }
-__device__ __forceinline__ void a_max3x2(float& r0, float& r1, float a0, float a1, float a2, float b0, float b1, float b2) {
-  asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %5, %6, %7" : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2));
-}
-__device__ __forceinline__ float a_mov(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
-__device__ __forceinline__ float a_max3(float x, float y, float z) { float r; asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; }
 
 template <typename T> struct pw_ops;
 #define MI355_DEF_PW_OPS(TAG, MFMA, CVT)                                                                          \
@@ -105,7 +104,6 @@ template <typename T> struct pw_ops;
     }                                                                                                             \
   };
 MI355_DEF_PW_OPS(bf16_t, "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
-MI355_DEF_PW_OPS(f16_t, "v_mfma_f32_32x32x16_f16", "v_cvt_pk_f16_f32")
 #undef MI355_DEF_PW_OPS
 
 template <typename T> __device__ __forceinline__ float pw_lo(uint32_t w);
@@ -158,6 +156,38 @@ __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int n
   return left - 1;
 }
 
+// One query row against keys [key_lo, key_hi), the plain way: all 64 lanes on the row, two head dimensions each, the
+// textbook online softmax with a true running maximum in f32 (kernel_unified_attention_2d, :467-510, one key at a
+// time). Slow on purpose - it only ever runs for rows whose scores left the range prefill_pw_kernel's fixed
+// reference is good for - and independent of everything the fast path keeps on chip: K/V straight from the cache.
+template <typename T>
+__device__ __forceinline__ void pw_row_fallback(const mi355_attn_params& p, const PwArgs& a, const int32_t* bt, const char* kbase, const char* vbase,
+                                             int token, int hq, int key_lo, int key_hi, uint16_t* out_base, float* lse_base, int lane) {
+  const uint32_t qw = *(const uint32_t*)((const uint16_t*)p.q + (int64_t)token * p.q_stride_token + (int64_t)hq * p.q_stride_head + 2 * lane);
+  const float q0 = pw_lo<T>(qw), q1 = pw_hi<T>(qw);
+  const float scale2 = p.scale * kPwLog2e;
+  const int page_mask = p.page_size - 1;
+  float m = -INFINITY, l = 0.0f, a0 = 0.0f, a1 = 0.0f;
+  for (int j = key_lo; j < key_hi; ++j) {
+    const int64_t page = bt[j >> a.page_shift];
+    const int64_t slot = j & page_mask;
+    const uint32_t kw = *(const uint32_t*)(kbase + (page * a.k_page_stride + slot * a.k_slot_stride) * 2 + 4 * lane);
+    const uint32_t vw = *(const uint32_t*)(vbase + (page * a.v_page_stride + slot * a.v_slot_stride) * 2 + 4 * lane);
+    const float sc = wave_sum(q0 * pw_lo<T>(kw) + q1 * pw_hi<T>(kw)) * scale2;
+    const float mn = fmaxf(m, sc);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
+    const uint32_t pr = pw_pack<T>(pj, pj);                 // P is rounded to V's type before P.V (:508), not for the sum
+    l = l * alpha + pj;
+    a0 = a0 * alpha + pw_lo<T>(pr) * pw_lo<T>(vw);
+    a1 = a1 * alpha + pw_lo<T>(pr) * pw_hi<T>(vw);
+    m = mn;
+  }
+  const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+  *(uint32_t*)(out_base + (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head + 2 * lane) = pw_pack<T>(a0 * inv, a1 * inv);
+  if (lse_base && lane == 0)
+    lse_base[(int64_t)token * p.lse_stride_token + hq] = l > 0.0f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+}
+
 // Diagnostic build only (-DMI355_PW_STAMP, tools/pw_clock.py): shader-cycle sums of the tile loop's segments.
 #ifdef MI355_PW_STAMP
 #define PW_SEG_STAMP(idx)                                                                   \
@@ -175,12 +205,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   using ops = pw_ops<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
-  // Reference maxima. bf16: a row keeps the reference 0 while its tile maxima stay in [-kLo, kHi] (log2 units):
-  // P = 2^s <= 2^32 is a bf16 with full relative precision and the f32 sums have 2^90 of headroom above it.
-  // f16 (P <= 65504, 2^-14 normal): the reference is the first tile's maximum and may be exceeded by 2^8, as in
-  // prefill_dma_kernel.
-  constexpr bool kAutoStart = __is_same(T, bf16_t);
-  constexpr float kHi = kAutoStart ? 32.0f : kPwDeferThr, kLo = 32.0f;
+  static_assert(__is_same(T, bf16_t), "P = 2^s with the reference 0 needs the exponent range of bf16");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   asm volatile("" ::: "a255");                 // the kernel owns all 256 accumulator registers
   const mi355_attn_params& p = a.p;
@@ -344,24 +369,15 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   });
 
   // ---- state -------------------------------------------------------------------------------------------
-  wf32x16_t S[2][2];          // [sub-block][32-key block]: S^T - m_ref of the tile in flight
-  float cneg[2] = {0.0f, 0.0f};   // -m_ref of this lane's rows
-  bool zmode[2] = {true, true};   // wave-uniform: every row of the sub-block still has the reference 0 -> S^T starts from the constant 0
-  bool all_started[2] = {false, false};   // wave-uniform: every row has a reference (first tile done)
+  wf32x16_t S[2][2];          // [sub-block][32-key block]: S^T of the tile in flight
   uint32_t pw[2][16];         // P^T as packed pairs; dwords 4 sk .. 4 sk + 3 = B operand of k-step sk
   wu32x4_t vfr[4][4];         // transposed V fragments [output block b][k-step sk]
-  float e0[2][16], e1[2][16], tmax[2][2][8];
-  float ps0[2] = {0.0f, 0.0f}, ps1[2] = {0.0f, 0.0f};   // running row sums (two chains), relative to m_ref
-  float m_ref[2] = {0.0f, 0.0f};
-  bool started[2] = {!row_ok[0], !row_ok[1]};           // padding rows never see a key: keep them off the slow path
+  float e0[2][16], e1[2][16];
+  float ps0[2] = {0.0f, 0.0f}, ps1[2] = {0.0f, 0.0f};   // running row sums (two chains)
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[x][0][r] = -INFINITY; S[x][1][r] = -INFINITY; pw[x][r] = 0u; e0[x][r] = 0.0f; e1[x][r] = 0.0f; }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int o = 0; o < 8; ++o) tmax[x][kb][o] = -INFINITY;
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -369,29 +385,20 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
 
   // ---- the pieces of an iteration ------------------------------------------------------------------------
-  // S_x[kb] before its MFMA chain, when it cannot start from the constant 0: -m_ref of the row, or -inf for the keys
-  // the row must not see (tiles on the causal diagonal / at the sequence end). S is never modified after its chain.
-  auto s_init = [&](auto X, auto KB, int t, bool need_mask) __attribute__((always_inline)) {
-    constexpr int x = decltype(X)::value, kb = decltype(KB)::value;
-    if (need_mask) {
-      const int rel = lim[x] - t * kPwTile - 32 * kb - 4 * half;     // visible: (r & 3) + 8 (r >> 2) <= rel
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S[x][kb][r] = ((r & 3) + 8 * (r >> 2) <= rel) ? cneg[x] : -INFINITY;
-    } else {
-      sfor<16>([&](auto RC) __attribute__((always_inline)) { S[x][kb][decltype(RC)::value] = a_mov(cneg[x]); });
-    }
-    asm volatile("s_nop 1");      // VALU write -> MFMA read
-  };
-  // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7. A chain starts from the constant 0 when every row of
-  // the sub-block has the reference 0 and sees every key of the tile, else from s_init.
+  // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7. A chain starts from the constant 0; on a tile that
+  // straddles the causal diagonal or the sequence end it starts from 0 / -inf per key instead (the mask enters
+  // through the accumulator: S is never modified after its chain).
   auto qk = [&](auto X, auto GC, int t, bool need_mask) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kb = g >> 3, ks = g & 7;
     constexpr int KA = kAK + 32 * kb + 4 * ks, QA = kAQ + 32 * x + 4 * ks;
     if constexpr (ks == 0) {
-      if (__builtin_expect(zmode[x] && !need_mask, 1)) {
+      if (__builtin_expect(!need_mask, 1)) {
         ops::template qk_zero<KA, QA>(S[x][kb]);
       } else {
-        s_init(X, ic<kb>{}, t, need_mask);
+        const int rel = lim[x] - t * kPwTile - 32 * kb - 4 * half;     // visible: (r & 3) + 8 (r >> 2) <= rel
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[x][kb][r] = ((r & 3) + 8 * (r >> 2) <= rel) ? 0.0f : -INFINITY;
+        asm volatile("s_nop 1");      // VALU write -> MFMA read
         ops::template qk_acc<KA, QA>(S[x][kb]);
       }
     } else {
@@ -402,20 +409,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto pv = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, b = g >> 2, sk = g & 3;
     ops::template pv<kAO + 64 * x + 16 * b>(vfr[b][sk], wu32x4_t{pw[x][4 * sk], pw[x][4 * sk + 1], pw[x][4 * sk + 2], pw[x][4 * sk + 3]});
-  };
-  // row maximum of S_x[kb]: 8 instructions in 4 two-instruction statements i = 0 .. 3 (issue >= 2 MFMAs after the
-  // chain's last MFMA: its result needs 12 issue slots to become readable and hipcc pads nothing around an asm MFMA)
-  auto maxpair = [&](auto X, auto KB, auto IC) __attribute__((always_inline)) {
-    constexpr int x = decltype(X)::value, kb = decltype(KB)::value, i = decltype(IC)::value;
-#ifdef PW_ABL_MAX
-    return;
-#endif
-    const wf32x16_t& s = S[x][kb];
-    float* tm = tmax[x][kb];
-    if constexpr (i == 0) a_max3x2(tm[0], tm[1], s[0], s[1], s[2], s[3], s[4], s[5]);
-    else if constexpr (i == 1) a_max3x2(tm[2], tm[3], s[6], s[7], s[8], s[9], s[10], s[11]);
-    else if constexpr (i == 2) a_max3x2(tm[4], tm[5], s[12], s[13], s[14], tm[0], tm[1], s[15]);
-    else asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_max_f32 %1, %5, %0" : "=&v"(tm[6]), "=&v"(tm[7]) : "v"(tm[2]), "v"(tm[3]), "v"(tm[4]), "v"(tm[5]));
   };
   // exponentials, row sums and packing of sub-block x: 32 two- or three-instruction statements (per P word: exp exp,
   // and a few blocks later add add cvt) dealt over a window of 28 MFMA gaps. One statement per block: hipcc pads
@@ -439,48 +432,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       else ops::sum_pack(ps0[x], ps1[x], pw[x][j], e0[x][j], e1[x][j]);
     });
   };
-  // after both 32-key maxima: may every row of sub-block x keep its reference? (almost always: one compare on this
-  // half-wave's maximum; the other half of the row sits in the other half-wave and is covered by the wave-wide vote)
-  // If a reference has to move, S_x(t) is COMPUTED AGAIN from K(t), which is still in its registers, on top of the new
-  // -m_ref: nothing the fast path keeps in registers is modified in place (an in-place fix would put copies of all of S
-  // on the fast path: hipcc cannot merge the two versions otherwise).
-  auto decide = [&](auto X, int t, bool need_mask) __attribute__((always_inline)) {
-    constexpr int x = decltype(X)::value;
-    const float mxh = a_max(tmax[x][0][7], tmax[x][1][7]);
-    if (__builtin_expect(!all_started[x] || !__all(mxh <= kHi), 0)) {
-      const float mx = fmaxf(mxh, lane_xor32(mxh));   // the other half-wave holds the row's other 32 keys
-      const bool seen = mx > -INFINITY;
-      // the reference stays: started rows below the ceiling; bf16 rows that start inside [-kLo, kHi] keep 0
-      const bool calm = mx <= kHi && (started[x] || !seen || (kAutoStart && mx >= -kLo));
-      started[x] = started[x] || seen;
-      all_started[x] = __all(started[x]);
-      if (!__all(calm)) {                        // move the reference of the rows that need it
-        const float upd = (!calm && seen) ? mx : 0.0f;
-        m_ref[x] += upd;
-        const float alpha = __builtin_amdgcn_exp2f(-upd);
-        cneg[x] = -m_ref[x];
-        zmode[x] = __all(m_ref[x] == 0.0f);
-        ps0[x] *= alpha;
-        ps1[x] *= alpha;
-        if (t != tile_lo) {                      // O_x is idle here: its last MFMA retired half an iteration ago
-          sfor<64>([&](auto I) __attribute__((always_inline)) {
-            constexpr int idx = kAO + 64 * x + decltype(I)::value;
-            const float o = acc_read<idx>() * alpha;
-            acc_write<idx>(__builtin_bit_cast(uint32_t, o));
-          });
-        }
-        sfor<2>([&](auto KB) __attribute__((always_inline)) {
-          constexpr int kb = decltype(KB)::value;
-          s_init(X, KB, t, need_mask);
-          sfor<8>([&](auto KS) __attribute__((always_inline)) {
-            constexpr int ks = decltype(KS)::value;
-            ops::template qk_acc<kAK + 32 * kb + 4 * ks, kAQ + 32 * x + 4 * ks>(S[x][kb]);
-          });
-        });
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S[x][0]), "+v"(S[x][1]));   // MFMA result -> VALU read
-      }
-    }
-  };
   // LDS reads. V(t)[b][sk]: two transposed 8-byte reads into one 4-register fragment
   auto vread = [&](auto B, auto SK, auto SLOT) __attribute__((always_inline)) {
     constexpr int b = decltype(B)::value, sk = decltype(SK)::value, off = decltype(SLOT)::value + sk * 16 * ROWB;
@@ -503,10 +454,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   unsigned st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
 #endif
   // One iteration = one KV tile t. Matrix pipe: S_A(t) | O_B += P_B(t-1) | S_B(t) | O_A += P_A(t); beside it, per gap:
-  //   seg 1: B(t-1) exponentials (second half) . A's first 32-key maximum . LDS-DMA of K(t+3), V(t+2)
-  //   seg 2: A's second maximum, decision, A exponentials . V(t) fragment reads as V(t-1)'s registers retire
-  //   seg 3: A exponentials (second half) . B's first maximum
-  //   seg 4: B's second maximum, decision, B exponentials . K(t+1) fragment reads (K(t) is kept until B's decision)
+  //   seg 1: B(t-1) exponentials (second half) . LDS-DMA of K(t+3), V(t+2)
+  //   seg 2: A exponentials . V(t) fragment reads as V(t-1)'s registers retire
+  //   seg 3: A exponentials (second half) . K(t+1) fragment reads as K(t)'s registers retire
+  //   seg 4: B exponentials
   // IT = (t - tile_lo) % 3 picks the ring slots at compile time.
   auto iteration = [&](auto ITC, int t) __attribute__((always_inline)) {
     constexpr int it = decltype(ITC)::value;
@@ -527,7 +478,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       constexpr int g = decltype(GC)::value;
       qk(ic<0>{}, GC, t, need_mask);
       estream(ic<1>{}, ic<12 + g>{});
-      if constexpr (g >= 10 && g < 14) maxpair(ic<0>{}, ic<0>{}, ic<g - 10>{});
 #ifndef PW_ABL_DMA
       if constexpr (g >= 2 && g < 6) pw_glds16(koff[g - 2], kb64, KD + lds_wave + (g - 2) * 1024);
       if constexpr (g >= 6 && g < 10) pw_glds16(voff[g - 6], vb64, VD + lds_wave + (g - 6) * 1024);
@@ -538,10 +488,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       pv(ic<1>{}, GC);
-      if constexpr (g == 1 || g == 2) { maxpair(ic<0>{}, ic<1>{}, ic<2 * (g - 1)>{}); maxpair(ic<0>{}, ic<1>{}, ic<2 * (g - 1) + 1>{}); }
-#ifndef PW_ABL_MAX
-      if constexpr (g == 3) decide(ic<0>{}, t, need_mask);
-#endif
       if constexpr (g >= 4) { estream(ic<0>{}, ic<g - 4>{}); vread(ic<((g - 4) >> 2)>{}, ic<((g - 4) & 3)>{}, ic<VR>{}); }
     });
     PW_SEG_STAMP(2);
@@ -550,8 +496,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       constexpr int g = decltype(GC)::value;
       qk(ic<1>{}, GC, t, need_mask);
       estream(ic<0>{}, ic<12 + g>{});
-      if constexpr (g >= 10 && g < 14) maxpair(ic<1>{}, ic<0>{}, ic<g - 10>{});
       if constexpr (g < 4) vread(ic<3>{}, GC, ic<VR>{});
+      if constexpr (g >= 8) kread(ic<g - 8>{}, ic<KR>{});        // K(t+1)[kb 0][ks]: K(t)[kb 0][ks] was last read in gap ks
     });
     PW_SEG_STAMP(3);
     // ---- segment 4 -------------------------------------------------------------------------------------
@@ -562,13 +508,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       pv(ic<0>{}, GC);
-      // K(t+1) into K(t)'s registers once B's decision is taken (a moved reference recomputes S_B(t) from K(t))
-      // (two per gap, the last one four gaps before the wait that ends the iteration)
-      if constexpr (g >= 4 && g < 12) { kread(ic<2 * (g - 4)>{}, ic<KR>{}); kread(ic<2 * (g - 4) + 1>{}, ic<KR>{}); }
-      if constexpr (g == 1 || g == 2) { maxpair(ic<1>{}, ic<1>{}, ic<2 * (g - 1)>{}); maxpair(ic<1>{}, ic<1>{}, ic<2 * (g - 1) + 1>{}); }
-#ifndef PW_ABL_MAX
-      if constexpr (g == 3) decide(ic<1>{}, t, need_mask);
-#endif
+      if constexpr (g < 8) kread(ic<8 + g>{}, ic<KR>{});         // K(t+1)[kb 1][ks]
       if constexpr (g >= 4) estream(ic<1>{}, ic<g - 4>{});
     });
     PW_SEG_STAMP(4);
@@ -626,22 +566,30 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   constexpr int ORS = ROWB + 16;                                            // padded row stride of the parked O rows
   char* ost = smem + wave * (64 * ORS);
   const bool wide_store = (((uintptr_t)out_base & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
+  const int key_lo = tile_lo * kPwTile;
+  bool bad[2];                                 // the row left the range the reference-0 arithmetic is good for
   sfor<2>([&](auto SB) __attribute__((always_inline)) {
     constexpr int sb = decltype(SB)::value;
     float l = ps0[sb] + ps1[sb];
     l += lane_xor32(l);
-    if (lse_base && row_ok[sb] && half == 0)    // P = exp2(score - m_ref): the sum is relative to the reference maximum
-      lse_base[(int64_t)(q_start + tok_local[sb]) * p.lse_stride_token + hq[sb]] = l > 0.0f ? (m_ref[sb] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+    if (lse_base && row_ok[sb] && half == 0)    // P = exp2(score): ln of the sum is the lse
+      lse_base[(int64_t)(q_start + tok_local[sb]) * p.lse_stride_token + hq[sb]] = l > 0.0f ? __builtin_amdgcn_logf(l) * 0.6931471805599453f : -INFINITY;
     const float inv = (row_ok[sb] && l > 0.0f) ? 1.0f / l : 0.0f;
     uint16_t* op = out_base + (int64_t)(q_start + tok_local[sb]) * p.out_stride_token + (int64_t)hq[sb] * p.out_stride_head + 4 * half;
+    float amax = 0.0f;
     sfor<4>([&](auto B) __attribute__((always_inline)) {
       sfor<4>([&](auto C) __attribute__((always_inline)) {
         constexpr int b = decltype(B)::value, c = decltype(C)::value, base = kAO + 64 * sb + 16 * b + 4 * c;
-        const wu32x2_t w = {pw_pack<T>(acc_read<base>() * inv, acc_read<base + 1>() * inv), pw_pack<T>(acc_read<base + 2>() * inv, acc_read<base + 3>() * inv)};
+        const float o0 = acc_read<base>(), o1 = acc_read<base + 1>(), o2 = acc_read<base + 2>(), o3 = acc_read<base + 3>();
+        amax = fmaxf(fmaxf(amax, fmaxf(__builtin_fabsf(o0), __builtin_fabsf(o1))), fmaxf(__builtin_fabsf(o2), __builtin_fabsf(o3)));
+        const wu32x2_t w = {pw_pack<T>(o0 * inv, o1 * inv), pw_pack<T>(o2 * inv, o3 * inv)};
         if (wide_store) *(wu32x2_t*)(ost + (sb * 32 + qr) * ORS + (32 * b + 8 * c + 4 * half) * 2) = w;
         else if (row_ok[sb]) *(wu32x2_t*)(op + 32 * b + 8 * c) = w;
       });
     });
+    amax = fmaxf(amax, lane_xor32(amax));
+    const bool has_keys = row_ok[sb] && tile_hi > tile_lo && lim[sb] >= key_lo;
+    bad[sb] = has_keys && !(l >= kPwSumLo && l <= kPwSumHi && amax < INFINITY);   // a NaN sum fails both comparisons
   });
   if (wide_store) {
     // O leaves as whole 256-byte rows, 16 bytes per lane (a lane's own 8-byte pieces touch 32 rows per store)
@@ -659,17 +607,30 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       }
     }
   }
+  // ---- rows that left the range: computed again, the plain way (never on attention scores as models produce them)
+  const unsigned long long bad_a = __ballot(bad[0]), bad_b = __ballot(bad[1]);
+  if (__builtin_expect((bad_a | bad_b) != 0, 0)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores above are done before these rows are written again
+    for (int rr = 0; rr < 64; ++rr) {
+      const unsigned long long bits = rr < 32 ? bad_a : bad_b;
+      if (!((bits >> (rr & 31)) & 1)) continue;             // lane rr & 31 holds the row's flag (both half-waves agree)
+      const int m = wave * 64 + rr;
+      const int tok = tok0 + m / G;
+      const int key_hi = min(min(ctx_len + tok, seq_len - 1) + 1, tile_hi * kPwTile);
+      pw_row_fallback<T>(p, a, (const int32_t*)bt64, kbase, vbase, q_start + tok, head * G + m % G, key_lo, key_hi, out_base, lse_base, lane);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 
-// Preconditions beyond prefill_supported(): head size 128, no soft-cap / ALiBi / sliding window, 16-bit cache, G <= 256.
+// Preconditions beyond prefill_supported(): bf16, head size 128, no soft-cap / ALiBi / sliding window, bf16 cache, G <= 256.
 bool prefill_pw_applicable(const mi355_attn_params& p) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  return !feat && p.head_size == 128 && G <= kPwRows && p.kv_dtype == p.q_dtype;
+  return !feat && p.head_size == 128 && G <= kPwRows && p.q_dtype == MI355_BF16 && p.kv_dtype == p.q_dtype;
 }
 
 template <typename T>
@@ -697,8 +658,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
 }
 
 int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, hipStream_t stream) {
-  return p.q_dtype == MI355_BF16 ? launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, stream)
-                                 : launch_pw_t<f16_t>(p, key_splits, out_split_stride, lse_split_stride, stream);
+  return launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, stream);
 }
 
 }  // namespace mi355
