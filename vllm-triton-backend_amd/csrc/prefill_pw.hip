@@ -216,12 +216,41 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   const int head = (int)(blockIdx.x % p.num_kv_heads);     // KV head fastest: one head per XCD at Hk = 8
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);   // heaviest first
-  const int seq = pw_find_seq(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
-  if (seq < 0) return;
-  const int q_start = p.cu_seqlens_q[seq];
-  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
+  // Sequence of this Q block and its lengths in ONE memory round trip for batches of up to 63 sequences: lane i takes
+  // cu_seqlens_q[i] and seqused_k[i], the search (largest i with cu[i] / BQ + i <= qblock, find_seq_idx :32-52) is a
+  // ballot. With a single sequence the first block-table entries ride the same trip, speculatively (checked below):
+  // a workgroup's prologue is a chain of dependent round trips nothing else on its CU hides.
+  const bool spec_bt = p.num_seqs == 1 && a.key_splits == 1;
+  int spec_pg[4] = {0, 0, 0, 0}, spec_off[4] = {0, 0, 0, 0};
+  if (spec_bt) {
+    uint64_t b0 = (uint64_t)p.block_table;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b0), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32));
+    b0 = ((uint64_t)hi << 32) | lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      spec_off[i] = __builtin_amdgcn_readfirstlane(min(((i * 4 + wave) << 4) >> a.page_shift, (int)p.block_table_stride - 1) << 2);
+      pw_sload(spec_pg[i], b0, spec_off[i]);
+    }
+  }
+  int seq, q_start, q_len, seq_len;
+  if (p.num_seqs <= 63) {
+    const int cu_v = p.cu_seqlens_q[min(lane, p.num_seqs)];
+    const int sk_v = p.seqused_k[min(lane, p.num_seqs - 1)];
+    const unsigned long long le = __ballot(lane < p.num_seqs && cu_v / BQ + lane <= qblock);
+    seq = __builtin_popcountll(le) - 1;
+    if (seq < 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
+    q_start = __builtin_amdgcn_readlane(cu_v, seq);
+    q_len = __builtin_amdgcn_readlane(cu_v, seq + 1) - q_start;
+    seq_len = __builtin_amdgcn_readlane(sk_v, seq);
+  } else {
+    seq = pw_find_seq(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
+    if (seq < 0) return;
+    q_start = p.cu_seqlens_q[seq];
+    q_len = p.cu_seqlens_q[seq + 1] - q_start;
+    seq_len = p.seqused_k[seq];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(spec_pg[0]), "+s"(spec_pg[1]), "+s"(spec_pg[2]), "+s"(spec_pg[3]) :: "memory");
   const int qb_local = qblock - (q_start / BQ + seq);
-  const int seq_len = p.seqused_k[seq];
   if (qb_local * BQ >= q_len || (p.skip_decodes && q_len == 1) || (p.only_decodes && q_len != 1)) return;
   const int ctx_len = seq_len - q_len;
   const int tok0 = qb_local * BQ;
@@ -332,9 +361,14 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // ---- first tiles on their way: K0 K1 V0 | K2 V1 (the issue order fixes the counted waits below) -----
   int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration (V's = K's of one iteration earlier)
   if (tile_hi > tile_lo) {
-    int pk0, pk1, pk2, pv0, pv1, unused;
-    scalar_load4((const int32_t*)bt64, entry_off(tile_lo) >> 2, entry_off(tile_lo + 1) >> 2, entry_off(tile_lo + 2) >> 2, entry_off(tile_lo + 3) >> 2, pk0, pk1, pk2, pg_k);
-    pv0 = pk0; pv1 = pk1; pg_v = pk2; unused = 0; (void)unused;     // K and V share the block table
+    int pk0, pk1, pk2, pv0, pv1;
+    const int eo0 = entry_off(tile_lo), eo1 = entry_off(tile_lo + 1), eo2 = entry_off(tile_lo + 2), eo3 = entry_off(tile_lo + 3);
+    if (spec_bt && eo0 == spec_off[0] && eo1 == spec_off[1] && eo2 == spec_off[2] && eo3 == spec_off[3]) {
+      pk0 = spec_pg[0]; pk1 = spec_pg[1]; pk2 = spec_pg[2]; pg_k = spec_pg[3];     // the speculative entries are the right ones
+    } else {
+      scalar_load4((const int32_t*)bt64, eo0 >> 2, eo1 >> 2, eo2 >> 2, eo3 >> 2, pk0, pk1, pk2, pg_k);
+    }
+    pv0 = pk0; pv1 = pk1; pg_v = pk2;            // K and V share the block table
     auto group = [&](int tile, int page, auto ISV, uint32_t lds_dst) {
       constexpr bool isv = decltype(ISV)::value != 0;
       tail_check(tile, ISV);
