@@ -187,3 +187,79 @@ def test_prefill_c2_full_size_properties():
     d3["v_cache"] = torch.full_like(d["v_cache"], -0.25)
     out3, _ = gpu_util.run_unified(d3, scale)
     torch.testing.assert_close(out3.float(), torch.full_like(out3, -0.25).float(), atol=2e-3, rtol=0)
+
+
+def _spiked_inputs(seed, query_lens, kv_lens, hq, hk, gains):
+    """Keys = one fixed direction u per KV head plus noise; query rows r with gains[r % len(gains)] != 0 are gain * u, so
+    every score of such a row is about gain * |u|^2 * scale: far above or far below what a fixed reference can hold."""
+    inp = orc.make_paged_inputs(seed, query_lens, kv_lens, hq, hk, 128, 16, torch.bfloat16)
+    g = torch.Generator().manual_seed(seed + 1)
+    u = torch.rand(hk, 128, generator=g) * 2 - 1
+    noise = (torch.rand(inp["k_cache"].shape, generator=g) * 2 - 1) * 0.1
+    inp["k_cache"] = (u[None, None] + noise).to(torch.bfloat16)
+    q = inp["q"].float()
+    G = hq // hk
+    for r in range(q.shape[0]):
+        gain = gains[r % len(gains)]
+        if gain != 0.0:
+            for h in range(hq):
+                q[r, h] = gain * u[h // G]
+    inp["q"] = q.to(torch.bfloat16)
+    return inp
+
+
+@pytest.mark.parametrize("gains", [(0.0, 4.0, -4.0), (0.0, 30.0, 0.0, -30.0), (60.0, -60.0, 0.0), (0.0, 0.0, 0.0, 0.0, 2000.0, -2000.0)])
+def test_prefill_rows_whose_scores_leave_the_fixed_reference_range(gains):
+    """prefill_pw_kernel computes P = 2^score against the FIXED reference 0 and checks each row's sum once at the end;
+    rows outside [2^-64, 2^100] are computed again by its plain per-row routine. |u|^2 * scale * log2(e) ~ 5.4, so a
+    gain of 4 stays inside, 30 lands on both sides of the range, 2000 overflows f32 itself without a running maximum.
+    Every row must match the oracle whichever way it was computed."""
+    import os
+
+    import gpu_util
+
+    if max(gains) > 1000 and os.environ.get("MI355_PREFILL") != "pw":
+        # scores of +-10^4: the kernels that fold scale * log2(e) into a bf16 Q (2^-9 relative, i.e. whole nats at this
+        # size) are not expected to hold 2e-2 here; prefill_pw_kernel sends such rows to its f32 per-row routine
+        pytest.skip("needs the per-row routine of prefill_pw_kernel (tests/test_gpu_variants.py pins it)")
+    query_lens, kv_lens = [700, 270, 1], [2300, 2100, 2500]
+    inp = _spiked_inputs(31, query_lens, kv_lens, 8, 2, gains)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    lse = torch.full((inp["q"].shape[0], 8), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], lse=lse)
+    assert kernel.startswith("prefill_mfma"), kernel
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    # the same rows through every other prefill kernel family of the library (they track a running maximum)
+    for force in (2, 9):
+        out_f, _ = gpu_util.run_unified(d, inp["scale"], force=force)
+        torch.testing.assert_close(out_f.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    # the log-sum-exp of the rows the MFMA kernel wrote (query_len > 1), against float64
+    q64, T = inp["q"].double(), inp["q"].shape[0]
+    cu, sk, bt = inp["cu_seqlens_q"].tolist(), inp["seqused_k"].tolist(), inp["block_table"]
+    for s_idx, tok in ((0, 0), (0, 699), (1, 35)):
+        t = cu[s_idx] + tok
+        n_keys = sk[s_idx] - (cu[s_idx + 1] - cu[s_idx]) + tok + 1
+        pages = bt[s_idx, : (n_keys + 15) // 16].long()
+        keys = inp["k_cache"][pages].reshape(-1, 2, 128)[:n_keys].double()
+        for h in (0, 7):
+            sc = (keys[:, h // 4] @ q64[t, h]) * inp["scale"]
+            want = torch.logsumexp(sc, 0).item()
+            assert abs(lse[t, h].item() - want) <= 2e-2 * max(1.0, abs(want)), (s_idx, tok, h, lse[t, h].item(), want)
+
+
+def test_prefill_key_split_with_rows_outside_the_fixed_reference_range():
+    """The same through the key-split launch of the 64-rows-per-wave kernel (one 512-token chunk over 8k keys):
+    partial outputs and lse per share, some of them from the per-row routine, merged by merge_key_splits_kernel."""
+    import gpu_util
+
+    inp = _spiked_inputs(33, [512], [8192], 4, 1, (0.0, 0.0, 40.0, -40.0, 0.0))
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(d, inp["scale"])
+    assert kernel == "prefill_mfma_ksplit", kernel
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)

@@ -44,8 +44,18 @@ def test_prefill_register_staged_kernel_for_plain_head_size_128():
 
 
 def test_prefill_64_rows_per_wave_kernel_on_small_shapes():
-    _run({"MI355_PREFILL": "pw"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"],
-         keyword="(mixed and 128 and (8-2 or 32-1)) or c2_full")
+    """prefill_pw_kernel (auto-selected from 2048 keys on, bf16) pinned on the small parity shapes, and its per-row
+    routine for rows whose scores leave the range of its fixed reference, without a key split in front of it."""
+    _run({"MI355_PREFILL": "pw", "MI355_PREFILL_KEY_SPLITS": "1"},
+         ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
+          "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_prefill.py::test_prefill_rows_whose_scores_leave_the_fixed_reference_range",
+          "tests/test_gpu_fuzz.py"],
+         keyword="(mixed and 128 and dtype0) or page_sizes or strided or leave or agree")
+
+
+def test_prefill_8_wave_kernel_with_rows_outside_its_first_reference():
+    _run({"MI355_PREFILL": "d8", "MI355_PREFILL_KEY_SPLITS": "1"},
+         ["tests/test_gpu_prefill.py::test_prefill_rows_whose_scores_leave_the_fixed_reference_range"])
 
 
 def test_decode_merge_in_a_launch_of_its_own():

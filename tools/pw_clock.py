@@ -34,7 +34,7 @@ def main():
     sl = torch.full((batch,), L, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
     max_wgs = (batch * L * (Hq // Hk) // 256 + batch) * Hk + 64
-    dbg = torch.zeros(8 * max_wgs, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(12 * max_wgs, dtype=torch.int64, device=dev)
     p, keep = ua.fill_attn_params(q, k, v, out, cu, L, sl, L, 1 / math.sqrt(D), (-1, -1), bt, 0.0, None, None, None, 2)
     addr = dbg.data_ptr()
     p.reserved0 = C.c_int32(addr & 0xFFFFFFFF).value
@@ -53,7 +53,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
-    rec = dbg.cpu().view(-1, 8)
+    rec = dbg.cpu().view(-1, 12)
     rec = rec[rec[:, 2] > 0]
     cyc, rt, tiles = rec[:, 0].double(), rec[:, 1].double(), rec[:, 2].double()
     clk = (cyc / rt * 100.0)                      # MHz
@@ -65,6 +65,10 @@ def main():
     print(f"  cycles per KV tile (64 MFMA per SIMD): median {cpt[big].median():.0f}  = {cpt[big].median()/64:.1f} per MFMA   (all workgroups: {cpt.median():.0f})")
     seg = rec[:, 3:8].double().sum(0) / tiles.sum()
     print("  cycles per tile by segment (stamps included, ~40 each): seg1 S_A|B exps|DMA %.0f, seg2 O_B|A max+exps|V reads %.0f, seg3 S_B|A exps|K reads %.0f, seg4 O_A|B max+exps %.0f, end wait+barrier %.0f" % tuple(seg.tolist()))
+    pro, loop, epi = (rec[:, 9] - rec[:, 8]).double() * 0.01, (rec[:, 10] - rec[:, 9]).double() * 0.01, (rec[:, 11] - rec[:, 10]).double() * 0.01
+    t0 = rec[:, 8].min()
+    print(f"  workgroup life (us): entry->loop median {pro.median():.2f} (p90 {pro.kthvalue(max(1,len(pro)*9//10)).values:.2f}), loop {loop.median():.2f}, loop end->exit median {epi.median():.2f} (p90 {epi.kthvalue(max(1,len(epi)*9//10)).values:.2f})")
+    print(f"  first entry -> last exit {(rec[:, 11].max() - t0) * 0.01:.1f} us; last entry at {(rec[:, 8].max() - t0) * 0.01:.1f} us; sum of lives / 256 = {((rec[:, 11] - rec[:, 8]).double().sum() * 0.01 / 256):.1f} us")
     print(f"  time per tile: {(rt[big]/tiles[big]).median()*10:.0f} ns; tile loop = {(rt.sum()*0.01)/ (us*256)*100:.1f} % of CU time (256 CUs x launch time)")
 
 

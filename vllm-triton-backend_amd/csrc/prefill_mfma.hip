@@ -867,9 +867,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     if (!__all(calm)) {
       // move the reference of the rows that need it: first visible key, or max grew past the threshold
       const float upd = (!calm && mx > -INFINITY) ? mx : 0.0f;
+      // a row's FIRST reference may lie far below 0 (scores under -128 in log2 units): 2^-upd would overflow and turn the
+      // row's (still zero) sums into NaN. Nothing has been accumulated for such a row yet: its factor is 1.
+      alpha = started ? __builtin_amdgcn_exp2f(-upd) : 1.0f;
       started = started || (mx > -INFINITY);
       m_ref += upd;
-      alpha = __builtin_amdgcn_exp2f(-upd);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1315,12 +1317,21 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   }
   const bool bf = p.q_dtype == MI355_BF16;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
-  // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), w64 (64 rows/wave, one wave per SIMD); default = LDS-DMA, 32 rows/wave
+  // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), pw / d8 / d4 pin one of the three LDS-DMA kernels
   static const char* variant = getenv("MI355_PREFILL");
-  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1', pw = variant && variant[0] == 'p';
-  if (pw && prefill_pw_applicable(p) && (!g_key_split || g_key_split->wide))
-    return launch_prefill_pw(p, g_key_split ? g_key_split->splits : 1, g_key_split ? g_key_split_layout->out_split_stride : 0,
-                             g_key_split ? g_key_split_layout->lse_split_stride : 0, stream);
+  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1';
+  // prefill_pw_kernel (prefill_pw.hip: four waves of 64 rows, one per SIMD; bf16) wherever the 8-wave kernel was the
+  // choice, and instead of the 4-wave kernel from 2048 keys on (sustained TFLOP/s, Hq 32 / Hk 8, pw | 8-wave | 4-wave:
+  // 1 x 4096 1153 | 1068 | 933, 16 x 4096 1129 | 1032 | 978, 1 x 16384 1325 | 1188 | 1095, 1 x 3072 996 | 915 | 924,
+  // 2 x 2048 962 | 920 | 849, 1 x 2048 670 | 624 | 674; below that a workgroup's prologue and epilogue (~9 us at one
+  // workgroup per CU) outweigh its few tiles: 4 x 1024 628 | 636 | 663, 8 x 512 419 | 451 | 453, 1 x 1024 274 | 273 | 329).
+  if (prefill_pw_applicable(p) && !v1 && (!variant || variant[0] == 'p')) {
+    const bool pinned = variant && variant[0] == 'p';
+    const bool use_pw = g_key_split ? g_key_split->wide : p.max_seqlen_k >= 2048;
+    if (pinned ? (!g_key_split || g_key_split->wide) : use_pw)
+      return launch_prefill_pw(p, g_key_split ? g_key_split->splits : 1, g_key_split ? g_key_split_layout->out_split_stride : 0,
+                               g_key_split ? g_key_split_layout->lse_split_stride : 0, stream);
+  }
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped

@@ -214,6 +214,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.group, BQ = a.block_q;
 
+#ifdef MI355_PW_STAMP
+  unsigned long long st_entry;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry) :: "memory");
+#endif
   const int head = (int)(blockIdx.x % p.num_kv_heads);     // KV head fastest: one head per XCD at Hk = 8
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);   // heaviest first
   // Sequence of this Q block and its lengths in ONE memory round trip for batches of up to 63 sequences: lane i takes
@@ -582,9 +586,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1) :: "memory");
       unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
       if (dbg && tid == 0) {
-        unsigned long long* rec = dbg + 8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
+        unsigned long long* rec = dbg + 12ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
         rec[0] = st_c1 - st_c0; rec[1] = st_r1 - st_r0; rec[2] = (unsigned long long)(tile_hi - tile_lo);
         for (int i = 1; i < 6; ++i) rec[2 + i] = st_sum[i];
+        rec[8] = st_entry; rec[9] = st_r0; rec[10] = st_r1;
       }
     }
 #endif
@@ -624,6 +629,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     amax = fmaxf(amax, lane_xor32(amax));
     const bool has_keys = row_ok[sb] && tile_hi > tile_lo && lim[sb] >= key_lo;
     bad[sb] = has_keys && !(l >= kPwSumLo && l <= kPwSumHi && amax < INFINITY);   // a NaN sum fails both comparisons
+#ifdef PW_FORCE_FALLBACK
+    bad[sb] = has_keys;                          // diagnostic build: every row through the per-row routine
+#endif
   });
   if (wide_store) {
     // O leaves as whole 256-byte rows, 16 bytes per lane (a lane's own 8-byte pieces touch 32 rows per store)
@@ -654,6 +662,15 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       pw_row_fallback<T>(p, a, (const int32_t*)bt64, kbase, vbase, q_start + tok, head * G + m % G, key_lo, key_hi, out_base, lse_base, lane);
     }
   }
+#ifdef MI355_PW_STAMP
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long st_exit;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_exit) :: "memory");
+    unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
+    if (dbg && tid == 0) dbg[12ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) + 11] = st_exit;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
