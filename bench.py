@@ -9,11 +9,18 @@ Metric (BASELINE.json): "attn fwd TFLOPS (prefill) + KV GB/s (decode), Llama-3-8
 The timed region is K steps of the PREFILL workload C2 (BASELINE configs[1]: Hq 32 / Hk 8 / D 128,
 one 4096-token sequence per GPU, bf16, paged KV with 16-token pages): `value` = attention-forward
 TFLOP/s, counted FA-style (4*q*kv*D*Hq/2 = 137.44 GFLOP per sequence), whole job over all GPUs.
-The DECODE workload C3 (configs[2]: batch 64, kv_len 8192 per GPU) is timed the same way right
-after it and reported in the same JSON line under "decode" (KV GB/s) with its own roofline.
-Multi-GPU: the path shards over sequences with no data-path collective: every rank
-owns its sequences, their KV pages and a local block table -> weak scaling; the only collectives
-are the timing barrier and the MAX over ranks of the measured time.
+Three more workloads are timed the same way right after it and reported in the same JSON line:
+  "decode"      C3 (configs[2]): batch 64 x kv_len 8192 per GPU, bf16 KV            -> KV GB/s
+  "decode_fp8"  C5 (configs[4]): Hq 64 / Hk 8, batch 16 x kv_len 32768 per GPU, fp8-e4m3 KV -> KV GB/s
+  "mixed"       C4 (configs[3]): the reference harness's mixed batch (32 decodes, 16 partial and 16 full prefills,
+                98 336 query tokens), ONE global batch dealt to the N ranks by mi355_attn.parallel.shard_batch
+                (cost-balanced, each rank holds only its sequences' pages)          -> TFLOP/s, strong scaling
+Multi-GPU: the path shards over sequences with no data-path collective: C2/C3/C5 are weak scaling
+(every rank owns its own sequences, KV pages and block table), C4 is the batch-sharded split of one batch; the only
+collectives are the timing barrier and the MAX over ranks of the measured time.
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts the N ranks itself
+(torch.distributed.run as a child process, before this process touches a GPU) and fails loudly when the box has
+fewer than N GPUs.
 Inputs are synthetic (U(-1,1), seed 0 + rank), resident in HBM before the timed region starts.
 """
 
@@ -23,46 +30,115 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vllm-triton-backend_amd")]
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
-PREWARM_S = float(os.environ.get("MI355_BENCH_PREWARM_S", "0.25"))   # untimed launches before the W warm-up steps
+# Untimed launches of the same call before the W warm-up steps (reported as "prewarm_s" in the line): a 120 us kernel timed
+# 20 times right after its inputs were generated measures the device's clock/power ramp out of idle, not the kernel.
+PREWARM_S = float(os.environ.get("MI355_BENCH_PREWARM_S", "0.25"))
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
-def make_workload(kind, device, seed, Hq=32, Hk=8, D=128, page=16):
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 without a torch.distributed environment: run the N ranks as a child torch.distributed.run.
+    Nothing in this process has touched a GPU yet (device_count() does not initialise the runtime)."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for, but this box has {have} GPU(s): refusing to report a smaller job under that label",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def c4_lens(batch=64, seqlen=4096):
+    """The reference harness's mixed batch (scripts/benchmark.py:1053-1112 with decode_share 0.5, partial_prefill_share
+    0.5, pattern [1.0], ALTERNATING; restated in tools/microbench.py::make_prefix_batch and pinned by
+    tests/test_cpu_host.py): 32 decodes (ctx 4095), 16 partial prefills (ctx 2048 + 2048 new), 16 full prefills."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from microbench import make_prefix_batch
+
+    q, ctx = make_prefix_batch(batch, seqlen, [1.0], 0.5, 0.5, "ALTERNATING", 16)
+    return q, [a + b for a, b in zip(q, ctx)]
+
+
+def make_workload(kind, device, seed, rank, world):
+    import torch
+
+    page = 16
+    dt = torch.bfloat16
+    gen = torch.Generator(device=device).manual_seed(seed)
     g = torch.Generator(device="cpu").manual_seed(seed)
+    if kind == "mixed":                                   # C4: one GLOBAL batch (same seed on every rank), sharded below
+        Hq, Hk, D = 32, 8, 128
+        qlens, kvlens = c4_lens()
+        S, T = len(qlens), sum(qlens)
+        pps = [(n + page - 1) // page for n in kvlens]
+        nb = sum(pps) + 8
+        k = (torch.rand(nb, page, Hk, D, device=device, generator=gen) * 2 - 1).to(dt)
+        v = (torch.rand(nb, page, Hk, D, device=device, generator=gen) * 2 - 1).to(dt)
+        q = (torch.rand(T, Hq, D, device=device, generator=gen) * 2 - 1).to(dt)
+        perm = torch.randperm(nb, generator=g).to(torch.int32)
+        bt = torch.zeros(S, max(pps), dtype=torch.int32)
+        o = 0
+        for i, n in enumerate(pps):
+            bt[i, :n] = perm[o:o + n]
+            o += n
+        cu = torch.zeros(S + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(torch.tensor(qlens, dtype=torch.int32), 0)
+        from mi355_attn import parallel
+
+        loc = parallel.shard_batch(rank, world, q, k, v, cu, torch.tensor(kvlens, dtype=torch.int32), bt)
+        del q, k, v
+        lq = (loc.cu_seqlens_q[1:] - loc.cu_seqlens_q[:-1]).tolist()
+        lk = loc.seqused_k.tolist()
+        flops_all = sum(4.0 * D * Hq * (a * (b - a) + a * (a + 1) / 2) for a, b in zip(qlens, kvlens))
+        bytes_all = sum(b * Hk * D * 4.0 for b in kvlens) + 2.0 * T * Hq * D * 2
+        return dict(kind=kind, q=loc.q.contiguous(), k_cache=loc.k_cache.contiguous(), v_cache=loc.v_cache.contiguous(), block_table=loc.block_table,
+                    cu_seqlens_q=loc.cu_seqlens_q, seqused_k=loc.seqused_k, out=torch.empty_like(loc.q), q_len=max(lq), kv_len=max(lk),
+                    Hq=Hq, Hk=Hk, D=D, scale=1.0 / math.sqrt(D), k_scale=None, flops=flops_all, bytes=bytes_all, global_work=True,
+                    local=dict(seqs=len(lq), tokens=sum(lq)))
     if kind == "prefill":      # C2
-        B, q_len, kv_len = 1, 4096, 4096
-    else:                      # C3
-        B, q_len, kv_len = 64, 1, 8192
+        Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 1, 4096, 4096, dt
+    elif kind == "decode":     # C3
+        Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 64, 1, 8192, dt
+    else:                      # C5 "decode_fp8": Llama-3-70B shape, fp8-e4m3 KV (batch not given in BASELINE: 16, SURVEY §8d)
+        Hq, Hk, D, B, q_len, kv_len, kvdt = 64, 8, 128, 16, 1, 32768, torch.float8_e4m3fn
     pps = (kv_len + page - 1) // page
     nb = int(B * pps * 1.25)
-    dt = torch.bfloat16
-    # generate on the device to keep start-up short; values U(-1,1) (scripts/benchmark.py:136,:1168-1174)
-    gen = torch.Generator(device=device).manual_seed(seed)
-    k = (torch.rand(nb, page, Hk, D, device=device, generator=gen) * 2 - 1).to(dt)
-    v = (torch.rand(nb, page, Hk, D, device=device, generator=gen) * 2 - 1).to(dt)
+    # generated on the device to keep start-up short; values U(-1,1) (scripts/benchmark.py:136,:1168-1174)
+    k = (torch.rand(nb, page, Hk, D, device=device, generator=gen) * 2 - 1).to(kvdt)
+    v = (torch.rand(nb, page, Hk, D, device=device, generator=gen) * 2 - 1).to(kvdt)
     q = (torch.rand(B * q_len, Hq, D, device=device, generator=gen) * 2 - 1).to(dt)
     bt = torch.randperm(nb, generator=g)[: B * pps].to(torch.int32).view(B, pps).to(device)
     cu = (torch.arange(B + 1, dtype=torch.int32) * q_len).to(device)
     sl = torch.full((B,), kv_len, dtype=torch.int32, device=device)
-    out = torch.empty_like(q)
-    w = dict(kind=kind, q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=cu, seqused_k=sl, out=out, B=B, q_len=q_len,
-             kv_len=kv_len, Hq=Hq, Hk=Hk, D=D, page=page, scale=1.0 / math.sqrt(D))
+    w = dict(kind=kind, q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=cu, seqused_k=sl, out=torch.empty_like(q), B=B, q_len=q_len,
+             kv_len=kv_len, Hq=Hq, Hk=Hk, D=D, scale=1.0 / math.sqrt(D), global_work=False,
+             k_scale=torch.ones(1, device=device) if kvdt != dt else None)
     if kind == "prefill":
         w["flops"] = 4.0 * q_len * kv_len * D * Hq / 2 * B
         w["bytes"] = (2 * q.numel() + 2 * B * kv_len * Hk * D) * 2.0
     else:
         w["flops"] = 4.0 * B * Hq * kv_len * D
-        w["bytes"] = B * kv_len * Hk * D * 2 * 2.0 + 2 * q.numel() * 2.0 + bt.numel() * 4.0 + (2 * B + 1) * 4.0
+        w["bytes"] = B * kv_len * Hk * D * 2 * float(k.element_size()) + 2 * q.numel() * 2.0 + bt.numel() * 4.0 + (2 * B + 1) * 4.0
     return w
 
 
@@ -70,20 +146,20 @@ def build_call(w, device):
     from mi355_attn.kernels import unified as ua
 
     p, keep = ua.fill_attn_params(w["q"], w["k_cache"], w["v_cache"], w["out"], w["cu_seqlens_q"], w["q_len"], w["seqused_k"], w["kv_len"],
-                                  w["scale"], (-1, -1), w["block_table"], 0.0, None, None, None, None)
+                                  w["scale"], (-1, -1), w["block_table"], 0.0, w["k_scale"], w["k_scale"], None, None)
     w["_keep"] = (p, keep)
     return lambda: ua.launch(p, device)
 
 
 def timed_steps(call, steps, warmup, device, distributed):
-    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize. One HIP event pair brackets the K
-    launches on the stream they are launched on: the kernel's average launch duration is that span / K (it includes
-    the gaps between back-to-back launches, as a serving loop would see them; rocprofv3's per-kernel average under
-    profiles/ is the same number minus those gaps). No event is recorded between launches: an event record is a
-    barrier packet, and two of them per launch cost ~3 % of a 165 us kernel."""
-    # Bring the device out of its idle power state first: a 165 us kernel timed 50 times right after the inputs were
-    # generated measures the clock/power ramp, not the kernel (C2: 840 TFLOP/s over 50 steps, 990 over 500, 1015 over
-    # 2000 on one box). PREWARM_S seconds of the same launches, untimed, precede the W warm-up steps.
+    """PREWARM_S seconds of untimed launches (disclosed in the line), W untimed steps, then EXACTLY K steps bracketed by
+    barrier + synchronize. One HIP event pair brackets the K launches on the stream they are launched on: the kernel's
+    average launch duration is that span / K (it includes the gaps between back-to-back launches, as a serving loop
+    sees them; rocprofv3's per-kernel average under profiles/ is the same number minus those gaps). No event is
+    recorded between launches: an event record is a barrier packet, and two per launch cost ~3 % of a 120 us kernel."""
+    import torch
+    import torch.distributed as dist
+
     t_end = time.perf_counter() + PREWARM_S
     while time.perf_counter() < t_end:
         for _ in range(20):
@@ -111,6 +187,8 @@ def timed_steps(call, steps, warmup, device, distributed):
 
 def cpu_baseline(w, out_gpu):
     """Reference-style CPU SDPA path on this box's host cores, on the same inputs (rank 0, N=1)."""
+    import torch
+
     from oracle.cpu_sdpa_baseline import time_paged_sdpa_cpu
 
     if w["kind"] == "prefill":
@@ -133,20 +211,33 @@ def cpu_baseline(w, out_gpu):
             "max_abs_diff_vs_gpu": err}
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/collect_traffic.py ->
-    profiles/r01/traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of the guide);
-    None when no profile of that kernel is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    if not os.path.exists(path):
+# device symbol behind each name mi355_last_kernel() reports for the benchmarked calls (profiles are keyed by symbol)
+KERNEL_SYMBOL = {"prefill_mfma": "prefill_pw_kernel", "decode_splitkv": "decode_splitkv_kernel"}
+
+
+def measured_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes of THIS
+    command (tools/collect_traffic.py -> profiles/r02/traffic.json, the guide's gfx950 correction). Hardware counters
+    cannot be read from inside the timed run, so the number comes from that separate, committed pass and is reported
+    only when it was taken on the kernel symbol this run launched; otherwise null."""
+    path = os.path.join(PROFILE_DIR, "traffic.json")
+    symbol = KERNEL_SYMBOL.get(kernel_name.split("+")[0])
+    if symbol is None or not os.path.exists(path):
         return None
     try:
         for name, rec in json.load(open(path)).items():
-            if name.startswith(kernel_prefix):
+            if name.startswith(symbol):
                 return rec["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def roofline(bound, achieved, peak, unit, w, res, extra):
+    r = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+         "traffic": measured_traffic(res["kernel"]), "kernel": res["kernel"], "kernel_us": round(res["per_launch"] * 1e6, 2)}
+    r.update(extra)
+    return r
 
 
 def main():
@@ -157,10 +248,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # inside torch.distributed.run
+    if args.gpus > 1 and not launched:
+        raise SystemExit(spawn_ranks(args))
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
+    distributed = launched
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product")
     device = torch.device("cuda", local_rank)
@@ -168,9 +268,8 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    n_gpus = world if distributed else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1", file=sys.stderr)
+        assert dist.get_world_size() == args.gpus
+    n_gpus = world
 
     import __graft_entry__ as ge
     from mi355_attn import _lib
@@ -182,8 +281,8 @@ def main():
             dist.barrier()
 
     results = {}
-    for kind in ("prefill", "decode"):
-        w = make_workload(kind, device, seed=rank)
+    for kind in ("prefill", "decode", "decode_fp8", "mixed"):
+        w = make_workload(kind, device, seed=0 if kind == "mixed" else rank, rank=rank, world=world)
         call = build_call(w, device)
         call()
         torch.cuda.synchronize(device)
@@ -194,35 +293,50 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max, launch_max = t.tolist()
         results[kind] = dict(w=w, kernel=kernel, wall=wall_max, per_launch=launch_max)
+        if kind not in ("prefill", "decode"):
+            for key in ("q", "k_cache", "v_cache", "out", "_keep"):     # free the big legs before the next one
+                w.pop(key, None)
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        pf, dc = results["prefill"], results["decode"]
         K = args.steps
+        pf, dc, d8, mx = results["prefill"], results["decode"], results["decode_fp8"], results["mixed"]
         pf_val = pf["w"]["flops"] * n_gpus * K / pf["wall"] / 1e12
-        dc_val = dc["w"]["bytes"] * n_gpus * K / dc["wall"] / 1e9
         pf_ach = pf["w"]["flops"] / pf["per_launch"] / 1e12
-        dc_ach = dc["w"]["bytes"] / dc["per_launch"] / 1e9
         line = {
             "metric": "attn fwd TFLOPS (prefill) + KV GB/s (decode), Llama-3-8B GQA seq4k",
-            "value": round(pf_val, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup,
+            "value": round(pf_val, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup, "prewarm_s": PREWARM_S,
             "ms_per_step": round(pf["wall"] / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "C2 prefill: Llama-3-8B shape Hq32/Hk8/D128, 1 seq x 4096 tokens per GPU, causal, paged KV (16-token pages)",
                        "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
-            "roofline": {"bound": "mfma", "achieved": round(pf_ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(pf_ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": measured_traffic("prefill_dma_kernel"), "kernel": pf["kernel"],
-                         "kernel_us": round(pf["per_launch"] * 1e6, 2), "algorithmic_flops_per_launch": pf["w"]["flops"],
-                         "note": "peak = nominal dense bf16 MFMA rate; the package is power-limited (1.4 kW) under MFMA load: a dense bf16 "
-                                 "hipBLASLt GEMM sustains 1403 TFLOP/s on the same chip (profiles/r01/gemm_reference_point.log)"},
-            "decode": {"metric": "KV GB/s (paged decode)", "value": round(dc_val, 1), "unit": "GB/s", "ms_per_step": round(dc["wall"] / K * 1e3, 4),
-                       "config": {"workload": "C3 decode: Hq32/Hk8/D128, batch 64 x kv_len 8192 per GPU, bf16, 16-token pages",
-                                  "global_batch": 64 * n_gpus, "kernel": dc["kernel"]},
-                       "roofline": {"bound": "hbm", "achieved": round(dc_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(dc_ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic("decode_splitkv_kernel"), "kernel": dc["kernel"],
-                                    "kernel_us": round(dc["per_launch"] * 1e6, 2), "algorithmic_bytes_per_launch": dc["w"]["bytes"],
-                                    "note": "peak = nominal HBM3E rate; a plain streaming read of 2 GiB reaches 7.15 TB/s on this chip with nt loads, "
-                                            "6.2 TB/s with ordinary ones (profiles/r01/hbm_read_reference_point.log)"}},
+            "roofline": roofline("mfma", pf_ach, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", pf["w"], pf, {
+                "algorithmic_flops_per_launch": pf["w"]["flops"],
+                "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.0-2.2 GHz (in-kernel clock, "
+                        "tools/pw_clock.py, profiles/r02/pw_clock.log)"}),
         }
+
+        def decode_leg(res, label, cfg):
+            val = res["w"]["bytes"] * n_gpus * K / res["wall"] / 1e9
+            ach = res["w"]["bytes"] / res["per_launch"] / 1e9
+            return {"metric": label, "value": round(val, 1), "unit": "GB/s", "ms_per_step": round(res["wall"] / K * 1e3, 4),
+                    "config": {"workload": cfg, "global_batch": res["w"]["B"] * n_gpus, "kernel": res["kernel"]},
+                    "roofline": roofline("hbm", ach, HBM_PEAK_GBS, "GB/s", res["w"], res, {
+                        "algorithmic_bytes_per_launch": res["w"]["bytes"],
+                        "note": "peak = nominal HBM3E rate; a plain streaming read of 2 GiB reaches 7.15 TB/s on this chip with nt loads, "
+                                "6.2 TB/s with ordinary ones (profiles/r01/hbm_read_reference_point.log)"})}
+
+        line["decode"] = decode_leg(dc, "KV GB/s (paged decode)", "C3 decode: Hq32/Hk8/D128, batch 64 x kv_len 8192 per GPU, bf16, 16-token pages")
+        line["decode_fp8"] = decode_leg(d8, "KV GB/s (paged decode, fp8-e4m3 KV)",
+                                        "C5 decode: Llama-3-70B shape Hq64/Hk8/D128, batch 16 x kv_len 32768 per GPU, fp8-e4m3 KV, bf16 Q, 16-token pages")
+        mx_val = mx["w"]["flops"] * K / mx["wall"] / 1e12          # ONE global batch: strong scaling
+        line["mixed"] = {"metric": "attn fwd TFLOPS (mixed chunked-prefill + decode batch)", "value": round(mx_val, 2), "unit": "TFLOP/s",
+                         "ms_per_step": round(mx["wall"] / K * 1e3, 4), "scaling": "strong",
+                         "kv_gbs": round(mx["w"]["bytes"] * K / mx["wall"] / 1e9, 1),
+                         "config": {"workload": "C4: Granite-3.1-8B shape Hq32/Hk8/D128, 64 sequences (32 decodes ctx 4095, 16 partial prefills 2048+2048, "
+                                                "16 full prefills 4096), 98336 query tokens, ONE batch dealt to the ranks by parallel.shard_batch",
+                                    "global_batch": 64, "parallelism": f"batch-sharded x{n_gpus} (LPT by attention cost), no collective",
+                                    "rank0_share": mx["w"]["local"], "kernel": mx["kernel"]}}
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pf["w"], pf["w"]["out"])
             line["decode"]["cpu_baseline"] = cpu_baseline(dc["w"], dc["w"]["out"])
