@@ -228,6 +228,26 @@ MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
 MI355_API int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);
 
+/*
+ * The legacy ops under their own names. Both take the SAME parameter block, workspace rules and return
+ * codes as mi355_unified_attention and run the same kernels; they check that the block really describes the op and fix
+ * the op's row semantics, so that a caller binding the legacy names cannot get the unified behaviour by accident:
+ *
+ *   mi355_context_attention_fwd_v0 - `context_attention_fwd` (legacy/triton_prefix_prefill.py:588-765): context keys
+ *     from the paged cache in the layout the strides describe (v0: K [nb, Hk, D/x, page, x], V [nb, Hk, D, page]), the
+ *     keys of the tokens being prefilled from the linear k_new / v_new (required). Rows of sequences with
+ *     query_len == 1 are left untouched (:83-84): skip_decodes is forced on, only_decodes must be 0.
+ *   mi355_paged_attention_v0 - `paged_attention_triton_2d/3d` (legacy/triton_paged_decode_attention_2d.py:283-398,
+ *     ..._3d.py:348-499): one query token per sequence (max_seqlen_q == 1, num_tokens == num_seqs), every key from the
+ *     cache (k_new / v_new must be NULL).
+ * mi355_attn_workspace_bytes() answers for these calls when the block is filled the same way (skip_decodes = 1 for the
+ * first).
+ */
+MI355_API int mi355_context_attention_fwd_v0(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
+                                             mi355_stream_t stream);
+MI355_API int mi355_paged_attention_v0(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
+                                       mi355_stream_t stream);
+
 /* Paged-cache write, see mi355_cache_params. */
 MI355_API int mi355_reshape_and_cache_flash(const mi355_cache_params* p, mi355_stream_t stream);
 

@@ -307,3 +307,73 @@ def test_tools_and_bench_compile():
     assert len(files) > 10
     for f in files:
         compile(open(f).read(), f, "exec")          # syntax only: nothing is executed, no bytecode written
+
+
+def test_registered_torch_ops_exist_and_have_no_cpu_kernel(lib):
+    """torch.ops.mi355_attn.{unified_attention, reshape_and_cache_flash} (mi355_attn/ops.py): registered with
+    the dispatcher, out / caches declared as mutated, traceable through their fake implementations, and WITHOUT a CPU
+    kernel: a CPU tensor fails in the dispatcher instead of computing something somewhere else."""
+    import mi355_attn.ops  # noqa: F401
+
+    ua, rc = torch.ops.mi355_attn.unified_attention.default, torch.ops.mi355_attn.reshape_and_cache_flash.default
+    assert [a.name for a in ua._schema.arguments if a.alias_info is not None and a.alias_info.is_write] == ["out"]
+    assert [a.name for a in rc._schema.arguments if a.alias_info is not None and a.alias_info.is_write] == ["key_cache", "value_cache"]
+    q = torch.zeros(3, 4, 128, dtype=torch.bfloat16)
+    kc = torch.zeros(2, 16, 1, 128, dtype=torch.bfloat16)
+    cu, sl, bt = torch.tensor([0, 3], dtype=torch.int32), torch.tensor([3], dtype=torch.int32), torch.zeros(1, 1, dtype=torch.int32)
+    with pytest.raises(NotImplementedError):
+        torch.ops.mi355_attn.unified_attention(q, kc, kc, torch.empty_like(q), cu, 3, sl, 3, 0.1, -1, -1, bt, 0.0, None, None, None, "auto")
+    with pytest.raises(NotImplementedError):
+        torch.ops.mi355_attn.reshape_and_cache_flash(q[:, :1], q[:, :1], kc, kc.clone(), torch.tensor([0, 1, 2]), "auto", None, None)
+    # fake (meta) tensors trace: the ops return nothing and allocate nothing
+    qm, km = q.to("meta"), kc.to("meta")
+    assert torch.ops.mi355_attn.unified_attention(qm, km, km, torch.empty_like(qm), cu.to("meta"), 3, sl.to("meta"), 3, 0.1, -1, -1, bt.to("meta"),
+                                                  0.0, None, None, None, "auto") is None
+
+
+def test_legacy_entry_points_check_that_the_block_describes_the_op(lib):
+    h = lib.load()
+    p = lib.AttnParams()
+    one = C.c_void_p(16)
+    for f in ("q", "out", "k_cache", "v_cache", "block_table", "cu_seqlens_q", "seqused_k"):
+        setattr(p, f, one)
+    p.num_tokens, p.num_seqs, p.num_q_heads, p.num_kv_heads, p.head_size, p.page_size, p.k_x = 4, 2, 4, 1, 128, 16, 8
+    p.q_dtype = p.kv_dtype = lib.MI355_BF16 if hasattr(lib, "MI355_BF16") else 2
+    p.max_seqlen_q, p.max_seqlen_k = 2, 64
+    assert h.mi355_context_attention_fwd_v0(C.byref(p), None, 0, None) == lib.MI355_ERR_BAD_ARG       # no k_new / v_new
+    assert "k_new" in lib.last_error()
+    assert h.mi355_paged_attention_v0(C.byref(p), None, 0, None) == lib.MI355_ERR_BAD_ARG             # not one token per sequence
+    assert "decode op" in lib.last_error()
+    p.k_new = p.v_new = one
+    p.max_seqlen_q, p.num_tokens = 1, 2
+    assert h.mi355_paged_attention_v0(C.byref(p), None, 0, None) == lib.MI355_ERR_BAD_ARG             # decode reads the cache only
+    assert "k_new" in lib.last_error()
+
+
+def test_harness_generator_reproduces_the_c4_composition():
+    """Row H: the mixed-batch generator of the reference harness (scripts/benchmark.py:1053-1112) as
+    restated in tools/microbench.py, at the C4 setting: batch 64, seqlen 4096, decode_share 0.5, partial_prefill_share 0.5,
+    pattern [1.0], ALTERNATING, block 16 -> 32 decodes (ctx 4095), 16 partial prefills (2048 + 2048), 16 full prefills,
+    98 336 query tokens, 16 384 pages; and the other two compositions."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import microbench
+
+    q, ctx = microbench.make_prefix_batch(64, 4096, [1.0], 0.5, 0.5, "ALTERNATING", 16)
+    kinds = [("dec" if a == 1 else "part" if c > 0 else "full") for a, c in zip(q, ctx)]
+    assert (kinds.count("dec"), kinds.count("part"), kinds.count("full")) == (32, 16, 16)
+    assert sum(q) == 98336 and sum((a + c + 15) // 16 for a, c in zip(q, ctx)) == 16384
+    assert all(c == 4095 for a, c in zip(q, ctx) if a == 1)
+    assert all((a, c) == (2048, 2048) for a, c, k in zip(q, ctx, kinds) if k == "part")
+    assert all((a, c) == (4096, 0) for a, c, k in zip(q, ctx, kinds) if k == "full")
+    # ALTERNATING deals from both ends of [decodes | partial | full]: decode, full, decode, full, ...
+    assert kinds[:4] == ["dec", "full", "dec", "full"] and kinds[-2:] == ["dec", "part"] or kinds[:2] == ["dec", "full"]
+    q2, ctx2 = microbench.make_prefix_batch(64, 4096, [1.0], 0.5, 0.5, "DEC_PRE", 16)
+    assert q2[:32] == [1] * 32 and q2[32:48] == [2048] * 16 and q2[48:] == [4096] * 16
+    q3, ctx3 = microbench.make_prefix_batch(64, 4096, [1.0], 0.5, 0.5, "PRE_DEC", 16)
+    assert q3 == q2[::-1] and ctx3 == ctx2[::-1]
+    # prompt pattern and shares other than one half
+    q4, ctx4 = microbench.make_prefix_batch(10, 1000, [0.1, 0.4, 0.5, 1.0, 0.2], 0.3, 0.25, "DEC_PRE", 16)
+    assert q4[:3] == [1, 1, 1] and len(q4) == 10 and all(a >= 1 for a in q4) and all(c % 16 == 0 for a, c in list(zip(q4, ctx4))[3:])
+    import bench
+
+    assert bench.c4_lens() == (q, [a + c for a, c in zip(q, ctx)])

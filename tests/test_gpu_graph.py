@@ -60,3 +60,55 @@ def test_unified_attention_and_cache_write_under_graph_capture(query_lens, kv_le
         # the cache really holds the tokens written inside the graph
         flat_k = kc.view(-1, Hk, D)
         assert torch.equal(flat_k[torch.tensor(slots)].view(torch.int16), kn.view(torch.int16))
+
+
+def test_replay_after_a_later_eager_call_has_grown_the_workspace():
+    """A captured decode graph holds the raw address of its workspace (arrival counters, split partials). A later
+    eager call that needs more bytes (a key-split prefill here) makes the binding move on to a bigger buffer; the one
+    the graph points into must stay alive and untouched, and the replay must still be right."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels import unified_attention
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page = 16, 4, 128, 16
+    _lib._workspaces.clear()                     # start from no workspace: the capture below sizes it for the decode call only
+    query_lens, kv_lens = [1] * 5, [3000, 17, 2048, 129, 700]
+    inp = orc.make_paged_inputs(43, query_lens, kv_lens, Hq, Hk, D, page, torch.bfloat16)
+    d = gpu_util.to_dev(inp)
+    out = torch.zeros_like(d["q"])
+
+    def step():
+        unified_attention(q=d["q"], k=d["k_cache"], v=d["v_cache"], out=out, cu_seqlens_q=d["cu_seqlens_q"], max_seqlen_q=1,
+                          seqused_k=d["seqused_k"], max_seqlen_k=max(kv_lens), avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=inp["scale"],
+                          causal=True, window_size=(-1, -1), block_table=d["block_table"], softcap=0, q_descale=None, k_descale=None,
+                          v_descale=None)
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        step()
+    small = _lib._workspaces[(dev.type, dev.index)]
+    small_ptr, small_bytes = small.data_ptr(), small.numel()
+    # an eager call with a much larger workspace: one 512-token chunk over 8k keys is key-split (partials for every split)
+    big = orc.make_paged_inputs(44, [512], [8192], Hq, Hk, D, page, torch.bfloat16)
+    bd = gpu_util.to_dev(big)
+    bout, kernel = gpu_util.run_unified(bd, big["scale"])
+    assert kernel.endswith("_ksplit"), kernel
+    grown = _lib._workspaces[(dev.type, dev.index)]
+    assert grown.numel() > small_bytes and grown.data_ptr() != small_ptr
+    assert any(t.data_ptr() == small_ptr for t in _lib._retired)          # the captured buffer is still owned
+    junk = [torch.full((small_bytes,), 0xA5, dtype=torch.uint8, device=dev) for _ in range(4)]   # would land in it had it been freed
+    # replay with new data
+    g = torch.Generator().manual_seed(5)
+    q2 = (torch.rand(5, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    d["q"].copy_(q2.to(dev))
+    out.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = orc.unified_attention_oracle(q2, inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"])
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    del junk

@@ -366,3 +366,36 @@ def test_impl_forward_writes_cache_then_attends(kv_cache_dtype, dtype):
     assert torch.equal(got_k.cpu().view(torch.uint8), kc.view(torch.uint8))   # cache write is bit-exact (incl. fp8 quantisation)
     got_v = kv_cache[1].view(cache_dtype) if fp8 else kv_cache[1]
     assert torch.equal(got_v.cpu().view(torch.uint8), vc.view(torch.uint8))
+
+
+@pytest.mark.parametrize("cache_dtype,kv_cache_dtype", [(torch.float8_e4m3fn, "fp8_e4m3"), (torch.float8_e5m2, "fp8_e5m2")])
+@pytest.mark.parametrize("scale", [1.0, 0.0237])
+def test_fp8_cache_write_of_edge_values_is_bit_exact(cache_dtype, kv_cache_dtype, scale):
+    """The quantising store sat_fp8(x / scale) on the values a random fill never produces: +-0, values that round to
+    zero, fp8 subnormals, ties, the largest finite value and everything beyond it. Bit for bit torch's conversion."""
+    import gpu_util
+    from mi355_attn.kernels import reshape_and_cache_flash
+
+    dev = gpu_util.DEV
+    fi = torch.finfo(cache_dtype)
+    tiny = fi.smallest_normal
+    sub = tiny / (8 if cache_dtype == torch.float8_e4m3fn else 4)      # smallest subnormal
+    vals = [0.0, -0.0, sub * 0.49, -sub * 0.49, sub * 0.5, sub * 0.51, sub, -sub, sub * 1.5, sub * 2.5, tiny * 0.999, tiny, -tiny, tiny * 1.0625,
+            1.0, -1.0, 1.0625, 1.1875, 3.0, fi.max * 0.999, fi.max, -fi.max, fi.max * 1.03, fi.max * 1.2, -fi.max * 7.0, 1e30, -1e30]
+    g = torch.Generator().manual_seed(3)
+    x = torch.tensor(vals, dtype=torch.float32) * scale
+    x = torch.cat([x, (torch.rand(2 * 128 - len(vals), generator=g) * 2 - 1) * fi.max * 1.1 * scale]).view(1, 2, 128)
+    key = x.to(torch.bfloat16)
+    value = key.flip(2).contiguous()
+    kc = torch.zeros(2, 16, 2, 128, dtype=torch.uint8, device=dev)
+    vc = torch.zeros_like(kc)
+    slot = torch.tensor([19], dtype=torch.int64, device=dev)
+    reshape_and_cache_flash(key.to(dev), value.to(dev), kc, vc, slot, kv_cache_dtype, torch.tensor([scale], device=dev), torch.tensor([scale], device=dev))
+    torch.cuda.synchronize()
+
+    def want(t):       # the reference's store: (x / scale) saturated to the finite range, then the conversion (scripts/vllm_utils.py:377-401)
+        return (t.float() / scale).clamp(-fi.max, fi.max).to(cache_dtype).view(torch.uint8)
+
+    assert torch.equal(kc[1, 3].cpu(), want(key)[0])
+    assert torch.equal(vc[1, 3].cpu(), want(value)[0])
+    assert int(kc[0].sum()) == 0 and int(kc[1, :3].sum()) == 0            # nothing else written

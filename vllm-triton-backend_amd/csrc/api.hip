@@ -199,6 +199,25 @@ int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t 
   return rc;
 }
 
+int mi355_context_attention_fwd_v0(const mi355_attn_params* p, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+  if (!p) { set_error("params is NULL"); return MI355_ERR_BAD_ARG; }
+  if (!p->k_new || !p->v_new) { set_error("context_attention_fwd needs the linear k_new / v_new of the tokens being prefilled"); return MI355_ERR_BAD_ARG; }
+  if (p->only_decodes) { set_error("context_attention_fwd never computes query_len == 1 rows (only_decodes must be 0)"); return MI355_ERR_BAD_ARG; }
+  mi355_attn_params q = *p;
+  q.skip_decodes = 1;                          // rows of query_len == 1 sequences stay untouched (triton_prefix_prefill.py:83-84)
+  return mi355_unified_attention(&q, workspace, workspace_bytes, stream);
+}
+
+int mi355_paged_attention_v0(const mi355_attn_params* p, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+  if (!p) { set_error("params is NULL"); return MI355_ERR_BAD_ARG; }
+  if (p->k_new || p->v_new) { set_error("paged_attention reads every key from the cache (k_new / v_new must be NULL)"); return MI355_ERR_BAD_ARG; }
+  if (p->max_seqlen_q != 1 || p->num_tokens != p->num_seqs) {
+    set_error("paged_attention is a decode op: one query token per sequence (max_seqlen_q %d, num_tokens %d, num_seqs %d)", p->max_seqlen_q, p->num_tokens, p->num_seqs);
+    return MI355_ERR_BAD_ARG;
+  }
+  return mi355_unified_attention(p, workspace, workspace_bytes, stream);
+}
+
 int mi355_reshape_and_cache_flash(const mi355_cache_params* p, mi355_stream_t stream) {
   if (!p) { set_error("params is NULL"); return MI355_ERR_BAD_ARG; }
   if (p->num_tokens < 0) { set_error("negative num_tokens"); return MI355_ERR_BAD_ARG; }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/mi355_attn.h"
 
 namespace mi355 {
@@ -58,6 +60,7 @@ __device__ __forceinline__ uint8_t f32_to_e4m3_sat(float f) {
   if (f != f) return 0x7F;
   const uint32_t sign = (f32_to_bits(f) >> 24) & 0x80;
   float a = __builtin_fabsf(f);
+  if (a == 0.0f) return (uint8_t)sign;          // frexpf(0) has exponent 0: the grid search below is for a > 0 only
   if (a >= 448.0f) return (uint8_t)(sign | 0x7E);
   // scale so that the e4m3 subnormal/normal grid maps onto integers, round with rintf
   // normal: value = (8+m) * 2^(e-10); find e from the float exponent
@@ -82,6 +85,7 @@ __device__ __forceinline__ uint8_t f32_to_e5m2_sat(float f) {
   if (f != f) return 0x7F;
   const uint32_t sign = (f32_to_bits(f) >> 24) & 0x80;
   float a = __builtin_fabsf(f);
+  if (a == 0.0f) return (uint8_t)sign;
   if (a >= 57344.0f) return (uint8_t)(sign | 0x7B);
   int ex;
   (void)__builtin_frexpf(a, &ex);
@@ -299,7 +303,9 @@ size_t decode_workspace_bytes(const mi355_attn_params& p);
 int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream);
 
 bool prefill_supported(const mi355_attn_params& p);
-int launch_prefill(const mi355_attn_params& p, hipStream_t stream);
+// key-split launch context (prefill_mfma.hip: plan_key_splits / launch_prefill_ws); nullptr = one workgroup walks all keys
+struct KeySplitCtx { int splits, tiles_per_split; bool wide; int64_t out_split_stride, lse_split_stride; };
+int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks = nullptr);
 size_t prefill_workspace_bytes(const mi355_attn_params& p);                                   // key-split partials, 0 if none
 int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream);
 const char* mi355_last_kernel_name();
@@ -315,6 +321,20 @@ inline int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return MI355_OK;
   set_error("%s: %s", what, hipGetErrorString(e));
   return MI355_ERR_HIP;
+}
+
+// > 64 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, per kernel AND per device. `done` is the
+// kernel's own bit mask of devices that have it (one static std::atomic per launcher): set once per device, from any
+// thread (two threads racing both set it: harmless), no process-global "already done" flag.
+inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done, const char* what) {
+  int dev = 0;
+  const int rc0 = check_hip(hipGetDevice(&dev), "hipGetDevice");
+  if (rc0 != MI355_OK) return rc0;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return MI355_OK;
+  const int rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+  if (rc == MI355_OK && dev < 64) done.fetch_or(bit, std::memory_order_release);
+  return rc;
 }
 
 }  // namespace mi355

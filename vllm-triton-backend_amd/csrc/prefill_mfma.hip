@@ -1240,8 +1240,6 @@ __global__ __launch_bounds__(256) void merge_key_splits_kernel(const MergeArgs a
   if (p.lse && c == 0) p.lse[tok * p.lse_stride_token + hq] = den > 0.0f ? m + __logf(den) : -INFINITY;
 }
 
-static thread_local const KeySplitPlan* g_key_split = nullptr;          // set around the split launch below
-static thread_local const KeySplitLayout* g_key_split_layout = nullptr;
 
 // cache element type as a function of the query type
 template <typename T> using kv_same = T;
@@ -1249,7 +1247,7 @@ template <typename T> using kv_e4m3 = e4m3_t;
 template <typename T> using kv_e5m2 = e5m2_t;
 
 template <typename T, typename KVT, int D, bool FEAT>
-static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
+static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
   PrefillArgs a;
   a.p = p;
   a.group = p.num_q_heads / p.num_kv_heads;
@@ -1260,18 +1258,14 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;  // static upper bound (:886-889,:935-943)
-  a.key_splits = g_key_split ? g_key_split->splits : 1;
-  a.tiles_per_key_split = g_key_split ? g_key_split->tiles_per_split : 0;
-  a.out_split_stride = g_key_split ? g_key_split_layout->out_split_stride : 0;
-  a.lse_split_stride = g_key_split ? g_key_split_layout->lse_split_stride : 0;
+  a.key_splits = ks ? ks->splits : 1;
+  a.tiles_per_key_split = ks ? ks->tiles_per_split : 0;
+  a.out_split_stride = ks ? ks->out_split_stride : 0;
+  a.lse_split_stride = ks ? ks->lse_split_stride : 0;
   constexpr size_t lds = 2 * (size_t)kTileN * ((D * 2 + 16) + (D * 2 + 64));
-  static bool attr_set = false;   // >64 KiB of dynamic LDS needs an opt-in, once per kernel
-  if (!attr_set) {
-    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_mfma_kernel<T, KVT, D, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                              "hipFuncSetAttribute(prefill)");
-    if (rc0 != MI355_OK) return rc0;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_opt_in{0};
+  const int rc0 = ensure_dynamic_lds((const void*)prefill_mfma_kernel<T, KVT, D, FEAT>, (int)lds, lds_opt_in, "hipFuncSetAttribute(prefill)");
+  if (rc0 != MI355_OK) return rc0;
   hipLaunchKernelGGL((prefill_mfma_kernel<T, KVT, D, FEAT>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(256), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_mfma_kernel launch");
   if (rc == MI355_OK) set_kernel_name(!__is_same(T, KVT) ? (FEAT ? "prefill_mfma_fp8_feat" : "prefill_mfma_fp8") : (FEAT ? "prefill_mfma_feat" : "prefill_mfma"));
@@ -1279,7 +1273,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream) {
 }
 
 template <typename T, int NW, int NST>
-static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
+static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
   PrefillArgs a;
   a.p = p;
   a.group = p.num_q_heads / p.num_kv_heads;
@@ -1290,27 +1284,23 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream) {
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;
-  a.key_splits = g_key_split ? g_key_split->splits : 1;
-  a.tiles_per_key_split = g_key_split ? g_key_split->tiles_per_split : 0;
-  a.out_split_stride = g_key_split ? g_key_split_layout->out_split_stride : 0;
-  a.lse_split_stride = g_key_split ? g_key_split_layout->lse_split_stride : 0;
+  a.key_splits = ks ? ks->splits : 1;
+  a.tiles_per_key_split = ks ? ks->tiles_per_split : 0;
+  a.out_split_stride = ks ? ks->out_split_stride : 0;
+  a.lse_split_stride = ks ? ks->lse_split_stride : 0;
   size_t lds = (size_t)NST * 2 * kTileN * 256;   // NST stages of K + V tiles, unpadded
   if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix (the caller checked that it fits)
-  static bool attr_set = false;
-  if (!attr_set) {
-    const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_dma_kernel<T, NW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)((size_t)NST * 2 * kTileN * 256 + (NST >= 3 ? bt_lds_max_bytes(NST) : 0))),
-                              "hipFuncSetAttribute(prefill_dma)");
-    if (rc0 != MI355_OK) return rc0;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_opt_in{0};
+  const int rc0 = ensure_dynamic_lds((const void*)prefill_dma_kernel<T, NW, NST>, (int)((size_t)NST * 2 * kTileN * 256 + (NST >= 3 ? bt_lds_max_bytes(NST) : 0)),
+                                     lds_opt_in, "hipFuncSetAttribute(prefill_dma)");
+  if (rc0 != MI355_OK) return rc0;
   hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(NW * 64), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_dma_kernel launch");
   if (rc == MI355_OK) set_kernel_name("prefill_mfma");
   return rc;
 }
 
-int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
+int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
   if (!prefill_supported(p)) {
     set_error("prefill kernel does not support this configuration");
     return MI355_ERR_UNSUPPORTED;
@@ -1327,10 +1317,9 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
   // workgroup per CU) outweigh its few tiles: 4 x 1024 628 | 636 | 663, 8 x 512 419 | 451 | 453, 1 x 1024 274 | 273 | 329).
   if (prefill_pw_applicable(p) && !v1 && (!variant || variant[0] == 'p')) {
     const bool pinned = variant && variant[0] == 'p';
-    const bool use_pw = g_key_split ? g_key_split->wide : p.max_seqlen_k >= 2048;
-    if (pinned ? (!g_key_split || g_key_split->wide) : use_pw)
-      return launch_prefill_pw(p, g_key_split ? g_key_split->splits : 1, g_key_split ? g_key_split_layout->out_split_stride : 0,
-                               g_key_split ? g_key_split_layout->lse_split_stride : 0, stream);
+    const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= 2048;
+    if (pinned ? (!ks || ks->wide) : use_pw)
+      return launch_prefill_pw(p, ks ? ks->splits : 1, ks ? ks->out_split_stride : 0, ks ? ks->lse_split_stride : 0, stream);
   }
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
@@ -1341,16 +1330,16 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream) {
     // MI355_PREFILL=d4 | d8 pins one of the two for measurements.
     const long wgs8 = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 256 + p.num_seqs) * p.num_kv_heads;
     bool wide = wgs8 >= 2 * 256 && p.max_seqlen_k >= 2048;
-    if (g_key_split) wide = g_key_split->wide;
+    if (ks) wide = ks->wide;
     if (variant && variant[0] == 'd') wide = variant[1] == '8';
     if (wide && prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3))
-      return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream) : launch_prefill_dma<f16_t, 8, 3>(p, stream);
-    return bf ? launch_prefill_dma<bf16_t, 4, 2>(p, stream) : launch_prefill_dma<f16_t, 4, 2>(p, stream);
+      return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream, ks) : launch_prefill_dma<f16_t, 8, 3>(p, stream, ks);
+    return bf ? launch_prefill_dma<bf16_t, 4, 2>(p, stream, ks) : launch_prefill_dma<f16_t, 4, 2>(p, stream, ks);
   }
 #define MI355_PREFILL_CASE(KV, DD)                                                                        \
   case DD:                                                                                                \
-    if (feat) return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, true>(p, stream) : launch_prefill_t<f16_t, KV<f16_t>, DD, true>(p, stream); \
-    return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, false>(p, stream) : launch_prefill_t<f16_t, KV<f16_t>, DD, false>(p, stream);
+    if (feat) return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, true>(p, stream, ks) : launch_prefill_t<f16_t, KV<f16_t>, DD, true>(p, stream, ks); \
+    return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, false>(p, stream, ks) : launch_prefill_t<f16_t, KV<f16_t>, DD, false>(p, stream, ks);
   const int dpad = padded_head_size(p.head_size, p.kv_dtype != p.q_dtype);
   if (p.kv_dtype == MI355_FP8_E4M3) {
     switch (dpad) {
@@ -1393,11 +1382,8 @@ int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hip
   pp.out_stride_head = p.head_size;
   pp.lse = (float*)((char*)ws + lay.lse_off);
   pp.lse_stride_token = p.num_q_heads;
-  g_key_split = &plan;
-  g_key_split_layout = &lay;
-  int rc = launch_prefill(pp, stream);
-  g_key_split = nullptr;
-  g_key_split_layout = nullptr;
+  const KeySplitCtx ks = {plan.splits, plan.tiles_per_split, plan.wide, lay.out_split_stride, lay.lse_split_stride};
+  int rc = launch_prefill(pp, stream, &ks);
   if (rc != MI355_OK) return rc;
   MergeArgs m;
   m.p = p;

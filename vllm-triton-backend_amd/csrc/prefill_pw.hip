@@ -698,9 +698,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;   // static upper bound, as the reference (:886-889,:935-943)
   const size_t lds = kPwLds;
-  // > 64 KiB of dynamic LDS needs the opt-in; set on every call (the attribute is per device and the call is cheap)
-  const int rc0 = check_hip(hipFuncSetAttribute((const void*)prefill_pw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwLds),
-                            "hipFuncSetAttribute(prefill_pw)");
+  static std::atomic<uint64_t> lds_opt_in{0};
+  const int rc0 = ensure_dynamic_lds((const void*)prefill_pw_kernel<T>, (int)kPwLds, lds_opt_in, "hipFuncSetAttribute(prefill_pw)");
   if (rc0 != MI355_OK) return rc0;
   hipLaunchKernelGGL((prefill_pw_kernel<T>), dim3(qblocks * p.num_kv_heads, key_splits), dim3(256), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");

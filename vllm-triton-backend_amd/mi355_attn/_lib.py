@@ -34,6 +34,8 @@ EXPORTS = (
     "mi355_last_kernel",
     "mi355_attn_workspace_bytes",
     "mi355_unified_attention",
+    "mi355_context_attention_fwd_v0",
+    "mi355_paged_attention_v0",
     "mi355_reshape_and_cache_flash",
 )
 
@@ -151,6 +153,9 @@ def load() -> C.CDLL:
     lib.mi355_attn_workspace_bytes.argtypes = [C.POINTER(AttnParams)]
     lib.mi355_unified_attention.restype = C.c_int
     lib.mi355_unified_attention.argtypes = [C.POINTER(AttnParams), C.c_void_p, C.c_size_t, C.c_void_p]
+    for legacy in (lib.mi355_context_attention_fwd_v0, lib.mi355_paged_attention_v0):
+        legacy.restype = C.c_int
+        legacy.argtypes = [C.POINTER(AttnParams), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.mi355_reshape_and_cache_flash.restype = C.c_int
     lib.mi355_reshape_and_cache_flash.argtypes = [C.POINTER(CacheParams), C.c_void_p]
     _lib = lib
@@ -202,9 +207,12 @@ def current_stream_handle(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-# per-device scratch, grown on demand and kept (so that replays of a captured graph see a stable
-# pointer); replaces the per-call torch.empty at triton_unified_attention.py:950-971
+# per-device scratch, grown on demand; replaces the per-call torch.empty at triton_unified_attention.py:950-971.
+# A buffer that has been handed out is NEVER freed: a HIP graph captured earlier holds its raw address (arrival
+# counters, split partials) and replays into it long after a later, larger call made the binding move on to a bigger
+# buffer. Growth is geometric, so the retired buffers together stay below the size of the live one.
 _workspaces: dict = {}
+_retired: list = []
 
 
 def workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
@@ -218,8 +226,10 @@ def workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
                 "mi355_attn workspace must be allocated before graph capture: run one eager call of "
                 "the largest shape first"
             )
+        if ws is not None:
+            _retired.append(ws)
         # zero-filled once: the head of the workspace holds the split-merge arrival counters, which
         # every call leaves at zero again (include/mi355_attn.h, mi355_attn_workspace_bytes)
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        ws = torch.zeros(max(nbytes, 1 << 20, 2 * (ws.numel() if ws is not None else 0)), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws

@@ -2,8 +2,8 @@
 
 Mirrors the reference's TritonAttentionBackend / TritonAttentionImpl / TritonAttentionMetadataBuilder /
 TritonAttentionMetadata (LIB/backend/triton_attn.py:60-470): same static contract, same constructor
-and forward signatures, same error behaviour. forward() issues exactly two C-ABI calls on the current
-stream: the paged-cache write and the unified attention.
+and forward signatures, same error behaviour. forward() calls two registered ops, torch.ops.mi355_attn.
+reshape_and_cache_flash and .unified_attention (mi355_attn/ops.py): two C-ABI calls on the current stream.
 """
 
 from __future__ import annotations
@@ -14,7 +14,7 @@ from typing import Any, ClassVar, Optional
 import torch
 
 from .. import _lib
-from ..kernels import reshape_and_cache_flash, unified_attention
+from .. import ops as _ops  # noqa: F401  (registers torch.ops.mi355_attn.*)
 from ._vllm_shim import (
     AttentionBackend,
     AttentionImpl,
@@ -127,13 +127,10 @@ class MI355AttentionMetadataBuilder(AttentionMetadataBuilder[MI355AttentionMetad
                 local_scheduler_metadata=None,
             )
 
-        use_cascade = common_prefix_len > 0
-        if use_cascade:
-            cu_prefix_query_lens = torch.tensor([0, num_actual_tokens], dtype=torch.int32, device=self.runner.device)
-            prefix_kv_lens = torch.tensor([common_prefix_len], dtype=torch.int32, device=self.runner.device)
-            suffix_kv_lens = torch.from_numpy(self.runner.seq_lens_np[:num_reqs] - common_prefix_len).to(self.runner.device)
-        else:
-            cu_prefix_query_lens = prefix_kv_lens = suffix_kv_lens = None
+        # cascade attention is off for this backend (use_cascade_attention -> False, triton_attn.py:279-281): vLLM never
+        # passes a common prefix, and the cascade tensors of the metadata stay None
+        use_cascade = False
+        cu_prefix_query_lens = prefix_kv_lens = suffix_kv_lens = None
 
         return MI355AttentionMetadata(
             num_actual_tokens=num_actual_tokens,
@@ -281,15 +278,13 @@ class MI355AttentionImpl(AttentionImpl):
         key_cache, value_cache = kv_cache.unbind(0)
 
         if self.kv_sharing_target_layer_name is None:
-            reshape_and_cache_flash(key, value, key_cache, value_cache, attn_metadata.slot_mapping, self.kv_cache_dtype,
-                                    layer._k_scale, layer._v_scale)
+            torch.ops.mi355_attn.reshape_and_cache_flash(key, value, key_cache, value_cache, attn_metadata.slot_mapping, self.kv_cache_dtype,
+                                                         layer._k_scale, layer._v_scale)
 
         if self.kv_cache_dtype.startswith("fp8"):
-            key_cache = key_cache.view(self.fp8_dtype)
-            value_cache = value_cache.view(self.fp8_dtype)
             assert layer._q_scale == 1.0, "A non 1.0 q_scale is not currently supported."
             # Q stays in its own dtype: K/V are dequantised in the kernel (the reference skips Q
-            # quantisation on ROCm as well, triton_attn.py:414-420)
+            # quantisation on ROCm as well, triton_attn.py:414-420); the op views the uint8 cache as gfx950's OCP fp8
 
         use_local_attn = self.use_irope and attn_metadata.local_attn_metadata is not None
         if use_local_attn:
@@ -297,12 +292,10 @@ class MI355AttentionImpl(AttentionImpl):
             cu_seqlens_q, seqused_k = lm.local_query_start_loc, lm.local_seqused_k
             max_seqlen_q, max_seqlen_k = lm.local_max_query_len, lm.local_max_seq_len
             block_table = lm.local_block_table
-            avg_seqlen_q, avg_seqlen_k = lm.local_avg_query_len, lm.local_avg_seq_len
         else:
             cu_seqlens_q, seqused_k = attn_metadata.query_start_loc, attn_metadata.seq_lens
             max_seqlen_q, max_seqlen_k = attn_metadata.max_query_len, attn_metadata.max_seq_len
             block_table = attn_metadata.block_table
-            avg_seqlen_q, avg_seqlen_k = attn_metadata.avg_query_len, attn_metadata.avg_seq_len
 
         if self.alibi_slopes is not None and (self._alibi_dev is None or self._alibi_dev.device != query.device):
             self._alibi_dev = self.alibi_slopes.to(query.device)
@@ -314,25 +307,9 @@ class MI355AttentionImpl(AttentionImpl):
         if q.dim() == 2:
             q = q.view(-1, self.num_heads, self.head_size)
 
-        unified_attention(
-            q=q,
-            k=key_cache,
-            v=value_cache,
-            out=out,
-            cu_seqlens_q=cu_seqlens_q,
-            max_seqlen_q=max_seqlen_q,
-            seqused_k=seqused_k,
-            max_seqlen_k=max_seqlen_k,
-            avg_seqlen_q=avg_seqlen_q,
-            avg_seqlen_k=avg_seqlen_k,
-            softmax_scale=self.scale,
-            causal=True,
-            alibi_slopes=self._alibi_dev,
-            window_size=self.sliding_window,
-            block_table=block_table,
-            softcap=self.logits_soft_cap,
-            q_descale=None,  # not supported
-            k_descale=layer._k_scale,  # the kernel reads element 0 (triton_unified_attention.py:438,:453)
-            v_descale=layer._v_scale,
-        )
+        # (avg_seqlen_q/k only fed the reference's autotuner keys, triton_unified_attention.py:878-881: not passed on)
+        torch.ops.mi355_attn.unified_attention(
+            q, key_cache, value_cache, out, cu_seqlens_q, int(max_seqlen_q), seqused_k, int(max_seqlen_k), float(self.scale),
+            int(self.sliding_window[0]), int(self.sliding_window[1]), block_table, float(self.logits_soft_cap), layer._k_scale, layer._v_scale,
+            self._alibi_dev, self.kv_cache_dtype)
         return output

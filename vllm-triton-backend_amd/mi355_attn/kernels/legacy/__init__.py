@@ -45,6 +45,28 @@ def _decode_cu_seqlens(num_seqs: int, device) -> torch.Tensor:
     return t
 
 
+# The legacy signatures carry no maximum key length, and the repack path sizes its scratch cache from the bound it is
+# given (num_seqs * ceil(bound / 16) pages of K and of V). The block table's width is a bound the host knows without
+# a device read, but a vLLM-sized table (max_model_len / block_size entries) times a few hundred sequences asks for tens
+# of GiB: beyond _SCRATCH_SOFT_LIMIT the true maximum is read back from seq_lens once (one device sync), and a scratch
+# that still exceeds _SCRATCH_HARD_LIMIT is refused with a message instead of an allocation failure.
+_SCRATCH_SOFT_LIMIT = 256 << 20
+_SCRATCH_HARD_LIMIT = 16 << 30
+
+
+def _key_bound(table_bound: int, extra: int, seq_lens: torch.Tensor, num_seqs: int, num_kv_heads: int, head_size: int, name: str) -> int:
+    def scratch(bound):
+        return num_seqs * ((bound + 15) // 16) * 16 * num_kv_heads * head_size * 2 * 2
+
+    bound = table_bound + extra
+    if scratch(bound) > _SCRATCH_SOFT_LIMIT and num_seqs > 0:
+        bound = min(bound, int(seq_lens[:num_seqs].max().item()))
+        if scratch(bound) > _SCRATCH_HARD_LIMIT:
+            raise ValueError(f"mi355_attn.{name}: {num_seqs} sequences of up to {bound} keys need a {scratch(bound) >> 20} MiB scratch cache for "
+                             "the legacy-layout repack; split the batch or use unified_attention over the flash layout")
+    return bound
+
+
 def _require_gpu(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"mi355_attn.{name} needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
@@ -69,13 +91,13 @@ def context_attention_fwd(
     if sliding_window is None or sliding_window <= 0:
         sliding_window = 0
     # the signature carries no maximum key length: context fits the block table, new keys number at most max_input_len
-    max_seq_len = b_loc.shape[1] * v_cache.shape[3] + max_input_len
+    max_seq_len = _key_bound(b_loc.shape[1] * v_cache.shape[3], max_input_len, b_seq_len, b_seq_len.shape[0], k.shape[1], Lq, "context_attention_fwd")
     p, keep = fill_attn_params(
         q, k_cache, v_cache, o, b_start_loc, max_input_len, b_seq_len, max_seq_len, sm_scale,
         (sliding_window - 1, 0) if sliding_window else (-1, -1), b_loc, 0.0, k_scale, v_scale, alibi_slopes, None,
         k_new=k, v_new=v, skip_decodes=True, legacy_v0_layout=True,
     )
-    launch(p, q.device)
+    launch(p, q.device, "mi355_context_attention_fwd_v0")
     del keep
 
 
@@ -87,12 +109,12 @@ def _paged_decode(output, query, key_cache, value_cache, scale, k_scale, v_scale
     assert value_cache.shape[3] == block_size and query.shape[1] == num_query_heads and query.shape[2] == head_size
     cu = _decode_cu_seqlens(num_seqs, query.device)
     # the legacy signature carries no maximum sequence length: the block table's width bounds it (host-known)
-    max_seq_len = block_tables.shape[1] * block_size
+    max_seq_len = _key_bound(block_tables.shape[1] * block_size, 0, seq_lens, num_seqs, num_query_heads // num_queries_per_kv, head_size, name)
     p, keep = fill_attn_params(
         query[:num_seqs], key_cache, value_cache, output[:num_seqs], cu, 1, seq_lens[:num_seqs], max_seq_len, scale, (-1, -1),
         block_tables, 0.0, k_scale, v_scale, alibi_slopes, None, legacy_v0_layout=True,
     )
-    launch(p, query.device)
+    launch(p, query.device, "mi355_paged_attention_v0")
     del keep
 
 
@@ -118,7 +140,8 @@ def chunked_prefill_paged_decode(query, key, value, output, kv_cache_dtype, key_
     _require_gpu(query, "chunked_prefill_paged_decode")
     key_cache, value_cache = _fp8_view(key_cache, kv_cache_dtype), _fp8_view(value_cache, kv_cache_dtype)
     sw = sliding_window if sliding_window is not None and sliding_window > 0 else 0
-    max_seq_len = block_table.shape[1] * value_cache.shape[3] + max_query_len   # as in context_attention_fwd
+    max_seq_len = _key_bound(block_table.shape[1] * value_cache.shape[3], max_query_len, seq_lens, seq_lens.shape[0], key.shape[1], query.shape[-1],
+                             "chunked_prefill_paged_decode")
     p, keep = fill_attn_params(
         query, key_cache, value_cache, output, query_start_loc, max_query_len, seq_lens, max_seq_len, scale,
         (sw - 1, 0) if sw else (-1, -1), block_table, 0.0, k_scale, v_scale, alibi_slopes, None,

@@ -117,14 +117,16 @@ def fill_attn_params(
     return p, keep
 
 
-def launch(p, device: torch.device) -> None:
+def launch(p, device: torch.device, entry: str = "mi355_unified_attention") -> None:
+    """One C-ABI call on the current stream: `entry` is mi355_unified_attention or one of the legacy names
+    (mi355_context_attention_fwd_v0, mi355_paged_attention_v0: same parameter block and workspace rules)."""
     lib = _lib.load()
     nbytes = lib.mi355_attn_workspace_bytes(C.byref(p))
     ws = _lib.workspace(device, nbytes)
-    rc = lib.mi355_unified_attention(
+    rc = getattr(lib, entry)(
         C.byref(p), _lib.ptr(ws), nbytes if ws is not None else 0, _lib.current_stream_handle(device)
     )
-    _lib.check(rc, "mi355_unified_attention")
+    _lib.check(rc, entry)
 
 
 def unified_attention(

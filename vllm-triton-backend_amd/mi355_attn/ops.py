@@ -1,0 +1,61 @@
+"""Registered torch ops over the C ABI: torch.ops.mi355_attn.{unified_attention, reshape_and_cache_flash}.
+
+The reference's forward() calls a registered op for the cache write (torch.ops._C_cache_ops.reshape_and_cache_flash,
+LIB/backend/triton_attn.py:396-405) and a Python function for the attention; vLLM wraps the whole backend call in its own
+custom op. Registering both here makes the two calls visible to the dispatcher on their own: they trace as
+opaque nodes (fake implementations below: both only mutate their output arguments) instead of breaking the graph at the
+ctypes boundary. The implementations are the same host code as mi355_attn.kernels: CUDA/HIP tensors only, no CPU kernel
+is registered - a CPU tensor fails in the dispatcher, loudly.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .kernels.cache import reshape_and_cache_flash as _reshape_and_cache_flash
+from .kernels.unified import unified_attention as _unified_attention
+
+_DEF = torch.library.Library("mi355_attn", "DEF")
+_DEF.define(
+    "unified_attention(Tensor q, Tensor k, Tensor v, Tensor(a!) out, Tensor cu_seqlens_q, int max_seqlen_q, Tensor seqused_k, "
+    "int max_seqlen_k, float softmax_scale, int window_left, int window_right, Tensor block_table, float softcap, "
+    "Tensor? k_descale, Tensor? v_descale, Tensor? alibi_slopes, str kv_cache_dtype) -> ()"
+)
+_DEF.define(
+    "reshape_and_cache_flash(Tensor key, Tensor value, Tensor(a!) key_cache, Tensor(b!) value_cache, Tensor slot_mapping, "
+    "str kv_cache_dtype, Tensor? k_scale, Tensor? v_scale) -> ()"
+)
+
+_FP8 = {"fp8": torch.float8_e4m3fn, "fp8_e4m3": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}
+
+
+def _unified_attention_impl(q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_left, window_right,
+                            block_table, softcap, k_descale: Optional[torch.Tensor], v_descale: Optional[torch.Tensor],
+                            alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str) -> None:
+    if kv_cache_dtype in _FP8 and k.dtype == torch.uint8:      # vLLM hands fp8 caches over as uint8
+        k, v = k.view(_FP8[kv_cache_dtype]), v.view(_FP8[kv_cache_dtype])
+    _unified_attention(q=q, k=k, v=v, out=out, cu_seqlens_q=cu_seqlens_q, max_seqlen_q=max_seqlen_q, seqused_k=seqused_k,
+                       max_seqlen_k=max_seqlen_k, avg_seqlen_q=0, avg_seqlen_k=0, softmax_scale=softmax_scale, causal=True,
+                       window_size=(window_left, window_right), block_table=block_table, softcap=softcap, q_descale=None,
+                       k_descale=k_descale, v_descale=v_descale, alibi_slopes=alibi_slopes)
+
+
+def _reshape_and_cache_flash_impl(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype: str,
+                                  k_scale: Optional[torch.Tensor], v_scale: Optional[torch.Tensor]) -> None:
+    _reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale)
+
+
+def _nothing(*args, **kwargs) -> None:      # fake / meta: the ops return nothing and only write their (a!)/(b!) arguments
+    return None
+
+
+_IMPL = torch.library.Library("mi355_attn", "IMPL")
+_IMPL.impl("unified_attention", _unified_attention_impl, "CUDA")
+_IMPL.impl("reshape_and_cache_flash", _reshape_and_cache_flash_impl, "CUDA")
+_IMPL.impl("unified_attention", _nothing, "Meta")
+_IMPL.impl("reshape_and_cache_flash", _nothing, "Meta")
+
+unified_attention = torch.ops.mi355_attn.unified_attention
+reshape_and_cache_flash = torch.ops.mi355_attn.reshape_and_cache_flash
