@@ -112,3 +112,68 @@ def test_replay_after_a_later_eager_call_has_grown_the_workspace():
     ref = orc.unified_attention_oracle(q2, inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"])
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
     del junk
+
+
+def test_decode_graph_captured_at_max_model_len_replays_any_length():
+    """vLLM captures full graphs with max_seq_len = max_model_len (seq_lens = 1 during capture) and replays them on
+    whatever the batch holds. The split COUNT is frozen by the capture; how many tiles a split walks is decided on the
+    device from each row's own length (reference: kernel_unified_attention_3d :592), so every replay is right AND a
+    512-key replay is not left to a single split sized for 131072 keys."""
+    import gpu_util
+    from mi355_attn.kernels import unified_attention
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page, B = 8, 2, 128, 16, 4
+    cap_len = 131072
+    pages_per_seq = cap_len // page
+    g = torch.Generator().manual_seed(47)
+    nb = B * 6300 + 8
+    k = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    v = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    bt = torch.zeros(B, pages_per_seq, dtype=torch.int32)
+    perm = torch.randperm(nb, generator=g).to(torch.int32)
+    for i in range(B):
+        bt[i, :6300] = perm[i * 6300:(i + 1) * 6300]
+    q = (torch.rand(B, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    cu = torch.arange(B + 1, dtype=torch.int32)
+    d = dict(q=q.to(dev), k=k.to(dev), v=v.to(dev), bt=bt.to(dev), cu=cu.to(dev), sl=torch.ones(B, dtype=torch.int32, device=dev))
+    out = torch.zeros_like(d["q"])
+    scale = 1.0 / (D ** 0.5)
+
+    def step(max_k):
+        unified_attention(q=d["q"], k=d["k"], v=d["v"], out=out, cu_seqlens_q=d["cu"], max_seqlen_q=1, seqused_k=d["sl"], max_seqlen_k=max_k,
+                          avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=scale, causal=True, window_size=(-1, -1), block_table=d["bt"], softcap=0,
+                          q_descale=None, k_descale=None, v_descale=None)
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step(cap_len)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        step(cap_len)
+
+    def timed(fn, n=40):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    for lens in ([17, 1, 5, 30], [512, 300, 512, 17], [8192, 8000, 100, 8192], [100000, 512, 65536, 99999]):
+        d["sl"].copy_(torch.tensor(lens, dtype=torch.int32))
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = orc.unified_attention_oracle(q, k, v, cu, torch.tensor(lens, dtype=torch.int32), bt, scale)
+        assert not torch.isnan(out).any(), lens
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+        if lens[0] == 512:
+            t_replay = timed(graph.replay)
+            t_eager = timed(lambda: step(512))                  # planned on the host for 512 keys
+            assert t_replay <= 1.5 * t_eager + 0.01, (t_replay, t_eager)

@@ -106,6 +106,9 @@ __device__ __forceinline__ float sum_over_lane_groups(float v) {
   return v + lane_xor16(v);
 }
 
+// tiles one split of a row walks: the row's own tiles dealt evenly over the (host-fixed) number of splits
+__device__ __forceinline__ int split_tiles(int n_tiles, int num_splits) { return max(1, (n_tiles + num_splits - 1) / num_splits); }
+
 // Shared by both kernels: which token a work unit is, and the key range it may see.
 struct RowInfo {
   int token, seq, q_len, ctx_len, q_pos, n_keys, first_key;
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     if (unit >= p.num_seqs || p.skip_decodes) return;
     load_q(unit);
     const int t0s = split * a.tiles_per_split;
-    const int last_blk = ((p.max_seqlen_k + p.page_size - 1) >> a.page_shift) - 1;
+    // (speculative: the entries are used only if this row's own split size puts the split where the host's did; any
+    // index inside the row is safe to read)
+    const int last_blk = max(0, min(((p.max_seqlen_k + p.page_size - 1) >> a.page_shift) - 1, (int)p.block_table_stride - 1));
     int seq_len;
     scalar_load_word_and_pair(p.seqused_k + unit, p.block_table + (int64_t)unit * p.block_table_stride,
                               min((t0s * 2 * 16) >> a.page_shift, last_blk), min(((t0s * 2 + 1) * 16) >> a.page_shift, last_blk),
@@ -229,8 +234,13 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 
   const int tile_lo = first_key / kTileKeys;
   const int tile_hi = (n_keys + kTileKeys - 1) / kTileKeys;
-  const int t0 = tile_lo + split * a.tiles_per_split;
-  const int t1 = min(t0 + a.tiles_per_split, tile_hi);
+  // The split COUNT is host arithmetic (capture-stable); how many tiles a split walks is decided here, from THIS row's
+  // own length, like the reference's 3D kernel (tiles_per_segment = cdiv(seq_len, NUM_SEGMENTS * TILE), :592): a graph
+  // captured at max_model_len and replayed on short sequences still spreads every row over all its splits, and a
+  // sequence longer than the host's max_seqlen_k is still read to its end.
+  const int tps = split_tiles(tile_hi - tile_lo, a.num_splits);
+  const int t0 = tile_lo + split * tps;
+  const int t1 = min(t0 + tps, tile_hi);
   const bool direct = a.num_splits == 1;
   if (t0 >= t1) {
     if (split == 0 && g_ok) {  // no visible key at all (no split has a tile): the reference returns acc/L = 0/1 = 0
@@ -329,7 +339,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
   for (int b = 0; b < DBLK; ++b) o_acc[b] = f32x4_t{0, 0, 0, 0};
 
-  if (fast_head) {   // looked up with the sequence length; a second group past the sequence re-reads the first
+  if (fast_head && t0 == split * a.tiles_per_split) {
+    // looked up with the sequence length, at the tile the host's split size predicted (the usual eager call: lengths
+    // near max_seqlen_k); a second group past the sequence re-reads the first
     pg[0] = pg_first[0];
     pg[1] = (t0 * 2 + 1 > last_group) ? pg_first[0] : pg_first[1];
   } else {
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   // ---- in-kernel merge by the last-arriving split of this (unit, KV head) (reference: reduce_segments, :757-836)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains before it signals
   const int n_tiles = max(0, tile_hi - tile_lo);
-  const int active = min(a.num_splits, (n_tiles + a.tiles_per_split - 1) / a.tiles_per_split);
+  const int active = min(a.num_splits, (n_tiles + tps - 1) / tps);
   int* cnt = a.ws_cnt + (unit * Hk + head);
   int ticket = 0;
   if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -605,7 +617,8 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
   const int tile_lo = ri.first_key / kTileKeys;
   const int tile_hi = (ri.n_keys + kTileKeys - 1) / kTileKeys;
   const int n_tiles = max(0, tile_hi - tile_lo);
-  const int active = min(a.num_splits, (n_tiles + a.tiles_per_split - 1) / a.tiles_per_split);
+  const int tps = split_tiles(n_tiles, a.num_splits);
+  const int active = min(a.num_splits, (n_tiles + tps - 1) / tps);
   const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
   const int r = tid / LPS, col = tid % LPS;
 
