@@ -132,7 +132,7 @@ def run_unified(ua, inp, *, window=0, softcap=0.0, alibi=None, k_scale=None, v_s
 
 
 def unified_case(ua, name, *, seed, query_lens, kv_lens, hq, hk, d, page, dtype, kv_dtype=None, kv_scale=1.0,
-                 window=0, softcap=0.0, use_alibi=False, force=None, tile=(16, 16), num_pages=None):
+                 window=0, softcap=0.0, use_alibi=False, force=None, tile=(16, 16), num_pages=None, v_scale=None):
     inp = make_paged_inputs(seed, query_lens, kv_lens, hq, hk, d, page, dtype, kv_dtype=kv_dtype, kv_scale=kv_scale,
                             num_pages=num_pages)
     alibi = None
@@ -141,11 +141,13 @@ def unified_case(ua, name, *, seed, query_lens, kv_lens, hq, hk, d, page, dtype,
     ks = vs = None
     if kv_dtype is not None and kv_dtype != dtype:
         ks = torch.tensor([kv_scale], dtype=torch.float32)
-        vs = torch.tensor([kv_scale], dtype=torch.float32)
+        vs = torch.tensor([kv_scale if v_scale is None else v_scale], dtype=torch.float32)   # (the cache bytes are the same either way)
     out = run_unified(ua, inp, window=window, softcap=softcap, alibi=alibi, k_scale=ks, v_scale=vs, force=force, tile=tile)
     path = "3d" if (max(query_lens) == 1 and force != 2) else "2d"
     meta = dict(kind="unified", scale=inp["scale"], window=window, softcap=softcap, kv_scale=kv_scale, path=path,
                 tile=tile, query_lens=list(query_lens), kv_lens=list(kv_lens))
+    if v_scale is not None:
+        meta["v_scale"] = v_scale
     t = dict(q=inp["q"], k_cache=inp["k_cache"], v_cache=inp["v_cache"], cu_seqlens_q=inp["cu_seqlens_q"],
              seqused_k=inp["seqused_k"], block_table=inp["block_table"], out=out)
     if alibi is not None:
@@ -237,6 +239,14 @@ def cache_cases():
 
 
 def main():
+    only = sys.argv[1:]            # optional name prefixes: regenerate just those fixtures
+    if only:
+        global save
+        _save = save
+
+        def save(name, meta, **tensors):      # noqa: F811
+            if any(name.startswith(o) for o in only):
+                _save(name, meta, **tensors)
     install_stubs()
     ua = load_by_path("ref_unified_attention", f"{LIBK}/triton_unified_attention.py")
     bf, hf, f32 = torch.bfloat16, torch.float16, torch.float32
@@ -278,6 +288,27 @@ def main():
     # MHA (G = 1) and MQA-ish (G = 8, Hk = 1)
     unified_case(ua, "mha_mixed_fp16", seed=13, dtype=hf, query_lens=[3, 1, 33], kv_lens=[35, 64, 33], hq=4, hk=4, d=128, page=16)
     unified_case(ua, "mqa8_mixed_fp16", seed=14, dtype=hf, query_lens=[3, 1, 33], kv_lens=[35, 64, 33], hq=8, hk=1, d=128, page=16)
+
+    # --- round 2: the fast (16-bit, matrix-core) kernels against the reference's own numbers -------------------------
+    # features and head sizes in fp16 (the fp32 fixtures above only ever reach the shape-agnostic kernel)
+    unified_case(ua, "sw8_mixed_fp16", seed=7, dtype=hf, window=8, **mixed)
+    unified_case(ua, "sw8_decode_fp16", seed=7, dtype=hf, window=8, hq=8, hk=2, **dec)
+    unified_case(ua, "softcap30_mixed_fp16", seed=8, dtype=hf, softcap=30.0, **mixed)
+    unified_case(ua, "alibi_mixed_fp16", seed=9, dtype=hf, use_alibi=True, **mixed)
+    unified_case(ua, "alibi_decode_fp16", seed=9, dtype=hf, use_alibi=True, hq=8, hk=2, **dec)
+    for d in (64, 80, 96, 120, 256):
+        unified_case(ua, f"headsize_{d}_mixed_fp16", seed=10 + d, dtype=hf, query_lens=[5, 1, 19], kv_lens=[37, 50, 19],
+                     hq=4, hk=2, d=d, page=16)
+    # the reference's own KAT matrix has head size 120 and (40, 40) heads (scripts/test.py:58-63)
+    unified_case(ua, "headsize_120_mixed_fp32", seed=130, dtype=f32, query_lens=[5, 1, 19], kv_lens=[37, 50, 19], hq=4, hk=2, d=120, page=16)
+    unified_case(ua, "headsize_120_decode_fp16", seed=131, dtype=hf, query_lens=[1, 1, 1], kv_lens=[37, 150, 19], hq=4, hk=2, d=120, page=16)
+    unified_case(ua, "heads_40_40_mixed_fp16", seed=15, dtype=hf, query_lens=[3, 1, 9], kv_lens=[19, 24, 9], hq=40, hk=40, d=64, page=16, num_pages=6)
+    unified_case(ua, "heads_40_40_decode_fp16", seed=16, dtype=hf, query_lens=[1, 1], kv_lens=[40, 33], hq=40, hk=40, d=64, page=16, num_pages=7)
+    # fp8 KV with scales that are no powers of two and differ between K and V (the kernels fold k_scale into the softmax
+    # scale and v_scale into the normalisation; the reference rounds (fp8 -> f32) * scale to the Q type first, :434-455)
+    unified_case(ua, "decode_fp8e4m3_kv_fp16q_scales", seed=17, dtype=hf, kv_dtype=e4, kv_scale=0.0237, v_scale=0.041, hq=8, hk=2, **dec)
+    unified_case(ua, "mixed_fp8e4m3_kv_fp16q_scales", seed=18, dtype=hf, kv_dtype=e4, kv_scale=0.0237, v_scale=0.041, **mixed)
+    unified_case(ua, "mixed_fp8e5m2_kv_fp16q_scales", seed=19, dtype=hf, kv_dtype=e5, kv_scale=0.0237, v_scale=0.041, **mixed)
 
     legacy_cases()
     cache_cases()

@@ -178,6 +178,74 @@ def test_decode_c3_full_size_properties():
     torch.testing.assert_close(out3.float(), torch.full_like(out3, 0.5).float(), atol=4e-3, rtol=0)
 
 
+def test_decode_c5_full_size_properties():
+    """BASELINE C5 (Llama-3-70B shape: Hq=64, Hk=8, D=128, B=16, kv=32768 = 2048 pages per sequence, fp8-e4m3 KV with
+    scalar scales that are no powers of two, bf16 Q): sampled (sequence, head) rows against the oracle, page-permutation
+    invariance bit for bit, constant V => constant output, and ragged lengths under the same (captured) split plan."""
+    import gpu_util
+
+    dev = gpu_util.DEV
+    B, Hq, Hk, D, kv, page = 16, 64, 8, 128, 32768, 16
+    ks, vs = 0.0237, 0.041
+    g = torch.Generator(device="cpu").manual_seed(5)
+    pps = kv // page
+    nb = B * pps + 5
+    k = ((torch.rand(nb, page, Hk, D, generator=g) * 2 - 1) / ks).to(torch.float8_e4m3fn)
+    v = ((torch.rand(nb, page, Hk, D, generator=g) * 2 - 1) / vs).to(torch.float8_e4m3fn)
+    q = (torch.rand(B, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    bt = torch.randperm(nb, generator=g)[: B * pps].to(torch.int32).view(B, pps)
+    t = dict(q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=torch.arange(B + 1, dtype=torch.int32),
+             seqused_k=torch.full((B,), kv, dtype=torch.int32))
+    scale = 1.0 / math.sqrt(D)
+    d = gpu_util.to_dev(t)
+    out, kernel = gpu_util.run_unified(d, scale, kv_scale=ks, v_scale=vs)
+    assert kernel == "decode_splitkv_fp8", kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(torch.bfloat16, torch.float8_e4m3fn)
+    for i in (0, 9, 15):
+        ref = orc.unified_attention_oracle(q[i:i + 1], k, v, torch.tensor([0, 1], dtype=torch.int32), torch.tensor([kv], dtype=torch.int32), bt[i:i + 1],
+                                           scale, k_scale=ks, v_scale=vs, mode="3d")
+        torch.testing.assert_close(out[i:i + 1].float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    perm = torch.randperm(nb, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nb)
+    d2 = dict(d)
+    d2["k_cache"] = d["k_cache"].view(torch.uint8)[perm.to(dev)].view(torch.float8_e4m3fn)
+    d2["v_cache"] = d["v_cache"].view(torch.uint8)[perm.to(dev)].view(torch.float8_e4m3fn)
+    d2["block_table"] = inv.to(dev)[d["block_table"].long()].to(torch.int32)
+    out2, _ = gpu_util.run_unified(d2, scale, kv_scale=ks, v_scale=vs)
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    d3 = dict(d)
+    d3["v_cache"] = torch.full((nb, page, Hk, D), 0.5 / vs, device=dev).to(torch.float8_e4m3fn)
+    out3, _ = gpu_util.run_unified(d3, scale, kv_scale=ks, v_scale=vs)
+    const = float(torch.tensor(0.5 / vs).to(torch.float8_e4m3fn).float()) * vs
+    torch.testing.assert_close(out3.float(), torch.full_like(out3, const).float(), atol=6e-3, rtol=0)
+    # ragged lengths, same max_seqlen_k (what a graph captured at this size replays): rows vs the oracle
+    lens = [32768, 1, 17, 5000, 32767, 16384, 100, 31999, 2, 8192, 4096, 33, 32768, 777, 12345, 20000]
+    d4 = dict(d)
+    d4["seqused_k"] = torch.tensor(lens, dtype=torch.int32, device=dev)
+    out4, _ = _run_with_max_k(d4, scale, kv, ks, vs)
+    for i in (1, 2, 3, 4, 13):
+        ref = orc.unified_attention_oracle(q[i:i + 1], k, v, torch.tensor([0, 1], dtype=torch.int32), torch.tensor([lens[i]], dtype=torch.int32),
+                                           bt[i:i + 1], scale, k_scale=ks, v_scale=vs, mode="3d")
+        torch.testing.assert_close(out4[i:i + 1].float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+def _run_with_max_k(t, scale, max_k, ks, vs):
+    from mi355_attn import _lib
+    from mi355_attn.kernels import unified_attention
+
+    q = t["q"]
+    out = torch.full_like(q, float("nan"))
+    kt = torch.tensor([ks], dtype=torch.float32, device=q.device)
+    vt = torch.tensor([vs], dtype=torch.float32, device=q.device)
+    unified_attention(q=q, k=t["k_cache"], v=t["v_cache"], out=out, cu_seqlens_q=t["cu_seqlens_q"], max_seqlen_q=1, seqused_k=t["seqused_k"],
+                      max_seqlen_k=max_k, avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=scale, causal=True, window_size=(-1, -1),
+                      block_table=t["block_table"], softcap=0, q_descale=None, k_descale=kt, v_descale=vt)
+    torch.cuda.synchronize()
+    return out, _lib.last_kernel()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("hq,hk,d", [(32, 8, 128), (64, 8, 128), (8, 2, 64), (4, 1, 256)])

@@ -20,7 +20,7 @@ def test_unified_attention_vs_reference_golden(name, force):
     d = gpu_util.to_dev(t)
     fp8 = t["k_cache"].dtype in (torch.float8_e4m3fn, torch.float8_e5m2)
     out, kernel = gpu_util.run_unified(d, meta["scale"], window=meta["window"], softcap=meta["softcap"],
-                                       kv_scale=meta["kv_scale"] if fp8 else None, force=force)
+                                       kv_scale=meta["kv_scale"] if fp8 else None, v_scale=meta.get("v_scale") if fp8 else None, force=force)
     atol, rtol = golden_io.tolerance(t["q"].dtype, t["k_cache"].dtype)
     assert not torch.isnan(out).any(), f"{kernel}: NaN in output (unwritten rows?)"
     torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol, msg=lambda m: f"[{kernel}] {m}")

@@ -263,3 +263,68 @@ def test_prefill_key_split_with_rows_outside_the_fixed_reference_range():
     assert kernel == "prefill_mfma_ksplit", kernel
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+def test_mixed_c4_full_size_sampled_rows():
+    """BASELINE C4 at full size: the reference harness's mixed batch (64 sequences: 32 decodes over 4095 context keys,
+    16 partial prefills 2048 + 2048, 16 full prefills of 4096; 98 336 query tokens, Granite-3.1-8B shape Hq 32 / Hk 8 /
+    D 128, bf16). Too big for the oracle as a whole: sampled query tokens of every kind against the oracle (a token at
+    position p of its sequence == a decode over p + 1 keys), every output finite, and the same batch dealt to 8 ranks by
+    parallel.shard_batch gives the same rows on the rank that owns them (to rounding: the split plans of a call depend
+    on how many sequences it holds, so the order of the partial sums differs between the share and the whole batch)."""
+    import os
+    import sys
+
+    import gpu_util
+    from mi355_attn import parallel
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import microbench
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page = 32, 8, 128, 16
+    qlens, ctx = microbench.make_prefix_batch(64, 4096, [1.0], 0.5, 0.5, "ALTERNATING", 16)
+    kvlens = [a + b for a, b in zip(qlens, ctx)]
+    assert sum(qlens) == 98336
+    S, T = len(qlens), sum(qlens)
+    g = torch.Generator().manual_seed(7)
+    pps = [(n + page - 1) // page for n in kvlens]
+    nb = sum(pps) + 8
+    k = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    v = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    q = (torch.rand(T, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    perm = torch.randperm(nb, generator=g).to(torch.int32)
+    bt = torch.zeros(S, max(pps), dtype=torch.int32)
+    o = 0
+    for i, n in enumerate(pps):
+        bt[i, :n] = perm[o:o + n]
+        o += n
+    cu = torch.zeros(S + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(torch.tensor(qlens, dtype=torch.int32), 0)
+    sl = torch.tensor(kvlens, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(D)
+    d = dict(q=q.to(dev), k_cache=k.to(dev), v_cache=v.to(dev), block_table=bt.to(dev), cu_seqlens_q=cu.to(dev), seqused_k=sl.to(dev))
+    out, kernel = gpu_util.run_unified(d, scale)
+    assert kernel == "prefill_mfma+decode_splitkv", kernel
+    assert torch.isfinite(out.float()).all()
+    cul = cu.tolist()
+
+    def check_token(s_idx, tok, got):
+        pos = kvlens[s_idx] - qlens[s_idx] + tok               # absolute position: sees keys 0 .. pos
+        t = cul[s_idx] + tok
+        ref = orc.unified_attention_oracle(q[t:t + 1], k, v, torch.tensor([0, 1], dtype=torch.int32), torch.tensor([pos + 1], dtype=torch.int32),
+                                           bt[s_idx:s_idx + 1], scale, mode="2d", block_n=64)
+        torch.testing.assert_close(got.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+    kinds = {"dec": [i for i in range(S) if qlens[i] == 1], "part": [i for i in range(S) if qlens[i] == 2048], "full": [i for i in range(S) if qlens[i] == 4096]}
+    samples = [(kinds["dec"][0], 0), (kinds["dec"][-1], 0), (kinds["part"][0], 0), (kinds["part"][3], 1000), (kinds["part"][-1], 2047),
+               (kinds["full"][0], 0), (kinds["full"][5], 63), (kinds["full"][9], 2048), (kinds["full"][-1], 4095)]
+    for s_idx, tok in samples:
+        t = cul[s_idx] + tok
+        check_token(s_idx, tok, out[t:t + 1])
+    # the batch-sharded split: rank 3's share, computed on its own compacted pages, equals the rows of the whole-batch run
+    loc = parallel.shard_batch(3, 8, d["q"], d["k_cache"], d["v_cache"], cu, sl, bt)
+    dl = dict(q=loc.q.contiguous(), k_cache=loc.k_cache.contiguous(), v_cache=loc.v_cache.contiguous(), block_table=loc.block_table,
+              cu_seqlens_q=loc.cu_seqlens_q, seqused_k=loc.seqused_k)
+    out_l, _ = gpu_util.run_unified(dl, scale)
+    torch.testing.assert_close(out_l.float(), out[loc.token_index.to(dev)].float(), atol=2e-3, rtol=1.6e-2)

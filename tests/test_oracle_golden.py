@@ -14,7 +14,7 @@ def _run_oracle(meta, t, fn=orc.unified_attention_oracle, **kw):
     return fn(
         t["q"], t["k_cache"], t["v_cache"], t["cu_seqlens_q"], t["seqused_k"], t["block_table"], meta["scale"],
         sliding_window=meta["window"], softcap=meta["softcap"], alibi_slopes=t.get("alibi_slopes"),
-        k_scale=meta["kv_scale"], v_scale=meta["kv_scale"], **kw,
+        k_scale=meta["kv_scale"], v_scale=meta.get("v_scale", meta["kv_scale"]), **kw,
     )
 
 
