@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 200 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 300 /* major*10000 + minor*100 + patch */
 
 #if defined(__GNUC__)
 #define MI355_API __attribute__((visibility("default")))
@@ -145,6 +145,17 @@ typedef struct mi355_attn_params {
    * A row that sees no key gets -inf (and out 0). NULL = not wanted. */
   float* lse;                  /* [num_tokens, Hq] or NULL                                        */
   int64_t lse_stride_token;    /* elements between tokens; heads are contiguous                   */
+
+  /* fused paged-cache write of a decode step (library version >= 0.3.0): replaces the separate
+   * reshape_and_cache_flash launch in front of the attention (triton_attn.py:393-405) for calls in which every sequence
+   * has ONE query token. With write_new_kv != 0, k_new / v_new [num_tokens, Hk, D] hold, for sequence i, the key / value
+   * of its LAST position seqused_k[i] - 1 (the token being decoded): the kernel stores the row into the cache page of
+   * that position - saturating fp8(x / scale) for an fp8 cache, exactly what mi355_reshape_and_cache_flash stores - and
+   * attends over it, whatever the cache held there before. Requires max_seqlen_q == 1, num_tokens == num_seqs, the flash
+   * layout and the matrix-core decode kernel (mi355_decode_write_fusable() answers for a parameter block); the caches
+   * are written although the struct declares them const. */
+  int32_t write_new_kv;
+  int32_t reserved2;
 } mi355_attn_params;
 
 /*
@@ -247,6 +258,10 @@ MI355_API int mi355_context_attention_fwd_v0(const mi355_attn_params* p, void* w
                                              mi355_stream_t stream);
 MI355_API int mi355_paged_attention_v0(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
                                        mi355_stream_t stream);
+
+/* 1 if mi355_unified_attention serves these parameters with write_new_kv = 1 (host arithmetic only), else 0: the caller
+ * then issues mi355_reshape_and_cache_flash followed by the plain call. */
+MI355_API int mi355_decode_write_fusable(const mi355_attn_params* p);
 
 /* Paged-cache write, see mi355_cache_params. */
 MI355_API int mi355_reshape_and_cache_flash(const mi355_cache_params* p, mi355_stream_t stream);

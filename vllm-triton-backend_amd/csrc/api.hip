@@ -50,6 +50,14 @@ static int validate(const mi355_attn_params* p) {
   if (p->sliding_window < 0) { set_error("sliding_window must be >= 0"); return MI355_ERR_BAD_ARG; }
   if (p->lse && p->lse_stride_token < p->num_q_heads) { set_error("lse_stride_token %lld is smaller than num_q_heads %d", (long long)p->lse_stride_token, p->num_q_heads); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
+  if (p->write_new_kv) {
+    if (!p->k_new || !p->v_new) { set_error("write_new_kv needs k_new / v_new"); return MI355_ERR_BAD_ARG; }
+    if (p->max_seqlen_q != 1 || p->num_tokens != p->num_seqs || p->skip_decodes || p->only_decodes) {
+      set_error("write_new_kv is for decode steps: one query token per sequence (max_seqlen_q %d, num_tokens %d, num_seqs %d)", p->max_seqlen_q, p->num_tokens, p->num_seqs);
+      return MI355_ERR_BAD_ARG;
+    }
+    if (!decode_write_fusable(*p)) { set_error("write_new_kv: this configuration is not served by the fused decode kernel (mi355_decode_write_fusable)"); return MI355_ERR_UNSUPPORTED; }
+  }
   return MI355_OK;
 }
 
@@ -60,6 +68,7 @@ enum class Path { Generic, Decode, Prefill, PrefillPlusDecode, Repacked };
 
 static Path choose(const mi355_attn_params& p) {
   const int sel = p.kernel_select;
+  if (p.write_new_kv) return Path::Decode;     // validated: the fused decode kernel takes it
   if (sel == MI355_SELECT_GENERIC) return Path::Generic;
   // legacy ops: cache in the v0 layout and/or new keys in linear tensors - gathered into a flash-layout scratch
   // cache first, then the kernels below run on that (repack.hip)
@@ -197,6 +206,11 @@ int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t 
   }
   if (rc == MI355_OK) set_kernel_name(name);
   return rc;
+}
+
+int mi355_decode_write_fusable(const mi355_attn_params* p) {
+  if (!p || p->num_tokens <= 0 || p->num_seqs <= 0) return 0;
+  return decode_write_fusable(*p) ? 1 : 0;
 }
 
 int mi355_context_attention_fwd_v0(const mi355_attn_params* p, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {

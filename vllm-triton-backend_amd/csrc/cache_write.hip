@@ -50,14 +50,16 @@ __global__ __launch_bounds__(256) void cache_write_elem_kernel(const CacheArgs a
   const int64_t page = slot / p.page_size;
   const int64_t off = slot % p.page_size;
   constexpr bool kQuant = sizeof(typename CT::storage) == 1;
-  const float k_inv = (kQuant && p.k_scale) ? 1.0f / p.k_scale[0] : 1.0f;
-  const float v_inv = (kQuant && p.v_scale) ? 1.0f / p.v_scale[0] : 1.0f;
+  // x / scale, a true division like the reference's store (scripts/vllm_utils.py:377-401): x * (1 / scale) rounds
+  // differently for scales that are no powers of two
+  const float k_div = (kQuant && p.k_scale) ? p.k_scale[0] : 1.0f;
+  const float v_div = (kQuant && p.v_scale) ? p.v_scale[0] : 1.0f;
   const int n = p.num_kv_heads * p.head_size;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int h = i / p.head_size, d = i % p.head_size;
     float kx = elem<ST>::load(p.key, (int64_t)t * p.key_stride_token + (int64_t)h * p.key_stride_head + d);
     float vx = elem<ST>::load(p.value, (int64_t)t * p.value_stride_token + (int64_t)h * p.value_stride_head + d);
-    if (kQuant) { kx *= k_inv; vx *= v_inv; }
+    if (kQuant) { kx /= k_div; vx /= v_div; }
     elem<CT>::store(p.k_cache, page * p.k_stride_page + off * p.k_stride_slot + (int64_t)h * p.k_stride_head + d, kx);
     elem<CT>::store(p.v_cache, page * p.v_stride_page + off * p.v_stride_slot + (int64_t)h * p.v_stride_head + d, vx);
   }

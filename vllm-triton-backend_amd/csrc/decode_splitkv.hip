@@ -96,6 +96,31 @@ __device__ __forceinline__ void widen_fp8x16(u32x4_t in, u32x4_t& lo, u32x4_t& h
   hi = u32x4_t{o[4], o[5], o[6], o[7]};
 }
 
+// 16 values of the query's 16-bit type (two 16-byte pieces) -> 16 fp8 values: the quantising store of
+// reshape_and_cache_flash, sat_fp8(x / scale) with the same software encoder (cache_write.hip), bit for bit
+template <typename T, typename KVT>
+__device__ __forceinline__ u32x4_t quantise_fp8x16(u32x4_t lo, u32x4_t hi, float scale) {
+  u32x4_t out;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = 4 * w + e;                       // element 0 .. 15
+      const uint32_t src = idx < 8 ? lo[idx >> 1] : hi[(idx - 8) >> 1];
+      const uint16_t bits = (uint16_t)((idx & 1) ? (src >> 16) : (src & 0xffff));
+      float x;
+      if constexpr (__is_same(T, bf16_t)) x = bf16_to_f32(bits); else x = f16_to_f32(bits);
+      x /= scale;
+      uint8_t q;
+      if constexpr (__is_same(KVT, e4m3_t)) q = f32_to_e4m3_sat(x); else q = f32_to_e5m2_sat(x);
+      word |= (uint32_t)q << (8 * e);
+    }
+    out[w] = word;
+  }
+  return out;
+}
+
 // max / sum over the four lanes {g, g+16, g+32, g+48}
 __device__ __forceinline__ float max_over_lane_groups(float v) {
   v = fmaxf(v, lane_xor32(v));
@@ -364,6 +389,39 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
       for (int i = 0; i < NLD; ++i) kcur[h][i] = KR[h][i];
     const bool tail = (tile * kTileKeys + kTileKeys > n_keys);
+    if constexpr (!V0 && !FEAT) {
+      // Fused cache write (write_new_kv): the wave whose split ends at the sequence's last tile owns the key of the
+      // token being decoded. Its row of K and V comes from k_new / v_new instead of from the cache - quantised the way
+      // reshape_and_cache_flash would have stored it - is written to its page, and takes part in this tile like any
+      // cached row. pg[] still holds this tile's pages: a wave's last lookup is for its last tile.
+      if (p.write_new_kv && tile == tile_hi - 1 && t1 == tile_hi) {
+        const int r_last = n_keys - 1 - tile * kTileKeys;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < NLD; ++i)
+            if (h * 16 + ld_row[i] == r_last && !(PAD && ld_pad[i])) {
+              const uint16_t* kn = (const uint16_t*)p.k_new + (int64_t)token * p.new_stride_token + (int64_t)head * p.new_stride_head + ld_piece[i] * EPP;
+              const uint16_t* vn = (const uint16_t*)p.v_new + (int64_t)token * p.new_stride_token + (int64_t)head * p.new_stride_head + ld_piece[i] * EPP;
+              u32x4_t kq, vq;
+              if constexpr (FP8) {
+                kq = quantise_fp8x16<T, KVT>(*(const u32x4_t*)kn, *(const u32x4_t*)(kn + 8), k_scale);
+                vq = quantise_fp8x16<T, KVT>(*(const u32x4_t*)vn, *(const u32x4_t*)(vn + 8), v_scale);
+              } else {
+                kq = *(const u32x4_t*)kn;
+                vq = *(const u32x4_t*)vn;
+              }
+              const int slot0 = ((tile * 2 + h) << 4) & page_mask;
+              kv_elem_t* kp = (kv_elem_t*)kbase + ((uint64_t)(uint32_t)pg[h] * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride);
+              kv_elem_t* vp = (kv_elem_t*)vbase + ((uint64_t)(uint32_t)pg[h] * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
+              *(u32x4_t*)(kp + k_toff[i]) = kq;
+              *(u32x4_t*)(vp + v_toff[i]) = vq;
+              KR[h][i] = kq;
+              VR[h][i] = vq;
+              kcur[h][i] = kq;
+            }
+      }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -689,9 +747,12 @@ bool decode_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
   if (p.kv_dtype != p.q_dtype && !is_fp8_dtype(p.kv_dtype)) return false;
   if (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) == 0) return false;
-  if (p.k_new || p.v_new) return false;
+  if ((p.k_new || p.v_new) && !p.write_new_kv) return false;
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   const bool v0 = !layout_is_flash(p) && layout_is_v0(p);
+  if (p.write_new_kv && (v0 || p.max_seqlen_q != 1 || p.num_tokens != p.num_seqs || !p.k_new || !p.v_new || p.new_stride_token % 8 != 0 ||
+                         p.new_stride_head % 8 != 0 || ((uintptr_t)p.k_new & 15) != 0 || ((uintptr_t)p.v_new & 15) != 0))
+    return false;
   if (!layout_is_flash(p) && !v0) return false;
   const int G = p.num_q_heads / p.num_kv_heads;
   if (G > 16) return false;
@@ -706,6 +767,13 @@ bool decode_supported(const mi355_attn_params& p) {
   if (p.k_stride_slot >= (1 << 24) || p.v_stride_slot >= (1 << 24)) return false;      // 32-bit in-page offsets
   if (p.k_stride_page >= (1LL << 31) || p.v_stride_page >= (1LL << 31)) return false;
   return true;
+}
+
+bool decode_write_fusable(const mi355_attn_params& p) {
+  mi355_attn_params q = p;
+  q.write_new_kv = 1;
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;   // (the feature kernels take the general row lookup)
+  return !feat && p.kernel_select != MI355_SELECT_GENERIC && p.kernel_select != MI355_SELECT_2D && decode_supported(q);
 }
 
 struct SplitPlan { int num_splits, tiles_per_split; };

@@ -36,6 +36,7 @@ EXPORTS = (
     "mi355_unified_attention",
     "mi355_context_attention_fwd_v0",
     "mi355_paged_attention_v0",
+    "mi355_decode_write_fusable",
     "mi355_reshape_and_cache_flash",
 )
 
@@ -94,6 +95,8 @@ class AttnParams(C.Structure):
         ("reserved1", C.c_int32),
         ("lse", C.c_void_p),
         ("lse_stride_token", C.c_int64),
+        ("write_new_kv", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -156,6 +159,8 @@ def load() -> C.CDLL:
     for legacy in (lib.mi355_context_attention_fwd_v0, lib.mi355_paged_attention_v0):
         legacy.restype = C.c_int
         legacy.argtypes = [C.POINTER(AttnParams), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mi355_decode_write_fusable.restype = C.c_int
+    lib.mi355_decode_write_fusable.argtypes = [C.POINTER(AttnParams)]
     lib.mi355_reshape_and_cache_flash.restype = C.c_int
     lib.mi355_reshape_and_cache_flash.argtypes = [C.POINTER(CacheParams), C.c_void_p]
     _lib = lib

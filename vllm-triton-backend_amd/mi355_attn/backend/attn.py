@@ -25,7 +25,10 @@ from ._vllm_shim import (
     make_local_attention_virtual_batches,
 )
 
+import os  # noqa: E402
+
 logger = init_logger(__name__)
+_FUSED_DECODE_WRITE = os.environ.get("MI355_FUSED_DECODE_WRITE", "1") != "0"   # A/B switch: 0 = always two launches
 _lib.load()  # fail at import, not at the first forward, if the HIP library is missing
 
 
@@ -276,6 +279,26 @@ class MI355AttentionImpl(AttentionImpl):
 
         num_actual_tokens = attn_metadata.num_actual_tokens
         key_cache, value_cache = kv_cache.unbind(0)
+
+        # A decode step (every sequence one query token, no window / soft-cap / ALiBi / local attention): ONE launch - the
+        # wave that owns a sequence's last tile stores the new token's K/V row into its page and attends over it
+        # (the op falls back to the two calls below when the fused kernel does not serve the shape).
+        # vLLM's slot_mapping of such a step points at position seq_len - 1 of each sequence, which is where the kernel writes.
+        plain = self.alibi_slopes is None and self.sliding_window == (-1, -1) and not self.logits_soft_cap
+        if (attn_metadata.max_query_len == 1 and plain and self.kv_sharing_target_layer_name is None
+                and not (self.use_irope and attn_metadata.local_attn_metadata is not None) and _FUSED_DECODE_WRITE):
+            q = query[:num_actual_tokens]
+            out = output[:num_actual_tokens]
+            if out.dim() == 2:
+                out = out.view(-1, self.num_heads, self.head_size)
+            if q.dim() == 2:
+                q = q.view(-1, self.num_heads, self.head_size)
+            if self.kv_cache_dtype.startswith("fp8"):
+                assert layer._q_scale == 1.0, "A non 1.0 q_scale is not currently supported."
+            torch.ops.mi355_attn.decode_attention_and_cache_write(
+                q, key, value, key_cache, value_cache, out, attn_metadata.query_start_loc, attn_metadata.seq_lens, int(attn_metadata.max_seq_len),
+                float(self.scale), attn_metadata.block_table, attn_metadata.slot_mapping, layer._k_scale, layer._v_scale, self.kv_cache_dtype)
+            return output
 
         if self.kv_sharing_target_layer_name is None:
             torch.ops.mi355_attn.reshape_and_cache_flash(key, value, key_cache, value_cache, attn_metadata.slot_mapping, self.kv_cache_dtype,

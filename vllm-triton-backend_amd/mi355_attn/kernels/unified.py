@@ -34,7 +34,7 @@ def fill_attn_params(
     q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_size,
     block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection,
     k_new=None, v_new=None, skip_decodes=False, only_decodes=False, num_segments=0,
-    legacy_v0_layout=False, lse=None,
+    legacy_v0_layout=False, lse=None, write_new_kv=False,
 ):
     """Build the C struct. Returns (params, keepalive) — keepalive holds temporaries whose device
     memory the struct points to."""
@@ -110,6 +110,7 @@ def fill_attn_params(
     except KeyError:
         raise ValueError(f"force_selection must be None, 2, 3 or 9, got {force_selection}") from None
     p.num_segments = int(num_segments)
+    p.write_new_kv = int(bool(write_new_kv))
     if lse is not None:
         if lse.dtype != torch.float32 or lse.dim() != 2 or lse.shape[0] != q.shape[0] or lse.shape[1] != q.shape[1] or lse.stride(1) != 1:
             raise ValueError("softmax_lse must be a float32 [num_tokens, num_heads] tensor with contiguous heads")
@@ -168,3 +169,36 @@ def unified_attention(
     launch(p, q.device)
     del keep
     return None
+
+
+def decode_attention_and_cache_write(q, key, value, k_cache, v_cache, out, seqused_k, max_seqlen_k, softmax_scale, block_table,
+                                     k_descale=None, v_descale=None, cu_seqlens_q=None):
+    """One launch for a decode step (every sequence has ONE query token): the new token's key / value (row i of `key` /
+    `value` belongs to position seqused_k[i] - 1 of sequence i) is stored into its cache page - quantised for an fp8
+    cache exactly as reshape_and_cache_flash stores it - and attended over, by the wave that owns the sequence's last
+    tile. Replaces the pair of calls at LIB/backend/triton_attn.py:393-405 + :437 for such steps.
+    Returns False (and does nothing) when this configuration is not served fused: the caller then issues the two calls."""
+    if not q.is_cuda:
+        raise RuntimeError("mi355_attn.decode_attention_and_cache_write needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
+    n = q.shape[0]
+    if cu_seqlens_q is None:
+        cu_seqlens_q = _arange_cu(n, q.device)
+    p, keep = fill_attn_params(q, k_cache, v_cache, out, cu_seqlens_q, 1, seqused_k, max_seqlen_k, softmax_scale, (-1, -1), block_table, 0.0,
+                               k_descale, v_descale, None, None, k_new=key, v_new=value, write_new_kv=True)
+    if not _lib.load().mi355_decode_write_fusable(C.byref(p)):
+        return False
+    launch(p, q.device)
+    del keep
+    return True
+
+
+_cu_cache: dict = {}
+
+
+def _arange_cu(n: int, device: torch.device) -> torch.Tensor:
+    key = (device.type, device.index, n)
+    t = _cu_cache.get(key)
+    if t is None:
+        t = torch.arange(n + 1, dtype=torch.int32, device=device)
+        _cu_cache[key] = t
+    return t

@@ -1,4 +1,5 @@
-"""Registered torch ops over the C ABI: torch.ops.mi355_attn.{unified_attention, reshape_and_cache_flash}.
+"""Registered torch ops over the C ABI: torch.ops.mi355_attn.{unified_attention, reshape_and_cache_flash,
+decode_attention_and_cache_write}.
 
 The reference's forward() calls a registered op for the cache write (torch.ops._C_cache_ops.reshape_and_cache_flash,
 LIB/backend/triton_attn.py:396-405) and a Python function for the attention; vLLM wraps the whole backend call in its own
@@ -15,6 +16,7 @@ from typing import Optional
 import torch
 
 from .kernels.cache import reshape_and_cache_flash as _reshape_and_cache_flash
+from .kernels.unified import decode_attention_and_cache_write as _decode_attention_and_cache_write
 from .kernels.unified import unified_attention as _unified_attention
 
 _DEF = torch.library.Library("mi355_attn", "DEF")
@@ -26,6 +28,12 @@ _DEF.define(
 _DEF.define(
     "reshape_and_cache_flash(Tensor key, Tensor value, Tensor(a!) key_cache, Tensor(b!) value_cache, Tensor slot_mapping, "
     "str kv_cache_dtype, Tensor? k_scale, Tensor? v_scale) -> ()"
+)
+
+_DEF.define(
+    "decode_attention_and_cache_write(Tensor q, Tensor key, Tensor value, Tensor(a!) key_cache, Tensor(b!) value_cache, Tensor(c!) out, "
+    "Tensor cu_seqlens_q, Tensor seqused_k, int max_seqlen_k, float softmax_scale, Tensor block_table, Tensor slot_mapping, "
+    "Tensor? k_scale, Tensor? v_scale, str kv_cache_dtype) -> ()"
 )
 
 _FP8 = {"fp8": torch.float8_e4m3fn, "fp8_e4m3": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}
@@ -47,6 +55,24 @@ def _reshape_and_cache_flash_impl(key, value, key_cache, value_cache, slot_mappi
     _reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale)
 
 
+def _decode_attention_and_cache_write_impl(q, key, value, key_cache, value_cache, out, cu_seqlens_q, seqused_k, max_seqlen_k, softmax_scale,
+                                          block_table, slot_mapping, k_scale: Optional[torch.Tensor], v_scale: Optional[torch.Tensor],
+                                          kv_cache_dtype: str) -> None:
+    """A decode step (one query token per sequence) in ONE launch when the fused kernel serves the configuration, else
+    the cache write followed by the attention: the same results either way."""
+    kc, vc = key_cache, value_cache
+    if kv_cache_dtype in _FP8 and kc.dtype == torch.uint8:
+        kc, vc = kc.view(_FP8[kv_cache_dtype]), vc.view(_FP8[kv_cache_dtype])
+    n = q.shape[0]
+    if _decode_attention_and_cache_write(q, key[:n], value[:n], kc, vc, out, seqused_k, max_seqlen_k, softmax_scale, block_table,
+                                         k_scale, v_scale, cu_seqlens_q):
+        return
+    _reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale)
+    _unified_attention(q=q, k=kc, v=vc, out=out, cu_seqlens_q=cu_seqlens_q, max_seqlen_q=1, seqused_k=seqused_k, max_seqlen_k=max_seqlen_k,
+                       avg_seqlen_q=0, avg_seqlen_k=0, softmax_scale=softmax_scale, causal=True, window_size=(-1, -1), block_table=block_table,
+                       softcap=0.0, q_descale=None, k_descale=k_scale, v_descale=v_scale)
+
+
 def _nothing(*args, **kwargs) -> None:      # fake / meta: the ops return nothing and only write their (a!)/(b!) arguments
     return None
 
@@ -54,8 +80,11 @@ def _nothing(*args, **kwargs) -> None:      # fake / meta: the ops return nothin
 _IMPL = torch.library.Library("mi355_attn", "IMPL")
 _IMPL.impl("unified_attention", _unified_attention_impl, "CUDA")
 _IMPL.impl("reshape_and_cache_flash", _reshape_and_cache_flash_impl, "CUDA")
+_IMPL.impl("decode_attention_and_cache_write", _decode_attention_and_cache_write_impl, "CUDA")
+_IMPL.impl("decode_attention_and_cache_write", _nothing, "Meta")
 _IMPL.impl("unified_attention", _nothing, "Meta")
 _IMPL.impl("reshape_and_cache_flash", _nothing, "Meta")
 
 unified_attention = torch.ops.mi355_attn.unified_attention
 reshape_and_cache_flash = torch.ops.mi355_attn.reshape_and_cache_flash
+decode_attention_and_cache_write = torch.ops.mi355_attn.decode_attention_and_cache_write
