@@ -93,6 +93,42 @@ def main():
               nbytes = 2 * B * L * args.hk * args.d * 2
               print(f"B={B} kv={L:6d} seg={seg:2d} kernel={_lib.last_kernel():16s} stream {stream_us:7.1f} us/call   graph {graph_us:7.1f} us/call   "
                     f"({nbytes / graph_us / 1e3:7.1f} GB/s)", flush=True)
+            # a layer's decode step in a graph: cache write + attention (two nodes) against the fused launch (one node)
+            from mi355_attn.kernels import reshape_and_cache_flash
+            from mi355_attn.kernels.unified import decode_attention_and_cache_write
+            k_new = (torch.rand(B, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+            v_new = (torch.rand(B, args.hk, args.d, device=dev) * 2 - 1).to(dt)
+            slots = (bt[:, (L - 1) // page].long() * page + (L - 1) % page)
+            p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, 1, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, None, None, None, None)
+
+            def two():
+                reshape_and_cache_flash(k_new, v_new, k, v, slots, "auto", None, None)
+                ua_mod.launch(p, dev)
+
+            def one():
+                assert decode_attention_and_cache_write(q, k_new, v_new, k, v, out, sl, L, 1.0 / math.sqrt(args.d), bt, None, None, cu)
+
+            res = []
+            for fn in (two, one):
+                g = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    fn()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g, stream=s):
+                        for _ in range(50):
+                            fn()
+                for _ in range(3):
+                    g.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                res.append(e0.elapsed_time(e1) * 1e3 / 500)
+            print(f"B={B} kv={L:6d} decode step in a graph: cache write + attention {res[0]:6.1f} us, fused into one launch {res[1]:6.1f} us "
+                  f"(saves {res[0] - res[1]:4.1f} us per layer)", flush=True)
 
 
 if __name__ == "__main__":
