@@ -215,17 +215,33 @@ def cpu_baseline(w, out_gpu):
 KERNEL_SYMBOL = {"prefill_mfma": "prefill_pw_kernel", "decode_splitkv": "decode_splitkv_kernel"}
 
 
+def kernel_source_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/*.h), in name order: ties a counter pass to the code."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "vllm-triton-backend_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def measured_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes of THIS
     command (tools/collect_traffic.py -> profiles/r02/traffic.json, the guide's gfx950 correction). Hardware counters
     cannot be read from inside the timed run, so the number comes from that separate, committed pass and is reported
-    only when it was taken on the kernel symbol this run launched; otherwise null."""
+    only when it was taken on the kernel symbol this run launched AND on the kernel sources this run was built from
+    (the pass records a digest of csrc/, see kernel_source_digest); otherwise null."""
     path = os.path.join(PROFILE_DIR, "traffic.json")
     symbol = KERNEL_SYMBOL.get(kernel_name.split("+")[0])
     if symbol is None or not os.path.exists(path):
         return None
     try:
-        for name, rec in json.load(open(path)).items():
+        doc = json.load(open(path))
+        if doc.get("csrc_sha256") != kernel_source_digest():
+            return None                                          # counters of an older kernel: stale, not reported
+        for name, rec in doc["kernels"].items():
             if name.startswith(symbol):
                 return rec["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):

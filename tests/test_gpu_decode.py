@@ -40,6 +40,31 @@ def test_decode_heads_and_head_sizes(dtype, hq, hk, d):
     _check(inp, dtype, force=None, expect="decode")
 
 
+@pytest.mark.parametrize("hq,hk,d,kv", [(32, 1, 128, None), (40, 2, 64, None), (48, 1, 128, "e4m3"), (72, 2, 128, None), (34, 2, 256, None)])
+def test_decode_more_than_16_query_heads_per_kv_head(hq, hk, d, kv):
+    """A wave's MFMA columns hold 16 query heads; a KV head with more of them takes cdiv(G, 16) waves (the last one
+    partly filled: G = 20, 36, 17), through the in-kernel merge and through the merge launch (segments)."""
+    import gpu_util
+    kv_dtype = torch.float8_e4m3fn if kv else None
+    scale = 0.5 if kv else None
+    kv_lens = [1, 16, 17, 33, 257, 1023, 2500]
+    inp = orc.make_paged_inputs(21, [1] * len(kv_lens), kv_lens, hq, hk, d, 16, torch.bfloat16, **({"kv_dtype": kv_dtype, "kv_scale": scale} if kv else {}))
+    _check(inp, torch.bfloat16, force=None, expect="decode_splitkv", kv_dtype=kv_dtype, kv_scale=scale)
+    from mi355_attn.kernels import unified as ua_mod
+    dev = gpu_util.to_dev(inp)
+    ks = None if scale is None else torch.tensor([scale], dtype=torch.float32, device=gpu_util.DEV)
+    outs = []
+    for n in (1, 5, 64):
+        out = torch.full_like(dev["q"], float("nan"))
+        p, keep = ua_mod.fill_attn_params(dev["q"], dev["k_cache"], dev["v_cache"], out, dev["cu_seqlens_q"], 1, dev["seqused_k"], max(kv_lens),
+                                          inp["scale"], (-1, -1), dev["block_table"], 0.0, ks, ks, None, 3, num_segments=n)
+        ua_mod.launch(p, gpu_util.DEV)
+        torch.cuda.synchronize()
+        outs.append(out.float())
+    torch.testing.assert_close(outs[1], outs[0], atol=2e-3, rtol=1.6e-2)
+    torch.testing.assert_close(outs[2], outs[0], atol=2e-3, rtol=1.6e-2)
+
+
 @pytest.mark.parametrize("d", [32, 80, 96, 160, 192, 224])
 def test_decode_head_sizes_that_run_padded(d):
     """Head sizes between the built ones run on the next built size; the padding columns are never read or written

@@ -31,7 +31,7 @@ def _case(seed, kv_lens, hq, hk, d, page, dtype, kv_dtype=None, k_scale=1.0, v_s
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kv", ["same", "e4m3", "e5m2"])
-@pytest.mark.parametrize("hq,hk,d,page", [(32, 8, 128, 16), (8, 2, 64, 16), (4, 1, 256, 32), (6, 2, 96, 16)])
+@pytest.mark.parametrize("hq,hk,d,page", [(32, 8, 128, 16), (8, 2, 64, 16), (4, 1, 256, 32), (6, 2, 96, 16), (40, 2, 128, 16)])
 def test_fused_decode_write_matches_separate_write_and_oracle(dtype, kv, hq, hk, d, page):
     import gpu_util
     from mi355_attn import _lib

@@ -55,7 +55,7 @@ def test_prefill_head_sizes_that_run_padded(d):
     inp = orc.make_paged_inputs(40 + d, query_lens, kv_lens, 8, 2, d, 16, torch.bfloat16)
     _check(inp, torch.bfloat16)
     _check(inp, torch.bfloat16, force=2, window=64, softcap=30.0, expect="prefill_mfma_feat")
-    if d % 16 == 0 and d <= 128:
+    if d % 16 == 0:
         inp8 = orc.make_paged_inputs(41 + d, query_lens, kv_lens, 8, 2, d, 16, torch.float16, kv_dtype=torch.float8_e4m3fn, kv_scale=0.5)
         _check(inp8, torch.float16, force=2, expect="prefill_mfma_fp8", kv_dtype=torch.float8_e4m3fn, kv_scale=0.5)
 
@@ -80,7 +80,7 @@ def test_prefill_features_window_softcap_alibi():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
-@pytest.mark.parametrize("hq,hk,d", [(8, 2, 128), (32, 8, 128), (8, 2, 64), (4, 4, 64)])
+@pytest.mark.parametrize("hq,hk,d", [(8, 2, 128), (32, 8, 128), (8, 2, 64), (4, 4, 64), (8, 2, 256)])
 def test_prefill_fp8_kv_cache_on_the_mfma_path(dtype, kv_dtype, hq, hk, d):
     """fp8 KV cache under 16-bit queries: widened to the query type on the way into LDS, scalar k/v scales folded into the
     softmax scale / output normalisation (LIB/kernels/triton_unified_attention.py:434-455). Mixed batch: the prefill rows

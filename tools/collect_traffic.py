@@ -38,8 +38,11 @@ def main():
         res[short] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write.get(k, 0.0),
                       "hbm_bytes_per_launch": (2 * fetch[k] + write.get(k, 0.0)) * 1024,
                       "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads"}
-    json.dump(res, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
-    print(json.dumps(res, indent=1))
+    sys.path.insert(0, ROOT)
+    import bench
+    doc = {"csrc_sha256": bench.kernel_source_digest(), "command": "bench.py --no-cpu-baseline --steps 5 --warmup 2", "kernels": res}
+    json.dump(doc, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+    print(json.dumps(doc, indent=1))
 
 
 if __name__ == "__main__":

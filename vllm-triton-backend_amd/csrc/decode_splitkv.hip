@@ -64,6 +64,7 @@ struct DecodeArgs {
   int num_splits;
   int tiles_per_split;
   int group;       // G = Hq / Hk
+  int qgroups;     // cdiv(G, 16): a wave serves 16 of the KV head's query heads; more of them take more waves
   int page_shift;  // log2(page_size)
   int by_seq;      // 1: work items enumerate sequences (only_decodes), 0: query tokens
   int d_valid;     // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
@@ -204,14 +205,17 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   // ---- which (unit, split, kv head) this wave owns (all wave-uniform) ----------------------------
   const int Hk = p.num_kv_heads;
   const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave_in_wg);
-  const int head = item % Hk;
-  const int rest = item / Hk;
+  // (the waves of one KV head's query-head groups are neighbours: they stream the same K/V pages through one L2)
+  const int hitem = item % (Hk * a.qgroups);
+  const int head = hitem / a.qgroups, qg = hitem % a.qgroups;
+  const int rest = item / (Hk * a.qgroups);
   const int split = rest % a.num_splits;
   const int unit = rest / a.num_splits;
-  const int G = a.group;
+  const int hq0 = head * a.group + 16 * qg;   // first query head of this wave
+  const int G = min(16, a.group - 16 * qg);   // query heads of this wave
   const int g = lane & 15, grp = lane >> 4;
   const bool g_ok = g < G;
-  const int hq = head * G + g;
+  const int hq = hq0 + g;
 
   // ---- Q fragments: B operand of S^T = K.Q^T: lane (g, grp) holds Q[g][32c + 8grp .. +7] --------
   s16x8_t qf[KSTEPS];
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       // reshape_and_cache_flash would have stored it - is written to its page, and takes part in this tile like any
       // cached row. pg[] still holds this tile's pages: a wave's last lookup is for its last tile.
       if (p.write_new_kv && tile == tile_hi - 1 && t1 == tile_hi) {
+        const bool store_row = qg == 0;         // the waves of the other query-head groups only take the row
         const int r_last = n_keys - 1 - tile * kTileKeys;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -414,8 +419,10 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
               const int slot0 = ((tile * 2 + h) << 4) & page_mask;
               kv_elem_t* kp = (kv_elem_t*)kbase + ((uint64_t)(uint32_t)pg[h] * a.k_page_stride + (uint32_t)slot0 * a.k_slot_stride);
               kv_elem_t* vp = (kv_elem_t*)vbase + ((uint64_t)(uint32_t)pg[h] * a.v_page_stride + (uint32_t)slot0 * a.v_slot_stride);
-              *(u32x4_t*)(kp + k_toff[i]) = kq;
-              *(u32x4_t*)(vp + v_toff[i]) = vq;
+              if (store_row) {
+                *(u32x4_t*)(kp + k_toff[i]) = kq;
+                *(u32x4_t*)(vp + v_toff[i]) = vq;
+              }
               KR[h][i] = kq;
               VR[h][i] = vq;
               kcur[h][i] = kq;
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   constexpr int SLOT = D + kSlotPad;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ws_slots, 0, (int)a.ws_slot_bytes_total, 0x00020000);
   // slot rows are indexed by work unit: the query token, or the sequence when only decode rows are served
-  const uint32_t slot_g0 = (uint32_t)(((uint32_t)unit * p.num_q_heads + head * G) * a.num_splits);   // slot of (g = 0, split 0)
+  const uint32_t slot_g0 = (uint32_t)(((uint32_t)unit * p.num_q_heads + hq0) * a.num_splits);   // slot of (g = 0, split 0)
   if (g_ok) {
     const uint32_t so = ((slot_g0 + g * a.num_splits + split) * SLOT) * 4u;
 #pragma unroll
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains before it signals
   const int n_tiles = max(0, tile_hi - tile_lo);
   const int active = min(a.num_splits, (n_tiles + tps - 1) / tps);
-  int* cnt = a.ws_cnt + (unit * Hk + head);
+  int* cnt = a.ws_cnt + ((unit * Hk + head) * a.qgroups + qg);
   int ticket = 0;
   if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
@@ -641,9 +648,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   }
   if (gm_ok && sub == 0) {
     if (p.lse && grp == 0)
-      p.lse[(int64_t)token * p.lse_stride_token + head * G + gm] = l_acc > 0.0f ? (m_acc + __builtin_amdgcn_logf(l_acc)) * kLn2 : -INFINITY;
+      p.lse[(int64_t)token * p.lse_stride_token + hq0 + gm] = l_acc > 0.0f ? (m_acc + __builtin_amdgcn_logf(l_acc)) * kLn2 : -INFINITY;
     const float inv = l_acc > 0.0f ? v_scale / l_acc : 0.0f;              // "0 if the overall sum is 0" (:828)
-    const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)(head * G + gm) * p.out_stride_head;
+    const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)(hq0 + gm) * p.out_stride_head;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
       if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
@@ -754,8 +761,6 @@ bool decode_supported(const mi355_attn_params& p) {
                          p.new_stride_head % 8 != 0 || ((uintptr_t)p.k_new & 15) != 0 || ((uintptr_t)p.v_new & 15) != 0))
     return false;
   if (!layout_is_flash(p) && !v0) return false;
-  const int G = p.num_q_heads / p.num_kv_heads;
-  if (G > 16) return false;
   if (!aligned16(p.q) || !aligned16(p.k_cache) || !aligned16(p.v_cache)) return false;
   if (((uintptr_t)p.out & 7) != 0) return false;
   const int64_t kv_align = is_fp8_dtype(p.kv_dtype) ? 16 : 8;   // elements per 16 bytes
@@ -778,6 +783,10 @@ bool decode_write_fusable(const mi355_attn_params& p) {
 
 struct SplitPlan { int num_splits, tiles_per_split; };
 
+// A wave holds 16 query heads of its KV head (the MFMA columns); a KV head with more takes cdiv(G, 16) waves, each
+// streaming the head's K/V (neighbouring waves: the second reader hits in L2).
+static int query_head_groups(const mi355_attn_params& p) { return (p.num_q_heads / p.num_kv_heads + 15) / 16; }
+
 static long decode_units(const mi355_attn_params& p) { return p.only_decodes ? p.num_seqs : p.num_tokens; }
 
 // Capture-stable split policy: depends only on host-known sizes (units, Hk, max_seqlen_k).
@@ -788,7 +797,7 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
   if (p.num_segments > 0) {
     want = p.num_segments;
   } else {
-    const long base = std::max(1L, decode_units(p) * p.num_kv_heads);  // waves with one split each
+    const long base = std::max(1L, decode_units(p) * p.num_kv_heads * query_head_groups(p));  // waves with one split each
     // Work items in flight. With streaming loads a 16-bit cache runs best with 4 per CU: more only add partials and
     // a tail (8192 keys: batch 64 -> 2 splits 322 us, 4 splits 332, 8 splits 344; batch 16 -> 8 splits 90, 16: 95;
     // batch 4 at 32768 keys: 92 vs 94). The fp8 kernel spends its time widening, not waiting: it wants 8 per CU
@@ -815,7 +824,7 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
 constexpr size_t kCounterRegionBytes = 256 << 10;
 static size_t counters_bytes(const mi355_attn_params&) { return kCounterRegionBytes; }
 static bool counters_fit(const mi355_attn_params& p) {
-  return (size_t)decode_units(p) * p.num_kv_heads * sizeof(int) <= kCounterRegionBytes;
+  return (size_t)decode_units(p) * p.num_kv_heads * query_head_groups(p) * sizeof(int) <= kCounterRegionBytes;
 }
 
 size_t decode_workspace_bytes(const mi355_attn_params& p) {
@@ -836,6 +845,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.num_splits = sp.num_splits;
   a.tiles_per_split = sp.tiles_per_split;
   a.group = p.num_q_heads / p.num_kv_heads;
+  a.qgroups = query_head_groups(p);
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
   a.by_seq = p.only_decodes ? 1 : 0;
   a.d_valid = p.head_size;
@@ -866,13 +876,13 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     // in-kernel merge only where the last arriver reads its partials in ONE round trip (NS lanes x U
     // loads in flight, see the kernel's epilogue); more splits than that merge faster in a launch of
     // their own, which is one round trip at any split count
-    const int G = a.group, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));
+    const int G = std::min(a.group, 16), Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));
     const int one_trip = (16 / Gp) * (D >= 128 ? 2 : 4);
     a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip) ? 0 : 1;
   }
   const long units = decode_units(p);
   if (units == 0) return MI355_OK;
-  const long items = units * sp.num_splits * p.num_kv_heads;
+  const long items = units * sp.num_splits * p.num_kv_heads * a.qgroups;
   const int grid = (int)((items + WAVES - 1) / WAVES);
   const size_t lds = (size_t)WAVES * (16 * (D * 2 + 32) + (V0 ? D * 80 : 32 * (D * 2 + 32)));
   hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD, V0>), dim3(grid), dim3(WAVES * 64), lds, stream, a);

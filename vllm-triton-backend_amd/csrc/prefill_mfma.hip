@@ -1088,7 +1088,7 @@ bool prefill_supported(const mi355_attn_params& p) {
   const bool fp8_kv = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
   if (p.kv_dtype != p.q_dtype && !fp8_kv) return false;
   const int dpad = padded_head_size(p.head_size, fp8_kv);
-  if (dpad == 0 || (dpad == 256 && fp8_kv)) return false;
+  if (dpad == 0) return false;
   if (p.k_new || p.v_new) return false;
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
@@ -1345,11 +1345,13 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
     switch (dpad) {
       MI355_PREFILL_CASE(kv_e4m3, 64)
       MI355_PREFILL_CASE(kv_e4m3, 128)
+      MI355_PREFILL_CASE(kv_e4m3, 256)
     }
   } else if (p.kv_dtype == MI355_FP8_E5M2) {
     switch (dpad) {
       MI355_PREFILL_CASE(kv_e5m2, 64)
       MI355_PREFILL_CASE(kv_e5m2, 128)
+      MI355_PREFILL_CASE(kv_e5m2, 256)
     }
   } else {
     switch (dpad) {
