@@ -335,6 +335,17 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
     return ((uint64_t)hi << 32) | lo;
   };
+  // the same for a tile whose group is known to lie inside the share and the sequence (steady iterations below):
+  // no clamps, the in-page offset in 32 bits
+  const int wave16 = wave * 16;
+  auto entry_off_fast = [&](int tile) { return __builtin_amdgcn_readfirstlane(((tile * kPwTile + wave16) >> a.page_shift) << 2); };
+  auto group_base_fast = [&](int tile, int page, auto ISV) {
+    constexpr bool isv = decltype(ISV)::value != 0;
+    const uint32_t in_page = (uint32_t)((tile * kPwTile + wave16) & page_mask) * (isv ? vsb : ksb);
+    const uint64_t b = (uint64_t)(isv ? vbase : kbase) + (uint64_t)(uint32_t)page * (isv ? vpb : kpb) + in_page;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return ((uint64_t)hi << 32) | lo;
+  };
   // the sequence ends inside this group (only ever its last one, and every later fetch repeats it): clamp the rows once
   auto tail_check = [&](int tile, auto ISV) {
     constexpr bool isv = decltype(ISV)::value != 0;
@@ -497,29 +508,61 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   //   seg 3: A exponentials (second half) . K(t+1) fragment reads as K(t)'s registers retire
   //   seg 4: B exponentials
   // IT = (t - tile_lo) % 3 picks the ring slots at compile time.
-  auto iteration = [&](auto ITC, int t) __attribute__((always_inline)) {
+  // STEADY iterations (see the loops below) know at compile time that tile t needs no mask and that the groups this
+  // wave fetches for tiles t+2 .. t+4 lie inside the share and the sequence: no tail handling, no clamps, and the
+  // scalar address arithmetic sits BEHIND the first matrix instructions instead of in front of them (the general
+  // iteration spends ~55 scalar instructions and five branches between the barrier and its first MFMA).
+  auto iteration = [&](auto ITC, auto STC, int t) __attribute__((always_inline)) {
     constexpr int it = decltype(ITC)::value;
+    constexpr bool steady = decltype(STC)::value != 0;
     constexpr int KR = ((it + 1) % 3) * kSlotBytes;            // K(t+1) is read from here
     constexpr int VR = (it % 3) * kSlotBytes;                  // V(t)
     constexpr int KD = kLdsK + (it % 3) * kSlotBytes;          // K(t+3) goes where K(t) was
     constexpr int VD = kLdsV + ((it + 2) % 3) * kSlotBytes;    // V(t+2) goes where V(t-1) was
-    const bool need_mask = (t * kPwTile + kPwTile - 1 > ctx_len + w_tok_lo) || (t * kPwTile + kPwTile > seq_len);
+    bool need_mask = false;
+    uint64_t kb64 = 0, vb64 = 0;
     // scalar side of this iteration's LDS-DMA (entries fetched during the previous iteration), and the fetch of the
     // next iteration's entries (they land before the wait that ends this one)
-    tail_check(t + 3, ic<0>{});
-    tail_check(t + 2, ic<1>{});
-    const uint64_t kb64 = group_base(t + 3, pg_k, ic<0>{}), vb64 = group_base(t + 2, pg_v, ic<1>{});
-    pg_v = pg_k;                                 // V(t+3) lives in the page of K(t+3)
-    pw_sload(pg_k, bt64, entry_off(t + 4));
+    if constexpr (!steady) {
+      need_mask = (t * kPwTile + kPwTile - 1 > ctx_len + w_tok_lo) || (t * kPwTile + kPwTile > seq_len);
+      tail_check(t + 3, ic<0>{});
+      tail_check(t + 2, ic<1>{});
+      kb64 = group_base(t + 3, pg_k, ic<0>{});
+      vb64 = group_base(t + 2, pg_v, ic<1>{});
+      pg_v = pg_k;                                 // V(t+3) lives in the page of K(t+3)
+      pw_sload(pg_k, bt64, entry_off(t + 4));
+    }
+    // piece j of this iteration's LDS-DMA: 0..3 = K(t+3), 4..7 = V(t+2)
+    auto dma_piece = [&](auto JC) __attribute__((always_inline)) {
+      constexpr int j = decltype(JC)::value;
+#ifndef PW_ABL_DMA
+      if constexpr (j < 4) pw_glds16(koff[j], kb64, KD + lds_wave + j * 1024);
+      else pw_glds16(voff[j - 4], vb64, VD + lds_wave + (j - 4) * 1024);
+#endif
+    };
+#ifdef PW_DMA_SPREAD
+#define PW_DMA_AT(seg, g) if constexpr ((g) == 1 || (g) == 9) dma_piece(ic<2 * ((seg) - 1) + ((g) == 9)>{})
+#else
+#define PW_DMA_AT(seg, g) if constexpr ((seg) == 1 && (g) >= 2 && (g) < 10) dma_piece(ic<((seg) == 1 && (g) >= 2 && (g) < 10) ? (g) - 2 : 0>{})
+#endif
     // ---- segment 1 -------------------------------------------------------------------------------------
     sfor<16>([&](auto GC) __attribute__((always_inline)) {
       constexpr int g = decltype(GC)::value;
       qk(ic<0>{}, GC, t, need_mask);
+      if constexpr (steady && g == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        kb64 = group_base_fast(t + 3, pg_k, ic<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (steady && g == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        vb64 = group_base_fast(t + 2, pg_v, ic<1>{});
+        pg_v = pg_k;
+        pw_sload(pg_k, bt64, entry_off_fast(t + 4));
+        __builtin_amdgcn_sched_barrier(0);
+      }
       estream(ic<1>{}, ic<12 + g>{});
-#ifndef PW_ABL_DMA
-      if constexpr (g >= 2 && g < 6) pw_glds16(koff[g - 2], kb64, KD + lds_wave + (g - 2) * 1024);
-      if constexpr (g >= 6 && g < 10) pw_glds16(voff[g - 6], vb64, VD + lds_wave + (g - 6) * 1024);
-#endif
+      PW_DMA_AT(1, g);
     });
     PW_SEG_STAMP(1);
     // ---- segment 2 -------------------------------------------------------------------------------------
@@ -527,6 +570,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       constexpr int g = decltype(GC)::value;
       pv(ic<1>{}, GC);
       if constexpr (g >= 4) { estream(ic<0>{}, ic<g - 4>{}); vread(ic<((g - 4) >> 2)>{}, ic<((g - 4) & 3)>{}, ic<VR>{}); }
+      PW_DMA_AT(2, g);
     });
     PW_SEG_STAMP(2);
     // ---- segment 3 -------------------------------------------------------------------------------------
@@ -536,6 +580,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       estream(ic<0>{}, ic<12 + g>{});
       if constexpr (g < 4) vread(ic<3>{}, GC, ic<VR>{});
       if constexpr (g >= 8) kread(ic<g - 8>{}, ic<KR>{});        // K(t+1)[kb 0][ks]: K(t)[kb 0][ks] was last read in gap ks
+      PW_DMA_AT(3, g);
     });
     PW_SEG_STAMP(3);
     // ---- segment 4 -------------------------------------------------------------------------------------
@@ -548,6 +593,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       pv(ic<0>{}, GC);
       if constexpr (g < 8) kread(ic<8 + g>{}, ic<KR>{});         // K(t+1)[kb 1][ks]
       if constexpr (g >= 4) estream(ic<1>{}, ic<g - 4>{});
+      PW_DMA_AT(4, g);
     });
     PW_SEG_STAMP(4);
     // K(t+1) is in its registers and the next block-table entries in theirs; K(t+2) and V(t+1) (issued one iteration
@@ -572,20 +618,37 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
     st_last = (unsigned)st_c0;
 #endif
-    while (true) {
-      iteration(ic<0>{}, t);
-      if (++t >= tile_hi) break;
-      iteration(ic<1>{}, t);
-      if (++t >= tile_hi) break;
-      iteration(ic<2>{}, t);
-      if (++t >= tile_hi) break;
+    // Tiles below steady_hi are steady for THIS wave (the bound differs between the waves of a workgroup; both loops
+    // have the same barriers, so waves may sit in different ones): unmasked - wholly at or below the wave's first row's
+    // last visible key and inside the sequence - with tile t + 4 inside the share and this wave's group of it inside
+    // what the Q block can see (then the groups of t + 2, t + 3 are whole). Shifts, not divisions: the terms can be negative.
+    const int steady_hi = 1 + min(min(tile_hi - 5, ((last_group - wave) >> 2) - 4), min((ctx_len + w_tok_lo - (kPwTile - 1)) >> 6, (seq_len >> 6) - 1));
+    while (t + 3 <= steady_hi) {                 // three at a time: leaves the ring phase at 0
+      iteration(ic<0>{}, ic<1>{}, t);
+      iteration(ic<1>{}, ic<1>{}, t + 1);
+      iteration(ic<2>{}, ic<1>{}, t + 2);
+      t += 3;
+    }
+    // The workgroup walks tile_hi tiles, but a wave's 64 rows see no key past their last row's limit: the tiles from
+    // own_hi on are wholly masked for it (up to three of a Q block's last four). It computes nothing for them - it only
+    // keeps staging its share of the K/V tiles the other waves still need (the kernel runs at the chip's power limit:
+    // matrix work on masked tiles costs the other waves clock).
+    const int w_tok_hi = min(tok0 + (wave * 64 + 63) / G, q_len - 1);
+    const int own_hi = w_tok_lo >= q_len ? tile_lo : max(tile_lo, min(tile_hi, (min(ctx_len + w_tok_hi, seq_len - 1) >> 6) + 1));
+    while (t < own_hi) {
+      iteration(ic<0>{}, ic<0>{}, t);
+      if (++t >= own_hi) break;
+      iteration(ic<1>{}, ic<0>{}, t);
+      if (++t >= own_hi) break;
+      iteration(ic<2>{}, ic<0>{}, t);
+      ++t;
     }
 #ifdef MI355_PW_STAMP
     {
       unsigned long long st_c1, st_r1;
       asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1) :: "memory");
       unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
-      if (dbg && tid == 0) {
+      if (dbg && tid == 192) {
         unsigned long long* rec = dbg + 12ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
         rec[0] = st_c1 - st_c0; rec[1] = st_r1 - st_r0; rec[2] = (unsigned long long)(tile_hi - tile_lo);
         for (int i = 1; i < 6; ++i) rec[2 + i] = st_sum[i];
@@ -593,10 +656,27 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       }
     }
 #endif
-    // drain: sub-block B of the last tile
-    sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
-    asm volatile("s_nop 1");
-    sfor<16>([&](auto GC) __attribute__((always_inline)) { pv(ic<1>{}, GC); });
+    // drain: sub-block B of the wave's last tile
+    if (own_hi > tile_lo) {
+      sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
+      asm volatile("s_nop 1");
+      sfor<16>([&](auto GC) __attribute__((always_inline)) { pv(ic<1>{}, GC); });
+    }
+    // the tiles this wave only stages for the others: the memory side of an iteration, ring slots at run time
+    for (; t < tile_hi; ++t) {
+      const int ph = (t - tile_lo) % 3;
+      const uint32_t kd = (uint32_t)(kLdsK + ph * kSlotBytes) + lds_wave, vd = (uint32_t)(kLdsV + ((ph + 2) % 3) * kSlotBytes) + lds_wave;
+      tail_check(t + 3, ic<0>{});
+      tail_check(t + 2, ic<1>{});
+      const uint64_t kb64 = group_base(t + 3, pg_k, ic<0>{}), vb64 = group_base(t + 2, pg_v, ic<1>{});
+      pg_v = pg_k;
+      pw_sload(pg_k, bt64, entry_off(t + 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pw_glds16(koff[j], kb64, kd + j * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pw_glds16(voff[j], vb64, vd + j * 1024);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k) :: "memory");
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------
