@@ -69,6 +69,11 @@ def main():
     t0 = rec[:, 8].min()
     print(f"  workgroup life (us): entry->loop median {pro.median():.2f} (p90 {pro.kthvalue(max(1,len(pro)*9//10)).values:.2f}), loop {loop.median():.2f}, loop end->exit median {epi.median():.2f} (p90 {epi.kthvalue(max(1,len(epi)*9//10)).values:.2f})")
     print(f"  first entry -> last exit {(rec[:, 11].max() - t0) * 0.01:.1f} us; last entry at {(rec[:, 8].max() - t0) * 0.01:.1f} us; sum of lives / 256 = {((rec[:, 11] - rec[:, 8]).double().sum() * 0.01 / 256):.1f} us")
+    if os.environ.get("MI355_PW_SEAM"):     # library built with -DMI355_PW_SEAM too: realtime stamps inside the seam instead of the segment sums
+        r2 = rec[rec[:, 6] > 0]
+        d = lambda a_, b_: ((r2[:, b_] - r2[:, a_]).double() * 0.01).median().item()
+        print(f"  seam (us, medians; items followed by another): loop end -> drained {d(10, 3):.2f}, next item set up {d(3, 4):.2f}, loads landed + barrier {d(4, 5):.2f}, "
+              f"next rows and tiles requested {d(5, 6):.2f}, output stored {d(6, 11):.2f}")
     print(f"  time per tile: {(rt[big]/tiles[big]).median()*10:.0f} ns; tile loop = {(rt.sum()*0.01)/ (us*256)*100:.1f} % of CU time (256 CUs x launch time)")
 
 

@@ -30,6 +30,8 @@
 //
 // MFMA orientation, the in-register softmax layout and the LDS swizzles are those of prefill_dma_kernel
 // (prefill_mfma.hip).
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -53,14 +55,21 @@ constexpr int kAO = 0;     // O^T[sb][b]  : kAO + 64 sb + 16 b   (16 registers)
 constexpr int kAQ = 128;   // Q'[sb][ks]  : kAQ + 32 sb + 4 ks   (4 registers)
 constexpr int kAK = 192;   // K[kb][ks]   : kAK + 32 kb + 4 ks   (4 registers)
 // LDS map: K ring (3 x 16 KiB), V ring (3 x 16 KiB)
-constexpr int kSlotBytes = 16384, kLdsK = 0, kLdsV = 3 * kSlotBytes, kPwLds = 6 * kSlotBytes;
+// then the parking area of the epilogue: 32 rows of 272 bytes per wave (a sub-block of O on its way out). It lies
+// outside the rings because the next Q block's first tiles are already landing in them while O leaves.
+constexpr int kSlotBytes = 16384, kLdsK = 0, kLdsV = 3 * kSlotBytes, kLdsO = 6 * kSlotBytes;
+constexpr int kPwORS = 256 + 16;     // padded row stride of the parked O rows
+constexpr int kPwLds = kLdsO + 4 * 32 * kPwORS;
 
 struct PwArgs {
   mi355_attn_params p;
   int group;       // G
   int block_q;     // tokens per Q block = 256 / G
   int page_shift;  // log2(page_size)
-  int key_splits;  // grid.y: workgroup (x, s) attends the s-th even share of its Q block's key tiles (prefill_mfma.hip)
+  int key_splits;  // a work item (Q block, KV head, s) attends the s-th even share of its Q block's key tiles (prefill_mfma.hip)
+  int num_qblocks; // static upper bound of the Q blocks of the batch (num_tokens / block_q + num_seqs)
+  int g_shift, bq_shift;   // log2 of group / block_q when they are powers of two, else -1 (divisions become shifts)
+  int slots;       // workgroups per KV head: the grid is slots * num_kv_heads workgroups, each walking several items
   int64_t out_split_stride, lse_split_stride;
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
 };
@@ -118,6 +127,12 @@ template <typename T> __device__ __forceinline__ uint32_t pw_pack(float lo, floa
 
 template <int IDX> __device__ __forceinline__ void acc_write(uint32_t v) { asm volatile("v_accvgpr_write_b32 a%c0, %1" :: "n"(IDX), "v"(v)); }
 template <int IDX> __device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "n"(IDX)); }
+// running maximum of magnitudes: m = max(m, |a|, |b|) in one instruction (a NaN operand is dropped, like fmaxf)
+#ifdef PW_DBG_AMAX
+__device__ __forceinline__ void pw_amax3(float& m, float a, float b) { m = fmaxf(m, fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
+#else
+__device__ __forceinline__ void pw_amax3(float& m, float a, float b) { asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b)); }
+#endif
 template <int IDX> __device__ __forceinline__ float acc_read() { float r; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "n"(IDX)); return r; }
 
 // LDS -> accumulator registers (K fragments), LDS -> VGPR transposed (V fragments). "memory": LDS accesses the
@@ -142,6 +157,12 @@ __device__ __forceinline__ wu32x4_t pw_gload16(const void* ptr) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
   return r;
 }
+// the same with a scalar base and a 32-bit per-lane byte offset (+ an immediate)
+template <int IMM> __device__ __forceinline__ wu32x4_t pw_gload16_s(uint32_t voff, uint64_t sbase) {
+  wu32x4_t r;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+  return r;
+}
 // one block-table entry through the scalar cache; lands before the iteration-end s_waitcnt lgkmcnt(0) that names it
 __device__ __forceinline__ void pw_sload(int& dst, uint64_t base, int byte_off) {
   asm volatile("s_load_dword %0, %1, %2" : "=s"(dst) : "s"(base), "s"(byte_off) : "memory");
@@ -160,19 +181,19 @@ __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int n
 // textbook online softmax with a true running maximum in f32 (kernel_unified_attention_2d, :467-510, one key at a
 // time). Slow on purpose - it only ever runs for rows whose scores left the range prefill_pw_kernel's fixed
 // reference is good for - and independent of everything the fast path keeps on chip: K/V straight from the cache.
-template <typename T>
-__device__ __forceinline__ void pw_row_fallback(const mi355_attn_params& p, const PwArgs& a, const int32_t* bt, const char* kbase, const char* vbase,
+template <typename T, typename ArgPtr>
+__device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, const char* kbase, const char* vbase,
                                              int token, int hq, int key_lo, int key_hi, uint16_t* out_base, float* lse_base, int lane) {
-  const uint32_t qw = *(const uint32_t*)((const uint16_t*)p.q + (int64_t)token * p.q_stride_token + (int64_t)hq * p.q_stride_head + 2 * lane);
+  const uint32_t qw = *(const uint32_t*)((const uint16_t*)kp->p.q + (int64_t)token * kp->p.q_stride_token + (int64_t)hq * kp->p.q_stride_head + 2 * lane);
   const float q0 = pw_lo<T>(qw), q1 = pw_hi<T>(qw);
-  const float scale2 = p.scale * kPwLog2e;
-  const int page_mask = p.page_size - 1;
+  const float scale2 = kp->p.scale * kPwLog2e;
+  const int page_mask = kp->p.page_size - 1;
   float m = -INFINITY, l = 0.0f, a0 = 0.0f, a1 = 0.0f;
   for (int j = key_lo; j < key_hi; ++j) {
-    const int64_t page = bt[j >> a.page_shift];
+    const int64_t page = bt[j >> kp->page_shift];
     const int64_t slot = j & page_mask;
-    const uint32_t kw = *(const uint32_t*)(kbase + (page * a.k_page_stride + slot * a.k_slot_stride) * 2 + 4 * lane);
-    const uint32_t vw = *(const uint32_t*)(vbase + (page * a.v_page_stride + slot * a.v_slot_stride) * 2 + 4 * lane);
+    const uint32_t kw = *(const uint32_t*)(kbase + (page * kp->k_page_stride + slot * kp->k_slot_stride) * 2 + 4 * lane);
+    const uint32_t vw = *(const uint32_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) * 2 + 4 * lane);
     const float sc = wave_sum(q0 * pw_lo<T>(kw) + q1 * pw_hi<T>(kw)) * scale2;
     const float mn = fmaxf(m, sc);
     const float alpha = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
@@ -183,9 +204,9 @@ __device__ __forceinline__ void pw_row_fallback(const mi355_attn_params& p, cons
     m = mn;
   }
   const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-  *(uint32_t*)(out_base + (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head + 2 * lane) = pw_pack<T>(a0 * inv, a1 * inv);
+  *(uint32_t*)(out_base + (int64_t)token * kp->p.out_stride_token + (int64_t)hq * kp->p.out_stride_head + 2 * lane) = pw_pack<T>(a0 * inv, a1 * inv);
   if (lse_base && lane == 0)
-    lse_base[(int64_t)token * p.lse_stride_token + hq] = l > 0.0f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+    lse_base[(int64_t)token * kp->p.lse_stride_token + hq] = l > 0.0f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
 }
 
 // Diagnostic build only (-DMI355_PW_STAMP, tools/pw_clock.py): shader-cycle sums of the tile loop's segments.
@@ -213,103 +234,195 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.group, BQ = a.block_q;
-
-#ifdef MI355_PW_STAMP
-  unsigned long long st_entry;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry) :: "memory");
-#endif
-  const int head = (int)(blockIdx.x % p.num_kv_heads);     // KV head fastest: one head per XCD at Hk = 8
-  const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);   // heaviest first
-  // Sequence of this Q block and its lengths in ONE memory round trip for batches of up to 63 sequences: lane i takes
-  // cu_seqlens_q[i] and seqused_k[i], the search (largest i with cu[i] / BQ + i <= qblock, find_seq_idx :32-52) is a
-  // ballot. With a single sequence the first block-table entries ride the same trip, speculatively (checked below):
-  // a workgroup's prologue is a chain of dependent round trips nothing else on its CU hides.
-  const bool spec_bt = p.num_seqs == 1 && a.key_splits == 1;
-  int spec_pg[4] = {0, 0, 0, 0}, spec_off[4] = {0, 0, 0, 0};
-  if (spec_bt) {
-    uint64_t b0 = (uint64_t)p.block_table;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b0), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32));
-    b0 = ((uint64_t)hi << 32) | lo;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      spec_off[i] = __builtin_amdgcn_readfirstlane(min(((i * 4 + wave) << 4) >> a.page_shift, (int)p.block_table_stride - 1) << 2);
-      pw_sload(spec_pg[i], b0, spec_off[i]);
-    }
-  }
-  int seq, q_start, q_len, seq_len;
-  if (p.num_seqs <= 63) {
-    const int cu_v = p.cu_seqlens_q[min(lane, p.num_seqs)];
-    const int sk_v = p.seqused_k[min(lane, p.num_seqs - 1)];
-    const unsigned long long le = __ballot(lane < p.num_seqs && cu_v / BQ + lane <= qblock);
-    seq = __builtin_popcountll(le) - 1;
-    if (seq < 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
-    q_start = __builtin_amdgcn_readlane(cu_v, seq);
-    q_len = __builtin_amdgcn_readlane(cu_v, seq + 1) - q_start;
-    seq_len = __builtin_amdgcn_readlane(sk_v, seq);
-  } else {
-    seq = pw_find_seq(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
-    if (seq < 0) return;
-    q_start = p.cu_seqlens_q[seq];
-    q_len = p.cu_seqlens_q[seq + 1] - q_start;
-    seq_len = p.seqused_k[seq];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(spec_pg[0]), "+s"(spec_pg[1]), "+s"(spec_pg[2]), "+s"(spec_pg[3]) :: "memory");
-  const int qb_local = qblock - (q_start / BQ + seq);
-  if (qb_local * BQ >= q_len || (p.skip_decodes && q_len == 1) || (p.only_decodes && q_len != 1)) return;
-  const int ctx_len = seq_len - q_len;
-  const int tok0 = qb_local * BQ;
-
-  // ---- this lane's two query rows (sub-blocks A = 0, B = 1) -----------------------------------------
   const int qr = lane & 31, half = lane >> 5;
-  int tok_local[2], hq[2], lim[2];
-  bool row_ok[2];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    const int m_row = wave * 64 + sb * 32 + qr;
-    tok_local[sb] = tok0 + m_row / G;
-    hq[sb] = head * G + m_row % G;
-    row_ok[sb] = (m_row < BQ * G) && (tok_local[sb] < q_len);
-    lim[sb] = row_ok[sb] ? min(ctx_len + tok_local[sb], seq_len - 1) : -1;   // last visible key
-  }
-  const int w_tok_lo = tok0 + (wave * 64) / G;
-  const int wg_tok_hi = min(tok0 + BQ - 1, q_len - 1);
-  const int n_keys_wg = max(0, min(ctx_len + wg_tok_hi + 1, seq_len));
-  int tile_lo = 0;
-  int tile_hi = (n_keys_wg + kPwTile - 1) / kPwTile;
-  const int ksplit = a.key_splits > 1 ? (int)blockIdx.y : 0;
-  if (a.key_splits > 1) {                      // key-split launch: an even share of this Q block's tiles
-    const int tps = (tile_hi + a.key_splits - 1) / a.key_splits;
-    tile_lo = min(ksplit * tps, tile_hi);
-    tile_hi = min(tile_hi, tile_lo + tps);
-  }
-  uint16_t* const out_base = (uint16_t*)p.out + (int64_t)ksplit * a.out_split_stride;
-  float* const lse_base = p.lse ? p.lse + (int64_t)ksplit * a.lse_split_stride : nullptr;
+  // The per-item code (setup, query loads, epilogue) derives its lane-dependent values from an OPAQUE copy of the lane
+  // index, refreshed per item: otherwise the compiler hoists those values (row -> token / head divisions, addresses)
+  // out of the item loop, where they would have to stay in registers through the tile loop - which has none to spare
+  // (it spills to accumulator registers, and those belong to the asm statements).
+  // For the same reason that code reads the kernel arguments through an opaque pointer to the kernarg segment (scalar
+  // loads, a few hundred cycles, once per item): what it needs of them is then not held in SGPRs through the tile loop.
+  typedef const PwArgs __attribute__((address_space(4))) * KernArgs;
+  struct SeamArgs {                    // read in one batch of scalar loads at the start of an item's set-up
+    const uint16_t* q; uint16_t* out; float* lse;
+    const int32_t *cu, *sk, *bt;
+    int q_st, q_sh, out_st, out_sh;    // elements; the host admits [0, 2^22)
+    int64_t lse_st, bt_stride, out_split_stride, lse_split_stride;
+    int num_seqs, key_splits, num_qblocks, slots, G, BQ, g_shift, bq_shift, page_shift, skip_decodes, only_decodes, num_kv_heads;
+  };
+  int lane_o = lane;
+  KernArgs kp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  SeamArgs sa;
+  auto refresh_lane = [&]() __attribute__((always_inline)) {
+    lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    kp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    sa.q = (const uint16_t*)kp->p.q; sa.out = (uint16_t*)kp->p.out; sa.lse = kp->p.lse;
+    sa.cu = kp->p.cu_seqlens_q; sa.sk = kp->p.seqused_k; sa.bt = kp->p.block_table;
+    sa.q_st = (int)kp->p.q_stride_token; sa.q_sh = (int)kp->p.q_stride_head; sa.out_st = (int)kp->p.out_stride_token; sa.out_sh = (int)kp->p.out_stride_head;
+    sa.lse_st = kp->p.lse_stride_token; sa.bt_stride = kp->p.block_table_stride;
+    sa.out_split_stride = kp->out_split_stride; sa.lse_split_stride = kp->lse_split_stride;
+    sa.num_seqs = kp->p.num_seqs; sa.key_splits = kp->key_splits; sa.num_qblocks = kp->num_qblocks; sa.slots = kp->slots;
+    sa.G = kp->group; sa.BQ = kp->block_q; sa.g_shift = kp->g_shift; sa.bq_shift = kp->bq_shift; sa.page_shift = kp->page_shift;
+    sa.skip_decodes = kp->p.skip_decodes; sa.only_decodes = kp->p.only_decodes; sa.num_kv_heads = kp->p.num_kv_heads;
+  };
+  refresh_lane();
+  // x / G, x % G, x / BQ for x >= 0: shifts when the divisor is a power of two (every GQA ratio in use), else the division
+  auto div_g = [&](int x) { return sa.g_shift >= 0 ? (x >> sa.g_shift) : x / sa.G; };
+  auto mod_g = [&](int x) { return sa.g_shift >= 0 ? (x & (sa.G - 1)) : x % sa.G; };
+  auto div_bq = [&](int x) { return sa.bq_shift >= 0 ? (x >> sa.bq_shift) : x / sa.BQ; };
 
-  // ---- Q rows -> registers (padding rows read the sequence's last query row and are zeroed below) ----
+  // ---- work items ---------------------------------------------------------------------------------------
+  // The grid is `slots` workgroups per KV head (KV head fastest: one head per XCD at Hk = 8, whose L2 then serves
+  // that head's K/V to all its Q blocks), about one per CU, and a workgroup walks several items - (Q block, key
+  // split) pairs of its head, heaviest Q blocks first, dealt boustrophedon (round j hands item j S + s to slot s
+  // for even j, item j S + S-1-s for odd j: with causal weights every slot's total is the same). Walking them in
+  // ONE workgroup is what lets the next item's query rows and first K/V tiles load while this item's output is
+  // normalised and stored - a fresh workgroup pays that chain of round trips (~5 us) with its CU idle.
+  struct Item {
+    int seq, q_start, q_len, seq_len, ctx_len, tok0, ksplit, tile_lo, tile_hi, last_group, w_tok_lo, rank;
+    uint64_t bt64;                     // this sequence's block-table row
+    uint16_t* out_base;
+    float* lse_base;
+    int lim[2];                        // per lane: last visible key of its two query rows (sub-blocks A = 0, B = 1), -1 = padding row
+  };
+  const int head = (int)(blockIdx.x % p.num_kv_heads);
+  const int slot = (int)(blockIdx.x / p.num_kv_heads);
+  const char* const kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
+  const char* const vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
+
+  // Sequence of a Q block and its lengths in ONE memory round trip for batches of up to 63 sequences: lane i takes
+  // cu_seqlens_q[i] and seqused_k[i], the search (largest i with cu[i] / BQ + i <= qblock, find_seq_idx :32-52) is a
+  // ballot. With a single sequence the first block-table entries ride the same trip, speculatively (checked when the
+  // first tiles are requested).
+  int spec_pg[4] = {0, 0, 0, 0}, spec_off[4] = {0, 0, 0, 0};
+  auto setup = [&](Item& I, int& round) -> bool {       // the next non-empty item of this workgroup; false: none left
+    while (true) {
+      const int items_per_head = sa.num_qblocks * sa.key_splits;
+      const int idx = round * sa.slots + ((round & 1) ? sa.slots - 1 - slot : slot);
+      if (idx >= items_per_head) return false;
+      ++round;
+      const int BQ = sa.BQ;
+      const int qb_rank = sa.key_splits == 1 ? idx : idx / sa.key_splits;
+      const int qblock = sa.num_qblocks - 1 - qb_rank;      // heaviest first
+      I.ksplit = idx - qb_rank * sa.key_splits;
+      I.rank = idx * sa.num_kv_heads + head;
+      const bool spec_bt = sa.num_seqs == 1 && sa.key_splits == 1;
+      if (spec_bt) {
+        uint64_t b0 = (uint64_t)sa.bt;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b0), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32));
+        b0 = ((uint64_t)hi << 32) | lo;
+        // (ordinary scalar loads - the block table is not written during the launch: the compiler may park SGPRs in
+        // vector lanes around here, and it would park the destination of an asm load before the entry has landed)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          spec_off[i] = __builtin_amdgcn_readfirstlane(min(((i * 4 + wave) << 4) >> sa.page_shift, (int)sa.bt_stride - 1) << 2);
+          spec_pg[i] = *(const __attribute__((address_space(4))) int*)(b0 + (uint32_t)spec_off[i]);
+        }
+      }
+      int seq, q_start, q_len, seq_len;
+      const int qr_o = lane_o & 31;
+      if (sa.num_seqs <= 63) {
+        const int cu_v = sa.cu[min(lane_o, sa.num_seqs)];
+        const int sk_v = sa.sk[min(lane_o, sa.num_seqs - 1)];
+        const unsigned long long le = __ballot(lane_o < sa.num_seqs && div_bq(cu_v) + lane_o <= qblock);
+        seq = __builtin_popcountll(le) - 1;
+        const int sq = max(seq, 0);
+        q_start = __builtin_amdgcn_readlane(cu_v, sq);
+        q_len = __builtin_amdgcn_readlane(cu_v, sq + 1) - q_start;
+        seq_len = __builtin_amdgcn_readlane(sk_v, sq);
+      } else {
+        seq = pw_find_seq(sa.cu, sa.num_seqs, qblock, BQ);
+        const int sq = max(seq, 0);
+        q_start = sa.cu[sq];
+        q_len = sa.cu[sq + 1] - q_start;
+        seq_len = sa.sk[sq];
+      }
+      if (seq < 0) continue;
+      const int qb_local = qblock - (div_bq(q_start) + seq);
+      if (qb_local * BQ >= q_len || (sa.skip_decodes && q_len == 1) || (sa.only_decodes && q_len != 1)) continue;
+      I.seq = seq; I.q_start = q_start; I.q_len = q_len; I.seq_len = seq_len;
+      I.ctx_len = seq_len - q_len;
+      I.tok0 = qb_local * BQ;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        const int m_row = wave * 64 + sb * 32 + qr_o;
+        const int tok = I.tok0 + div_g(m_row);
+        I.lim[sb] = ((m_row < BQ * sa.G) && (tok < q_len)) ? min(I.ctx_len + tok, seq_len - 1) : -1;
+      }
+      I.w_tok_lo = I.tok0 + div_g(wave * 64);
+      const int wg_tok_hi = min(I.tok0 + BQ - 1, q_len - 1);
+      const int n_keys_wg = max(0, min(I.ctx_len + wg_tok_hi + 1, seq_len));
+      I.last_group = (max(n_keys_wg, 1) - 1) >> 4;                 // last 16-key group this Q block can see
+      I.tile_lo = 0;
+      I.tile_hi = (n_keys_wg + kPwTile - 1) / kPwTile;
+      if (sa.key_splits > 1) {                    // key-split launch: an even share of this Q block's tiles
+        const int tps = (I.tile_hi + sa.key_splits - 1) / sa.key_splits;
+        I.tile_lo = min(I.ksplit * tps, I.tile_hi);
+        I.tile_hi = min(I.tile_hi, I.tile_lo + tps);
+      }
+      I.out_base = sa.out + (int64_t)I.ksplit * sa.out_split_stride;
+      I.lse_base = sa.lse ? sa.lse + (int64_t)I.ksplit * sa.lse_split_stride : nullptr;
+      {
+        const uint64_t b = (uint64_t)(sa.bt + (int64_t)seq * sa.bt_stride);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        I.bt64 = ((uint64_t)hi << 32) | lo;
+      }
+      return true;
+    }
+  };
+
+  // this lane's query row of sub-block sb (recomputed where it is needed: nothing of it lives through the tile loop)
+  auto row_of = [&](const Item& I, int sb, int& tok_local, int& hq) __attribute__((always_inline)) {
+    const int m_row = wave * 64 + sb * 32 + (lane_o & 31);
+    tok_local = I.tok0 + div_g(m_row);
+    hq = head * sa.G + mod_g(m_row);
+    return (m_row < sa.BQ * sa.G) && (tok_local < I.q_len);
+  };
+  // a 64-bit address that is the same for the whole wave, in scalar registers
+  auto uniform64 = [&](uint64_t b) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return ((uint64_t)hi << 32) | lo;
+  };
+
+  // ---- Q rows -> registers (padding rows read the sequence's last query row and are zeroed on conversion): scalar base,
+  // 32-bit lane offset (the host admits strides below 2^22 elements). Ordinary loads, so that the compiler never touches
+  // their registers before they have landed (it copies the outputs of an asm load at will); its wait before their first
+  // use counts only what IT issued after them - the epilogue's stores - and the LDS-DMA pieces between are older than
+  // those, so the wait covers them too (vmcnt retires in order).
   wu32x4_t qraw[2][8];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)(q_start + min(tok_local[sb], q_len - 1)) * p.q_stride_token + (int64_t)hq[sb] * p.q_stride_head + 8 * half;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qraw[sb][ks] = pw_gload16(qp + 16 * ks);
-  }
+  auto issue_q = [&](const Item& I) __attribute__((always_inline)) {
+    // scalar address of the block's first token and this KV head's first query head; a lane's row is within 2^31 bytes of it
+    const uint64_t qb = uniform64((uint64_t)(sa.q + (int64_t)(I.q_start + I.tok0) * (int64_t)sa.q_st + (int64_t)(head * sa.G) * (int64_t)sa.q_sh));
+    sfor<2>([&](auto SB) {
+      constexpr int sb = decltype(SB)::value;
+      int tok_local, hq;
+      row_of(I, sb, tok_local, hq);
+      const uint32_t off = (uint32_t)(((min(tok_local, I.q_len - 1) - I.tok0) * sa.q_st + (hq - head * sa.G) * sa.q_sh + 8 * (lane_o >> 5)) * 2);
+      typedef const __attribute__((address_space(1))) char* gq_t;
+      sfor<8>([&](auto KS) { constexpr int ks = decltype(KS)::value; qraw[sb][ks] = *(const __attribute__((address_space(1))) wu32x4_t*)((gq_t)qb + off + 32 * ks); });
+    });
+  };
 
   // ---- LDS-DMA constants: wave w stages key rows 16 w .. 16 w + 15 of every tile, four rows per instruction -
-  const char* kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
-  const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
-  const int last_group = (max(n_keys_wg, 1) - 1) >> 4;                   // last 16-key group this Q block can see
   const int page_mask = p.page_size - 1;
   const uint32_t ksb = a.k_slot_stride * 2, vsb = a.v_slot_stride * 2;   // bytes between key rows of a page
   const uint32_t kpb = a.k_page_stride * 2, vpb = a.v_page_stride * 2;   // bytes between pages
-  const int r4 = lane >> 4, c16 = lane & 15;
   // LDS row R = 4 i + r4 of the group, chunk position c16 holds logical chunk c16 ^ f(R) (swizzle on the source side);
-  // rows past the sequence (R > maxr, last group only) re-read row maxr: finite data under a zero probability
+  // rows past the sequence (R > maxr, last group only) re-read row maxr: finite data under a zero probability.
+  // (The swizzle terms are recomputed from an opaque lane index at each - rare - call, not kept in eight registers.)
   uint32_t koff[4], voff[4];
   auto set_k_offsets = [&](int maxr) {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int r4 = lo >> 4, c16 = lo & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + ((c16 ^ R) << 4)); }
   };
   auto set_v_offsets = [&](int maxr) {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int r4 = lo >> 4, c16 = lo & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + ((c16 ^ (((R & 3) << 2) | ((R >> 2) & 3))) << 4)); }
   };
@@ -317,20 +430,14 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   set_v_offsets(15);
   bool k_tail = false, v_tail = false;           // offsets already clamped for the sequence's last, partial group
   const uint32_t lds_wave = (uint32_t)(wave * 4096);
-  uint64_t bt64;
-  {
-    const uint64_t b = (uint64_t)(p.block_table + (int64_t)seq * p.block_table_stride);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-    bt64 = ((uint64_t)hi << 32) | lo;
-  }
   // 16-key group of wave w in `tile` (tiles past the share repeat its last tile: never read, keeps the DMA count
   // per iteration fixed), its first key, the byte offset of its block-table entry
-  auto group_key0 = [&](int tile) { return min(min(tile, tile_hi - 1) * 4 + wave, last_group) << 4; };
-  auto entry_off = [&](int tile) { return __builtin_amdgcn_readfirstlane((group_key0(tile) >> a.page_shift) << 2); };
+  auto group_key0 = [&](const Item& I, int tile) { return min(min(tile, I.tile_hi - 1) * 4 + wave, I.last_group) << 4; };
+  auto entry_off = [&](const Item& I, int tile) { return __builtin_amdgcn_readfirstlane((group_key0(I, tile) >> a.page_shift) << 2); };
   // block-table entry -> 64-bit address of the group's first key row
-  auto group_base = [&](int tile, int page, auto ISV) {
+  auto group_base = [&](const Item& I, int tile, int page, auto ISV) {
     constexpr bool isv = decltype(ISV)::value != 0;
-    const uint32_t slot0 = (uint32_t)(group_key0(tile) & page_mask);
+    const uint32_t slot0 = (uint32_t)(group_key0(I, tile) & page_mask);
     const uint64_t b = (uint64_t)(isv ? vbase : kbase) + (uint64_t)(uint32_t)page * (isv ? vpb : kpb) + (uint64_t)slot0 * (isv ? vsb : ksb);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
     return ((uint64_t)hi << 32) | lo;
@@ -339,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // no clamps, the in-page offset in 32 bits
   const int wave16 = wave * 16;
   auto entry_off_fast = [&](int tile) { return __builtin_amdgcn_readfirstlane(((tile * kPwTile + wave16) >> a.page_shift) << 2); };
-  auto group_base_fast = [&](int tile, int page, auto ISV) {
+  auto group_base_fast = [&](const Item&, int tile, int page, auto ISV) {
     constexpr bool isv = decltype(ISV)::value != 0;
     const uint32_t in_page = (uint32_t)((tile * kPwTile + wave16) & page_mask) * (isv ? vsb : ksb);
     const uint64_t b = (uint64_t)(isv ? vbase : kbase) + (uint64_t)(uint32_t)page * (isv ? vpb : kpb) + in_page;
@@ -347,9 +454,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     return ((uint64_t)hi << 32) | lo;
   };
   // the sequence ends inside this group (only ever its last one, and every later fetch repeats it): clamp the rows once
-  auto tail_check = [&](int tile, auto ISV) {
+  auto tail_check = [&](const Item& I, int tile, auto ISV) {
     constexpr bool isv = decltype(ISV)::value != 0;
-    const int maxr = seq_len - 1 - group_key0(tile);
+    const int maxr = I.seq_len - 1 - group_key0(I, tile);
     if (__builtin_expect(maxr < 15 && !(isv ? v_tail : k_tail), 0)) {
       if (isv) { set_v_offsets(maxr); v_tail = true; } else { set_k_offsets(maxr); k_tail = true; }
     }
@@ -373,49 +480,54 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     v_rd1[b] = (uint32_t)(kLdsV + r1 * ROWB + ((lc ^ f1) << 4) + 8 * (pp & 1));
   }
 
-  // ---- first tiles on their way: K0 K1 V0 | K2 V1 (the issue order fixes the counted waits below) -----
+  // ---- an item's first tiles on their way: K0 K1 V0 | K2 V1 (twenty pieces) ------------------------------
   int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration (V's = K's of one iteration earlier)
-  if (tile_hi > tile_lo) {
+  auto issue_first_tiles = [&](const Item& I) __attribute__((always_inline)) {
+    if (k_tail) { set_k_offsets(15); k_tail = false; }     // the previous item may have ended inside a group
+    if (v_tail) { set_v_offsets(15); v_tail = false; }
+    if (I.tile_hi <= I.tile_lo) return;
     int pk0, pk1, pk2, pv0, pv1;
-    const int eo0 = entry_off(tile_lo), eo1 = entry_off(tile_lo + 1), eo2 = entry_off(tile_lo + 2), eo3 = entry_off(tile_lo + 3);
-    if (spec_bt && eo0 == spec_off[0] && eo1 == spec_off[1] && eo2 == spec_off[2] && eo3 == spec_off[3]) {
+    const int eo0 = entry_off(I, I.tile_lo), eo1 = entry_off(I, I.tile_lo + 1), eo2 = entry_off(I, I.tile_lo + 2), eo3 = entry_off(I, I.tile_lo + 3);
+    if (sa.num_seqs == 1 && sa.key_splits == 1 && eo0 == spec_off[0] && eo1 == spec_off[1] && eo2 == spec_off[2] && eo3 == spec_off[3]) {
       pk0 = spec_pg[0]; pk1 = spec_pg[1]; pk2 = spec_pg[2]; pg_k = spec_pg[3];     // the speculative entries are the right ones
     } else {
-      scalar_load4((const int32_t*)bt64, eo0 >> 2, eo1 >> 2, eo2 >> 2, eo3 >> 2, pk0, pk1, pk2, pg_k);
+      scalar_load4((const int32_t*)I.bt64, eo0 >> 2, eo1 >> 2, eo2 >> 2, eo3 >> 2, pk0, pk1, pk2, pg_k);
     }
     pv0 = pk0; pv1 = pk1; pg_v = pk2;            // K and V share the block table
     auto group = [&](int tile, int page, auto ISV, uint32_t lds_dst) {
       constexpr bool isv = decltype(ISV)::value != 0;
-      tail_check(tile, ISV);
-      const uint64_t base = group_base(tile, page, ISV);
+      tail_check(I, tile, ISV);
+      const uint64_t base = group_base(I, tile, page, ISV);
 #pragma unroll
       for (int i = 0; i < 4; ++i) pw_glds16(isv ? voff[i] : koff[i], base, lds_dst + lds_wave + i * 1024);
     };
-    group(tile_lo, pk0, ic<0>{}, kLdsK);
-    group(tile_lo + 1, pk1, ic<0>{}, kLdsK + kSlotBytes);
-    group(tile_lo, pv0, ic<1>{}, kLdsV);
-    group(tile_lo + 2, pk2, ic<0>{}, kLdsK + 2 * kSlotBytes);
-    group(tile_lo + 1, pv1, ic<1>{}, kLdsV + kSlotBytes);
-  }
-  sfor<128>([&](auto I) { acc_zero<kAO + decltype(I)::value>(); });
+    group(I.tile_lo, pk0, ic<0>{}, kLdsK);
+    group(I.tile_lo + 1, pk1, ic<0>{}, kLdsK + kSlotBytes);
+    group(I.tile_lo, pv0, ic<1>{}, kLdsV);
+    group(I.tile_lo + 2, pk2, ic<0>{}, kLdsK + 2 * kSlotBytes);
+    group(I.tile_lo + 1, pv1, ic<1>{}, kLdsV + kSlotBytes);
+  };
 
-  // ---- Q' = Q * scale * log2(e), packed, into accumulator registers -----------------------------------
-  // the 16 Q loads are older than the (at most 20) LDS-DMA pieces behind them
-  asm volatile("s_waitcnt vmcnt(20)"
-               : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[0][4]), "+v"(qraw[0][5]), "+v"(qraw[0][6]), "+v"(qraw[0][7]),
-                 "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]), "+v"(qraw[1][4]), "+v"(qraw[1][5]), "+v"(qraw[1][6]), "+v"(qraw[1][7])
-               :: "memory");
+  // ---- O = 0 and Q' = Q * scale * log2(e), packed, into accumulator registers ---------------------------
   const float scale2 = p.scale * kPwLog2e;
-  sfor<2>([&](auto SB) {
-    sfor<8>([&](auto KS) {
-      constexpr int sb = decltype(SB)::value, ks = decltype(KS)::value;
-      const wu32x4_t v = row_ok[sb] ? qraw[sb][ks] : wu32x4_t{0, 0, 0, 0};
-      sfor<4>([&](auto E) {
-        constexpr int e = decltype(E)::value;
-        acc_write<kAQ + 32 * sb + 4 * ks + e>(pw_pack<T>(pw_lo<T>(v[e]) * scale2, pw_hi<T>(v[e]) * scale2));
+  auto zero_o_and_convert_q = [&](const Item& I) __attribute__((always_inline)) {
+    sfor<128>([&](auto IC) { acc_zero<kAO + decltype(IC)::value>(); });
+    // the item's query rows have landed (and everything older: its first tiles, the previous item's output)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[0][4]), "+v"(qraw[0][5]), "+v"(qraw[0][6]), "+v"(qraw[0][7]),
+                   "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]), "+v"(qraw[1][4]), "+v"(qraw[1][5]), "+v"(qraw[1][6]), "+v"(qraw[1][7])
+                 :: "memory");
+    sfor<2>([&](auto SB) {
+      sfor<8>([&](auto KS) {
+        constexpr int sb = decltype(SB)::value, ks = decltype(KS)::value;
+        const wu32x4_t v = I.lim[sb] >= 0 ? qraw[sb][ks] : wu32x4_t{0, 0, 0, 0};
+        sfor<4>([&](auto E) {
+          constexpr int e = decltype(E)::value;
+          acc_write<kAQ + 32 * sb + 4 * ks + e>(pw_pack<T>(pw_lo<T>(v[e]) * scale2, pw_hi<T>(v[e]) * scale2));
+        });
       });
     });
-  });
+  };
 
   // ---- state -------------------------------------------------------------------------------------------
   wf32x16_t S[2][2];          // [sub-block][32-key block]: S^T of the tile in flight
@@ -423,15 +535,29 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   wu32x4_t vfr[4][4];         // transposed V fragments [output block b][k-step sk]
   float e0[2][16], e1[2][16];
   float ps0[2] = {0.0f, 0.0f}, ps1[2] = {0.0f, 0.0f};   // running row sums (two chains)
+  auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < 2; ++x) {
+      ps0[x] = 0.0f; ps1[x] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { S[x][0][r] = -INFINITY; S[x][1][r] = -INFINITY; pw[x][r] = 0u; e0[x][r] = 0.0f; e1[x][r] = 0.0f; }
-  }
+      for (int r = 0; r < 16; ++r) { S[x][0][r] = -INFINITY; S[x][1][r] = -INFINITY; pw[x][r] = 0u; e0[x][r] = 0.0f; e1[x][r] = 0.0f; }
+    }
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
+      for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
+  };
+
+  Item cur;
+  int round = 0;
+#ifdef MI355_PW_STAMP
+  unsigned long long st_entry;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry) :: "memory");
+#endif
+  if (!setup(cur, round)) return;
+  issue_q(cur);
+  issue_first_tiles(cur);
+  zero_o_and_convert_q(cur);
 
   // ---- the pieces of an iteration ------------------------------------------------------------------------
   // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7. A chain starts from the constant 0; on a tile that
@@ -444,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       if (__builtin_expect(!need_mask, 1)) {
         ops::template qk_zero<KA, QA>(S[x][kb]);
       } else {
-        const int rel = lim[x] - t * kPwTile - 32 * kb - 4 * half;     // visible: (r & 3) + 8 (r >> 2) <= rel
+        const int rel = cur.lim[x] - t * kPwTile - 32 * kb - 4 * half;     // visible: (r & 3) + 8 (r >> 2) <= rel
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[x][kb][r] = ((r & 3) + 8 * (r >> 2) <= rel) ? 0.0f : -INFINITY;
         asm volatile("s_nop 1");      // VALU write -> MFMA read
@@ -524,13 +650,13 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     // scalar side of this iteration's LDS-DMA (entries fetched during the previous iteration), and the fetch of the
     // next iteration's entries (they land before the wait that ends this one)
     if constexpr (!steady) {
-      need_mask = (t * kPwTile + kPwTile - 1 > ctx_len + w_tok_lo) || (t * kPwTile + kPwTile > seq_len);
-      tail_check(t + 3, ic<0>{});
-      tail_check(t + 2, ic<1>{});
-      kb64 = group_base(t + 3, pg_k, ic<0>{});
-      vb64 = group_base(t + 2, pg_v, ic<1>{});
+      need_mask = (t * kPwTile + kPwTile - 1 > cur.ctx_len + cur.w_tok_lo) || (t * kPwTile + kPwTile > cur.seq_len);
+      tail_check(cur, t + 3, ic<0>{});
+      tail_check(cur, t + 2, ic<1>{});
+      kb64 = group_base(cur, t + 3, pg_k, ic<0>{});
+      vb64 = group_base(cur, t + 2, pg_v, ic<1>{});
       pg_v = pg_k;                                 // V(t+3) lives in the page of K(t+3)
-      pw_sload(pg_k, bt64, entry_off(t + 4));
+      pw_sload(pg_k, cur.bt64, entry_off(cur, t + 4));
     }
     // piece j of this iteration's LDS-DMA: 0..3 = K(t+3), 4..7 = V(t+2)
     auto dma_piece = [&](auto JC) __attribute__((always_inline)) {
@@ -551,14 +677,14 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       qk(ic<0>{}, GC, t, need_mask);
       if constexpr (steady && g == 0) {
         __builtin_amdgcn_sched_barrier(0);
-        kb64 = group_base_fast(t + 3, pg_k, ic<0>{});
+        kb64 = group_base_fast(cur, t + 3, pg_k, ic<0>{});
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (steady && g == 1) {
         __builtin_amdgcn_sched_barrier(0);
-        vb64 = group_base_fast(t + 2, pg_v, ic<1>{});
+        vb64 = group_base_fast(cur, t + 2, pg_v, ic<1>{});
         pg_v = pg_k;
-        pw_sload(pg_k, bt64, entry_off_fast(t + 4));
+        pw_sload(pg_k, cur.bt64, entry_off_fast(t + 4));
         __builtin_amdgcn_sched_barrier(0);
       }
       estream(ic<1>{}, ic<12 + g>{});
@@ -606,152 +732,231 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     PW_SEG_STAMP(5);
   };
 
-  if (tile_hi > tile_lo) {
-    // K(tile_lo), K(tile_lo + 1), V(tile_lo) have landed (K2 and V1, 8 pieces, may still fly)
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    sfor<16>([&](auto NC) __attribute__((always_inline)) { kread(NC, ic<0>{}); });
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 0 is re-filled (K(tile_lo + 3)) in the first iteration
-    int t = tile_lo;
-#ifdef MI355_PW_STAMP
-    // diagnostic build only (tools/pw_clock.py): shader cycles and 100 MHz ticks around the tile loop
-    unsigned long long st_c0, st_r0;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
-    st_last = (unsigned)st_c0;
+  // ---- an item's output: O / l through this wave's parking rows, whole 256-byte rows out ------------------
+  auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
+    const int G = sa.G;
+    const uint32_t g_inv = (65536u + (uint32_t)G - 1u) / (uint32_t)G;   // m / G == (m * g_inv) >> 16 for m < 256, G <= 256
+    const int lane = lane_o, qr = lane_o & 31, half = lane_o >> 5;
+    char* ost = smem + kLdsO + wave * (32 * kPwORS);
+    const bool wide_store = __builtin_amdgcn_readfirstlane((int)((((uintptr_t)I.out_base & 15) == 0) && (sa.out_st % 8 == 0) && (sa.out_sh % 8 == 0))) != 0;
+    const bool whole_block = (I.q_len - I.tok0 >= sa.BQ) && (sa.BQ * G == kPwRows);   // every row of the block is a row of the sequence
+    const int key_lo = I.tile_lo * kPwTile;
+    const int orow = lane >> 4, och = lane & 15;
+    // scalar address of the block's first token, this KV head's first query head; a row is a 32-bit byte offset from it
+    typedef __attribute__((address_space(1))) char* gptr_t;
+    const gptr_t out0 = (gptr_t)uniform64((uint64_t)(I.out_base + (int64_t)(I.q_start + I.tok0) * (int64_t)sa.out_st + (int64_t)(head * G) * (int64_t)sa.out_sh));
+    const uint32_t st_b = (uint32_t)sa.out_st * 2u, sh_b = (uint32_t)sa.out_sh * 2u;
+    const uint32_t tok_left = (uint32_t)min(I.q_len - I.tok0, sa.BQ);   // tokens of this block inside the sequence
+    bool bad[2];                                 // the row left the range the reference-0 arithmetic is good for
+    sfor<2>([&](auto SB) __attribute__((always_inline)) {
+      constexpr int sb = decltype(SB)::value;
+      float l = ps0[sb] + ps1[sb];
+      l += lane_xor32(l);
+      int tok_local, hq;
+      const bool row_ok = row_of(I, sb, tok_local, hq);
+      if (I.lse_base && row_ok && half == 0)    // P = exp2(score): ln of the sum is the lse
+        I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? __builtin_amdgcn_logf(l) * 0.6931471805599453f : -INFINITY;
+      const float inv = (row_ok && l > 0.0f) ? 1.0f / l : 0.0f;
+      float amax = 0.0f;
+      if (__builtin_expect(wide_store, 1)) {
+        // the sub-block leaves as whole 256-byte rows, 16 bytes per lane (a lane's own 8-byte pieces touch 32 rows per
+        // store): parked in this wave's rows, read back by other lanes (LDS is in order per wave, also against the next
+        // sub-block's writes)
+        sfor<4>([&](auto B) __attribute__((always_inline)) {
+          sfor<4>([&](auto C) __attribute__((always_inline)) {
+            constexpr int b = decltype(B)::value, c = decltype(C)::value, base = kAO + 64 * sb + 16 * b + 4 * c;
+            const float o0 = acc_read<base>(), o1 = acc_read<base + 1>(), o2 = acc_read<base + 2>(), o3 = acc_read<base + 3>();
+            pw_amax3(amax, o0, o1);
+            pw_amax3(amax, o2, o3);
+            *(wu32x2_t*)(ost + qr * kPwORS + (32 * b + 8 * c + 4 * half) * 2) = wu32x2_t{pw_pack<T>(o0 * inv, o1 * inv), pw_pack<T>(o2 * inv, o3 * inv)};
+          });
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        wu32x4_t rows[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rows[j] = *(const wu32x4_t*)(ost + (4 * j + orow) * kPwORS + och * 16);
+        typedef __attribute__((address_space(1))) wu32x4_t* grow_t;
+        auto row_off = [&](int j, uint32_t& tq) {
+          const uint32_t m = (uint32_t)(wave * 64 + sb * 32 + 4 * j + orow);
+          tq = sa.g_shift >= 0 ? (m >> sa.g_shift) : ((m * g_inv) >> 16);      // token and query head of row m inside the block
+          return tq * st_b + (m - tq * (uint32_t)G) * sh_b + (uint32_t)och * 16u;
+        };
+        if (__builtin_expect(whole_block, 1)) {
+#pragma unroll
+#ifdef PW_DBG_STORE
+          for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); *(wu32x4_t*)((char*)(uint64_t)out0 + off) = rows[j]; }
+#else
+          for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
 #endif
-    // Tiles below steady_hi are steady for THIS wave (the bound differs between the waves of a workgroup; both loops
-    // have the same barriers, so waves may sit in different ones): unmasked - wholly at or below the wave's first row's
-    // last visible key and inside the sequence - with tile t + 4 inside the share and this wave's group of it inside
-    // what the Q block can see (then the groups of t + 2, t + 3 are whole). Shifts, not divisions: the terms can be negative.
-    const int steady_hi = 1 + min(min(tile_hi - 5, ((last_group - wave) >> 2) - 4), min((ctx_len + w_tok_lo - (kPwTile - 1)) >> 6, (seq_len >> 6) - 1));
-    while (t + 3 <= steady_hi) {                 // three at a time: leaves the ring phase at 0
-      iteration(ic<0>{}, ic<1>{}, t);
-      iteration(ic<1>{}, ic<1>{}, t + 1);
-      iteration(ic<2>{}, ic<1>{}, t + 2);
-      t += 3;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); if (tq < tok_left) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
+        }
+      } else {
+        uint16_t* op = I.out_base + (int64_t)(I.q_start + tok_local) * (int64_t)sa.out_st + (int64_t)hq * (int64_t)sa.out_sh + 4 * half;
+        sfor<4>([&](auto B) __attribute__((always_inline)) {
+          sfor<4>([&](auto C) __attribute__((always_inline)) {
+            constexpr int b = decltype(B)::value, c = decltype(C)::value, base = kAO + 64 * sb + 16 * b + 4 * c;
+            const float o0 = acc_read<base>(), o1 = acc_read<base + 1>(), o2 = acc_read<base + 2>(), o3 = acc_read<base + 3>();
+            pw_amax3(amax, o0, o1);
+            pw_amax3(amax, o2, o3);
+            if (row_ok) *(wu32x2_t*)(op + 32 * b + 8 * c) = wu32x2_t{pw_pack<T>(o0 * inv, o1 * inv), pw_pack<T>(o2 * inv, o3 * inv)};
+          });
+        });
+      }
+      amax = fmaxf(amax, lane_xor32(amax));
+      const bool has_keys = row_ok && I.tile_hi > I.tile_lo && I.lim[sb] >= key_lo;
+      bad[sb] = has_keys && !(l >= kPwSumLo && l <= kPwSumHi && amax < INFINITY);   // a NaN sum fails both comparisons
+#ifdef PW_FORCE_FALLBACK
+      bad[sb] = has_keys;                          // diagnostic build: every row through the per-row routine
+#endif
+    });
+    asm volatile("; MARK rows_stored");
+    // ---- rows that left the range: computed again, the plain way (never on attention scores as models produce them)
+    const unsigned long long bad_a = __ballot(bad[0]), bad_b = __ballot(bad[1]);
+    if (__builtin_expect((bad_a | bad_b) != 0, 0)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores above are done before these rows are written again
+      for (int rr = 0; rr < 64; ++rr) {
+        const unsigned long long bits = rr < 32 ? bad_a : bad_b;
+        if (!((bits >> (rr & 31)) & 1)) continue;             // lane rr & 31 holds the row's flag (both half-waves agree)
+        const int m = wave * 64 + rr;
+        const int tok = I.tok0 + div_g(m);
+        const int key_hi = min(min(I.ctx_len + tok, I.seq_len - 1) + 1, I.tile_hi * kPwTile);
+        pw_row_fallback<T>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo, key_hi, I.out_base, I.lse_base, lane);
+      }
     }
-    // The workgroup walks tile_hi tiles, but a wave's 64 rows see no key past their last row's limit: the tiles from
-    // own_hi on are wholly masked for it (up to three of a Q block's last four). It computes nothing for them - it only
-    // keeps staging its share of the K/V tiles the other waves still need (the kernel runs at the chip's power limit:
-    // matrix work on masked tiles costs the other waves clock).
-    const int w_tok_hi = min(tok0 + (wave * 64 + 63) / G, q_len - 1);
-    const int own_hi = w_tok_lo >= q_len ? tile_lo : max(tile_lo, min(tile_hi, (min(ctx_len + w_tok_hi, seq_len - 1) >> 6) + 1));
-    while (t < own_hi) {
-      iteration(ic<0>{}, ic<0>{}, t);
-      if (++t >= own_hi) break;
-      iteration(ic<1>{}, ic<0>{}, t);
-      if (++t >= own_hi) break;
-      iteration(ic<2>{}, ic<0>{}, t);
-      ++t;
+  };
+
+  while (true) {
+    reset_state();
+    const int tile_lo = cur.tile_lo, tile_hi = cur.tile_hi;
+    // (every load behind the item - its query rows and its first tiles - has landed: zero_o_and_convert_q waited)
+    if (tile_hi > tile_lo) {
+      asm volatile("s_barrier" ::: "memory");
+      sfor<16>([&](auto NC) __attribute__((always_inline)) { kread(NC, ic<0>{}); });
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 0 is re-filled (K(tile_lo + 3)) in the first iteration
+      int t = tile_lo;
+#ifdef MI355_PW_STAMP
+      // diagnostic build only (tools/pw_clock.py): shader cycles and 100 MHz ticks around the tile loop
+      unsigned long long st_c0, st_r0;
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
+      st_last = (unsigned)st_c0;
+      for (int i = 0; i < 6; ++i) st_sum[i] = 0;
+#endif
+      // Tiles below steady_hi are steady for THIS wave (the bound differs between the waves of a workgroup; both loops
+      // have the same barriers, so waves may sit in different ones): unmasked - wholly at or below the wave's first row's
+      // last visible key and inside the sequence - with tile t + 4 inside the share and this wave's group of it inside
+      // what the Q block can see (then the groups of t + 2, t + 3 are whole). Shifts, not divisions: the terms can be negative.
+      const int steady_hi = 1 + min(min(tile_hi - 5, ((cur.last_group - wave) >> 2) - 4),
+                                    min((cur.ctx_len + cur.w_tok_lo - (kPwTile - 1)) >> 6, (cur.seq_len >> 6) - 1));
+      while (t + 3 <= steady_hi) {                 // three at a time: leaves the ring phase at 0
+        iteration(ic<0>{}, ic<1>{}, t);
+        iteration(ic<1>{}, ic<1>{}, t + 1);
+        iteration(ic<2>{}, ic<1>{}, t + 2);
+        t += 3;
+      }
+      // The workgroup walks tile_hi tiles, but a wave's 64 rows see no key past their last row's limit: the tiles from
+      // own_hi on are wholly masked for it (G < 4: up to three of a Q block's last four). It computes nothing for
+      // them - it only keeps staging its share of the K/V tiles the other waves still need.
+      const int w_tok_hi = min(cur.tok0 + (wave * 64 + 63) / G, cur.q_len - 1);
+      const int own_hi = cur.w_tok_lo >= cur.q_len ? tile_lo : max(tile_lo, min(tile_hi, (min(cur.ctx_len + w_tok_hi, cur.seq_len - 1) >> 6) + 1));
+      while (t < own_hi) {
+        iteration(ic<0>{}, ic<0>{}, t);
+        if (++t >= own_hi) break;
+        iteration(ic<1>{}, ic<0>{}, t);
+        if (++t >= own_hi) break;
+        iteration(ic<2>{}, ic<0>{}, t);
+        ++t;
+      }
+#ifdef MI355_PW_STAMP
+      {
+        unsigned long long st_c1, st_r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1) :: "memory");
+        unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
+        if (dbg && tid == 192) {
+          unsigned long long* rec = dbg + 12ull * cur.rank;
+          rec[0] = st_c1 - st_c0; rec[1] = st_r1 - st_r0; rec[2] = (unsigned long long)(tile_hi - tile_lo);
+#ifndef MI355_PW_SEAM
+          for (int i = 1; i < 6; ++i) rec[2 + i] = st_sum[i];
+#endif
+          rec[8] = st_entry; rec[9] = st_r0; rec[10] = st_r1;
+        }
+      }
+#endif
+      // drain: sub-block B of the wave's last tile
+      if (own_hi > tile_lo) {
+        sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
+        asm volatile("s_nop 1");
+        sfor<16>([&](auto GC) __attribute__((always_inline)) { pv(ic<1>{}, GC); });
+      }
+      // the tiles this wave only stages for the others: the memory side of an iteration, ring slots at run time
+      for (; t < tile_hi; ++t) {
+        const int ph = (t - tile_lo) % 3;
+        const uint32_t kd = (uint32_t)(kLdsK + ph * kSlotBytes) + lds_wave, vd = (uint32_t)(kLdsV + ((ph + 2) % 3) * kSlotBytes) + lds_wave;
+        tail_check(cur, t + 3, ic<0>{});
+        tail_check(cur, t + 2, ic<1>{});
+        const uint64_t kb64 = group_base(cur, t + 3, pg_k, ic<0>{}), vb64 = group_base(cur, t + 2, pg_v, ic<1>{});
+        pg_v = pg_k;
+        pg_k = *(const __attribute__((address_space(4))) int*)(cur.bt64 + (uint32_t)entry_off(cur, t + 4));   // (an ordinary load: see setup)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pw_glds16(koff[j], kb64, kd + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pw_glds16(voff[j], vb64, vd + j * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k) :: "memory");
+      }
     }
+
+    // ---- seam: the next item's loads go out, then this item's output ----------------------------------------
+#ifdef MI355_PW_SEAM
+#define PW_SEAM_STAMP(i) do { unsigned long long st_x; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_x) :: "memory"); \
+    unsigned long long* dbg_ = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0); \
+    if (dbg_ && tid == 192) dbg_[12ull * cur.rank + (i)] = st_x; } while (0)
+#else
+#define PW_SEAM_STAMP(i) do { } while (0)
+#endif
+    PW_SEAM_STAMP(3);
+    asm volatile("; MARK seam_begin");
+    refresh_lane();
+    Item nxt;
+    const bool more = setup(nxt, round);
+    PW_SEAM_STAMP(4);
+    asm volatile("; MARK setup_done");
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA results readable; no LDS-DMA of this item in flight
+    __syncthreads();                                                          // every wave is done with the rings
+    PW_SEAM_STAMP(5);
+    asm volatile("; MARK barrier_done");
+    if (more) {
+      issue_q(nxt);
+      asm volatile("; MARK q_issued");
+      issue_first_tiles(nxt);
+      asm volatile("; MARK tiles_issued");
+      PW_SEAM_STAMP(6);
+    } else {
+      // (defined on both paths: the registers of the previous item's rows are then not kept alive through the tile loop)
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qraw[sb][ks] = wu32x4_t{0, 0, 0, 0};
+    }
+    asm volatile("; MARK epilogue_begin");
+    epilogue(cur);
+    asm volatile("; MARK epilogue_done");
 #ifdef MI355_PW_STAMP
     {
-      unsigned long long st_c1, st_r1;
-      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1) :: "memory");
+      unsigned long long st_exit;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_exit) :: "memory");
       unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
-      if (dbg && tid == 192) {
-        unsigned long long* rec = dbg + 12ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
-        rec[0] = st_c1 - st_c0; rec[1] = st_r1 - st_r0; rec[2] = (unsigned long long)(tile_hi - tile_lo);
-        for (int i = 1; i < 6; ++i) rec[2 + i] = st_sum[i];
-        rec[8] = st_entry; rec[9] = st_r0; rec[10] = st_r1;
-      }
+      if (dbg && tid == 192) dbg[12ull * cur.rank + 11] = st_exit;
+      st_entry = st_exit;
     }
 #endif
-    // drain: sub-block B of the wave's last tile
-    if (own_hi > tile_lo) {
-      sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
-      asm volatile("s_nop 1");
-      sfor<16>([&](auto GC) __attribute__((always_inline)) { pv(ic<1>{}, GC); });
-    }
-    // the tiles this wave only stages for the others: the memory side of an iteration, ring slots at run time
-    for (; t < tile_hi; ++t) {
-      const int ph = (t - tile_lo) % 3;
-      const uint32_t kd = (uint32_t)(kLdsK + ph * kSlotBytes) + lds_wave, vd = (uint32_t)(kLdsV + ((ph + 2) % 3) * kSlotBytes) + lds_wave;
-      tail_check(t + 3, ic<0>{});
-      tail_check(t + 2, ic<1>{});
-      const uint64_t kb64 = group_base(t + 3, pg_k, ic<0>{}), vb64 = group_base(t + 2, pg_v, ic<1>{});
-      pg_v = pg_k;
-      pw_sload(pg_k, bt64, entry_off(t + 4));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pw_glds16(koff[j], kb64, kd + j * 1024);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pw_glds16(voff[j], vb64, vd + j * 1024);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k) :: "memory");
-    }
+    if (!more) break;
+    zero_o_and_convert_q(nxt);
+    asm volatile("; MARK converted");
+    cur = nxt;
   }
-
-  // ---- epilogue ------------------------------------------------------------------------------------------
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA results readable; no DMA into LDS in flight
-  __syncthreads();                                                          // every wave is done with the rings
-  constexpr int ORS = ROWB + 16;                                            // padded row stride of the parked O rows
-  char* ost = smem + wave * (64 * ORS);
-  const bool wide_store = (((uintptr_t)out_base & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
-  const int key_lo = tile_lo * kPwTile;
-  bool bad[2];                                 // the row left the range the reference-0 arithmetic is good for
-  sfor<2>([&](auto SB) __attribute__((always_inline)) {
-    constexpr int sb = decltype(SB)::value;
-    float l = ps0[sb] + ps1[sb];
-    l += lane_xor32(l);
-    if (lse_base && row_ok[sb] && half == 0)    // P = exp2(score): ln of the sum is the lse
-      lse_base[(int64_t)(q_start + tok_local[sb]) * p.lse_stride_token + hq[sb]] = l > 0.0f ? __builtin_amdgcn_logf(l) * 0.6931471805599453f : -INFINITY;
-    const float inv = (row_ok[sb] && l > 0.0f) ? 1.0f / l : 0.0f;
-    uint16_t* op = out_base + (int64_t)(q_start + tok_local[sb]) * p.out_stride_token + (int64_t)hq[sb] * p.out_stride_head + 4 * half;
-    float amax = 0.0f;
-    sfor<4>([&](auto B) __attribute__((always_inline)) {
-      sfor<4>([&](auto C) __attribute__((always_inline)) {
-        constexpr int b = decltype(B)::value, c = decltype(C)::value, base = kAO + 64 * sb + 16 * b + 4 * c;
-        const float o0 = acc_read<base>(), o1 = acc_read<base + 1>(), o2 = acc_read<base + 2>(), o3 = acc_read<base + 3>();
-        amax = fmaxf(fmaxf(amax, fmaxf(__builtin_fabsf(o0), __builtin_fabsf(o1))), fmaxf(__builtin_fabsf(o2), __builtin_fabsf(o3)));
-        const wu32x2_t w = {pw_pack<T>(o0 * inv, o1 * inv), pw_pack<T>(o2 * inv, o3 * inv)};
-        if (wide_store) *(wu32x2_t*)(ost + (sb * 32 + qr) * ORS + (32 * b + 8 * c + 4 * half) * 2) = w;
-        else if (row_ok[sb]) *(wu32x2_t*)(op + 32 * b + 8 * c) = w;
-      });
-    });
-    amax = fmaxf(amax, lane_xor32(amax));
-    const bool has_keys = row_ok[sb] && tile_hi > tile_lo && lim[sb] >= key_lo;
-    bad[sb] = has_keys && !(l >= kPwSumLo && l <= kPwSumHi && amax < INFINITY);   // a NaN sum fails both comparisons
-#ifdef PW_FORCE_FALLBACK
-    bad[sb] = has_keys;                          // diagnostic build: every row through the per-row routine
-#endif
-  });
-  if (wide_store) {
-    // O leaves as whole 256-byte rows, 16 bytes per lane (a lane's own 8-byte pieces touch 32 rows per store)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads other lanes' pieces back: LDS is in order per wave
-    const int orow = lane >> 4, och = lane & 15;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int r = 4 * j + orow;
-      const int m = wave * 64 + r;
-      const int tok = tok0 + m / G;
-      const wu32x4_t v = *(const wu32x4_t*)(ost + r * ORS + och * 16);
-      if (m < BQ * G && tok < q_len) {
-        wu32x4_t* dst = (wu32x4_t*)(out_base + (int64_t)(q_start + tok) * p.out_stride_token + (int64_t)(head * G + m % G) * p.out_stride_head + och * 8);
-        __builtin_nontemporal_store(v, dst);
-      }
-    }
-  }
-  // ---- rows that left the range: computed again, the plain way (never on attention scores as models produce them)
-  const unsigned long long bad_a = __ballot(bad[0]), bad_b = __ballot(bad[1]);
-  if (__builtin_expect((bad_a | bad_b) != 0, 0)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores above are done before these rows are written again
-    for (int rr = 0; rr < 64; ++rr) {
-      const unsigned long long bits = rr < 32 ? bad_a : bad_b;
-      if (!((bits >> (rr & 31)) & 1)) continue;             // lane rr & 31 holds the row's flag (both half-waves agree)
-      const int m = wave * 64 + rr;
-      const int tok = tok0 + m / G;
-      const int key_hi = min(min(ctx_len + tok, seq_len - 1) + 1, tile_hi * kPwTile);
-      pw_row_fallback<T>(p, a, (const int32_t*)bt64, kbase, vbase, q_start + tok, head * G + m % G, key_lo, key_hi, out_base, lse_base, lane);
-    }
-  }
-#ifdef MI355_PW_STAMP
-  {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long st_exit;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_exit) :: "memory");
-    unsigned long long* dbg = (unsigned long long*)(((unsigned long long)(unsigned)p.reserved1 << 32) | (unsigned)p.reserved0);
-    if (dbg && tid == 0) dbg[12ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) + 11] = st_exit;
-  }
-#endif
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -761,7 +966,11 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 bool prefill_pw_applicable(const mi355_attn_params& p) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  return !feat && p.head_size == 128 && G <= kPwRows && p.q_dtype == MI355_BF16 && p.kv_dtype == p.q_dtype;
+  // (rows of a Q block are addressed as 32-bit byte offsets from the block's first row: strides below 2^22 elements)
+  const int64_t lim = (int64_t)1 << 22;
+  const bool strides_ok = p.q_stride_token >= 0 && p.q_stride_token < lim && p.q_stride_head >= 0 && p.q_stride_head < lim &&
+                          p.out_stride_token >= 0 && p.out_stride_token < lim && p.out_stride_head >= 0 && p.out_stride_head < lim;
+  return !feat && strides_ok && p.head_size == 128 && G <= kPwRows && p.q_dtype == MI355_BF16 && p.kv_dtype == p.q_dtype;
 }
 
 template <typename T>
@@ -771,17 +980,36 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = kPwRows / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
+  a.g_shift = (a.group & (a.group - 1)) == 0 ? __builtin_ctz((unsigned)a.group) : -1;
+  a.bq_shift = (a.block_q & (a.block_q - 1)) == 0 ? __builtin_ctz((unsigned)a.block_q) : -1;
   a.key_splits = key_splits;
   a.out_split_stride = out_split_stride;
   a.lse_split_stride = lse_split_stride;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
-  const int qblocks = p.num_tokens / a.block_q + p.num_seqs;   // static upper bound, as the reference (:886-889,:935-943)
+  a.num_qblocks = p.num_tokens / a.block_q + p.num_seqs;   // static upper bound, as the reference (:886-889,:935-943)
+  // one workgroup per CU (it holds exactly one), in whole sets of num_kv_heads; fewer when there are fewer items
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    static std::atomic<int> cu_count[64];
+    int c = dev < 64 ? cu_count[dev].load(std::memory_order_relaxed) : 0;
+    if (c == 0 && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0 && dev < 64)
+      cu_count[dev].store(c, std::memory_order_relaxed);
+    if (c > 0) cus = c;
+  }
+  static const int slots_env = [] { const char* e = getenv("MI355_PW_SLOTS"); return e ? atoi(e) : 0; }();   // measurements only
+  const int items_per_head = a.num_qblocks * key_splits;
+  // One sequence: about one workgroup per CU, each walking several items (the boustrophedon deal is balanced for causal
+  // weights that fall linearly along the list; 1 x 4096: 116.7 us vs 118.5 with one item per workgroup, 2 x 4096 229 vs
+  // 234). Several sequences: the weights are a sawtooth and a static deal loses more than the seams gain (4 x 2048:
+  // 143.5 vs 135.7 us, 16 x 4096: 2011 vs 1881) - one item per workgroup, dealt by the hardware as CUs fall free.
+  const int per_cu = std::max(1, cus / p.num_kv_heads);
+  a.slots = std::max(1, std::min(items_per_head, slots_env > 0 ? slots_env : (p.num_seqs == 1 ? per_cu : items_per_head)));
   const size_t lds = kPwLds;
   static std::atomic<uint64_t> lds_opt_in{0};
   const int rc0 = ensure_dynamic_lds((const void*)prefill_pw_kernel<T>, (int)kPwLds, lds_opt_in, "hipFuncSetAttribute(prefill_pw)");
   if (rc0 != MI355_OK) return rc0;
-  hipLaunchKernelGGL((prefill_pw_kernel<T>), dim3(qblocks * p.num_kv_heads, key_splits), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((prefill_pw_kernel<T>), dim3(a.slots * p.num_kv_heads), dim3(256), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");
   if (rc == MI355_OK) set_kernel_name("prefill_mfma");
   return rc;
