@@ -27,6 +27,15 @@
 //     fails (scores beyond +-90 or so in log2 units: not attention as models produce it) is computed again by a
 //     slow, plain online-softmax routine in the same launch (pw_row_fallback). f16 (P <= 65504) cannot do this and
 //     stays on prefill_dma_kernel.
+//   * the tile loop has two forms: STEADY iterations (tile unmasked for the wave, the groups it fetches for the next
+//     tiles whole) carry no mask path and no tail handling and put their scalar address arithmetic behind the first
+//     MFMAs; general iterations do the rest (a Q block's last tiles, short sequences).
+//   * a workgroup walks SEVERAL work items when the batch is one sequence (about one workgroup per CU): the next
+//     item's query rows and first K/V tiles are requested before the current item's output is normalised and stored,
+//     so that chain of round trips runs beside the epilogue instead of in front of an idle CU. Everything the per-item
+//     code needs is re-derived per item from opaque copies of the lane index and the kernarg pointer: the tile loop has
+//     no register to spare for values hoisted out of the item loop (tools/isa_audit.py must report no compiler
+//     accumulator-register or scratch use).
 //
 // MFMA orientation, the in-register softmax layout and the LDS swizzles are those of prefill_dma_kernel
 // (prefill_mfma.hip).
@@ -128,11 +137,7 @@ template <typename T> __device__ __forceinline__ uint32_t pw_pack(float lo, floa
 template <int IDX> __device__ __forceinline__ void acc_write(uint32_t v) { asm volatile("v_accvgpr_write_b32 a%c0, %1" :: "n"(IDX), "v"(v)); }
 template <int IDX> __device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "n"(IDX)); }
 // running maximum of magnitudes: m = max(m, |a|, |b|) in one instruction (a NaN operand is dropped, like fmaxf)
-#ifdef PW_DBG_AMAX
-__device__ __forceinline__ void pw_amax3(float& m, float a, float b) { m = fmaxf(m, fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
-#else
 __device__ __forceinline__ void pw_amax3(float& m, float a, float b) { asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b)); }
-#endif
 template <int IDX> __device__ __forceinline__ float acc_read() { float r; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "n"(IDX)); return r; }
 
 // LDS -> accumulator registers (K fragments), LDS -> VGPR transposed (V fragments). "memory": LDS accesses the
@@ -783,11 +788,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         };
         if (__builtin_expect(whole_block, 1)) {
 #pragma unroll
-#ifdef PW_DBG_STORE
-          for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); *(wu32x4_t*)((char*)(uint64_t)out0 + off) = rows[j]; }
-#else
           for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
-#endif
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); if (tq < tok_left) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
@@ -811,7 +812,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       bad[sb] = has_keys;                          // diagnostic build: every row through the per-row routine
 #endif
     });
-    asm volatile("; MARK rows_stored");
     // ---- rows that left the range: computed again, the plain way (never on attention scores as models produce them)
     const unsigned long long bad_a = __ballot(bad[0]), bad_b = __ballot(bad[1]);
     if (__builtin_expect((bad_a | bad_b) != 0, 0)) {
@@ -915,21 +915,16 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #define PW_SEAM_STAMP(i) do { } while (0)
 #endif
     PW_SEAM_STAMP(3);
-    asm volatile("; MARK seam_begin");
     refresh_lane();
     Item nxt;
     const bool more = setup(nxt, round);
     PW_SEAM_STAMP(4);
-    asm volatile("; MARK setup_done");
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA results readable; no LDS-DMA of this item in flight
     __syncthreads();                                                          // every wave is done with the rings
     PW_SEAM_STAMP(5);
-    asm volatile("; MARK barrier_done");
     if (more) {
       issue_q(nxt);
-      asm volatile("; MARK q_issued");
       issue_first_tiles(nxt);
-      asm volatile("; MARK tiles_issued");
       PW_SEAM_STAMP(6);
     } else {
       // (defined on both paths: the registers of the previous item's rows are then not kept alive through the tile loop)
@@ -938,9 +933,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qraw[sb][ks] = wu32x4_t{0, 0, 0, 0};
     }
-    asm volatile("; MARK epilogue_begin");
     epilogue(cur);
-    asm volatile("; MARK epilogue_done");
 #ifdef MI355_PW_STAMP
     {
       unsigned long long st_exit;
@@ -952,7 +945,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #endif
     if (!more) break;
     zero_o_and_convert_q(nxt);
-    asm volatile("; MARK converted");
     cur = nxt;
   }
 }
