@@ -377,3 +377,24 @@ def test_harness_generator_reproduces_the_c4_composition():
     import bench
 
     assert bench.c4_lens() == (q, [a + c for a, c in zip(q, ctx)])
+
+
+def test_prefill_pw_kernel_keeps_the_compiler_out_of_the_accumulator_registers(tmp_path):
+    """prefill_pw_kernel's asm statements own all 256 accumulator registers (O, Q', the K tile). hipcc uses free
+    accumulator registers as spill space when it runs out of VGPRs - it would overwrite them silently - so the build
+    must show no compiler-emitted v_accvgpr_* and no scratch traffic outside the asm blocks (tools/isa_audit.py)."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "vllm-triton-backend_amd", "csrc", "prefill_pw.hip")
+    out = tmp_path / "prefill_pw.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                    src, "-o", str(out)], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py"), str(out), "prefill_pw_kernel"], capture_output=True, text=True, check=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("compiler accvgpr/scratch outside asm:")]
+    assert line and line[0].split(":")[1].split()[0] == "0", r.stdout[-2000:]
+    text = out.read_text()
+    assert "ScratchSize: 0" in text.split("prefill_pw_kernel")[-1] or ".private_segment_fixed_size: 0" in text

@@ -91,15 +91,22 @@ def test_replay_after_a_later_eager_call_has_grown_the_workspace():
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=s):
         step()
-    small = _lib._workspaces[(dev.type, dev.index)]
+    key = (dev.type, dev.index, s.cuda_stream)   # workspaces are per (device, stream)
+    small = _lib._workspaces[key]
     small_ptr, small_bytes = small.data_ptr(), small.numel()
     # an eager call with a much larger workspace: one 512-token chunk over 8k keys is key-split (partials for every split)
     big = orc.make_paged_inputs(44, [512], [8192], Hq, Hk, D, page, torch.bfloat16)
     bd = gpu_util.to_dev(big)
-    bout, kernel = gpu_util.run_unified(bd, big["scale"])
+    with torch.cuda.stream(s):
+        bout, kernel = gpu_util.run_unified(bd, big["scale"])
     assert kernel.endswith("_ksplit"), kernel
-    grown = _lib._workspaces[(dev.type, dev.index)]
+    grown = _lib._workspaces[key]
     assert grown.numel() > small_bytes and grown.data_ptr() != small_ptr
+    # another stream of the same device works in a buffer of its own (calls on two streams may overlap)
+    bout2, _ = gpu_util.run_unified(bd, big["scale"])
+    other = _lib._workspaces[(dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)]
+    assert other.data_ptr() != grown.data_ptr()
+    assert torch.equal(bout.view(torch.int16), bout2.view(torch.int16))
     assert any(t.data_ptr() == small_ptr for t in _lib._retired)          # the captured buffer is still owned
     junk = [torch.full((small_bytes,), 0xA5, dtype=torch.uint8, device=dev) for _ in range(4)]   # would land in it had it been freed
     # replay with new data

@@ -212,7 +212,9 @@ def current_stream_handle(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-# per-device scratch, grown on demand; replaces the per-call torch.empty at triton_unified_attention.py:950-971.
+# per-(device, stream) scratch, grown on demand; replaces the per-call torch.empty at triton_unified_attention.py:950-971.
+# Keyed by the stream as well: two streams of one device may run attention calls concurrently (micro-batch overlap),
+# and both would otherwise count arrivals and park partials in the same bytes.
 # A buffer that has been handed out is NEVER freed: a HIP graph captured earlier holds its raw address (arrival
 # counters, split partials) and replays into it long after a later, larger call made the binding move on to a bigger
 # buffer. Growth is geometric, so the retired buffers together stay below the size of the live one.
@@ -223,7 +225,7 @@ _retired: list = []
 def workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     if nbytes == 0:
         return None
-    key = (device.type, device.index)
+    key = (device.type, device.index, current_stream_handle(device))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
