@@ -212,7 +212,9 @@ def cpu_baseline(w, out_gpu):
 
 
 # device symbol behind each name mi355_last_kernel() reports for the benchmarked calls (profiles are keyed by symbol)
-KERNEL_SYMBOL = {"prefill_mfma": "prefill_pw_kernel", "decode_splitkv": "decode_splitkv_kernel"}
+# (symbol prefix, substring the instantiation must carry, substring it must not carry)
+KERNEL_SYMBOL = {"prefill_mfma": ("prefill_pw_kernel", "", "\0"), "decode_splitkv": ("decode_splitkv_kernel", "", "e4m3"),
+                 "decode_splitkv_fp8": ("decode_splitkv_kernel", "e4m3", "\0")}
 
 
 def kernel_source_digest():
@@ -241,8 +243,9 @@ def measured_traffic(kernel_name):
         doc = json.load(open(path))
         if doc.get("csrc_sha256") != kernel_source_digest():
             return None                                          # counters of an older kernel: stale, not reported
+        prefix, need, forbid = symbol
         for name, rec in doc["kernels"].items():
-            if name.startswith(symbol):
+            if name.startswith(prefix) and need in name and forbid not in name:
                 return rec["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass

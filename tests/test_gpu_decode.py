@@ -215,8 +215,10 @@ def test_decode_c5_full_size_properties():
     g = torch.Generator(device="cpu").manual_seed(5)
     pps = kv // page
     nb = B * pps + 5
-    k = ((torch.rand(nb, page, Hk, D, generator=g) * 2 - 1) / ks).to(torch.float8_e4m3fn)
-    v = ((torch.rand(nb, page, Hk, D, generator=g) * 2 - 1) / vs).to(torch.float8_e4m3fn)
+    # (the 2 x 0.5 GB of cache values are drawn on the device: a minute of host time otherwise)
+    gd = torch.Generator(device=dev).manual_seed(5)
+    k = ((torch.rand(nb, page, Hk, D, generator=gd, device=dev) * 2 - 1) / ks).to(torch.float8_e4m3fn).cpu()
+    v = ((torch.rand(nb, page, Hk, D, generator=gd, device=dev) * 2 - 1) / vs).to(torch.float8_e4m3fn).cpu()
     q = (torch.rand(B, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
     bt = torch.randperm(nb, generator=g)[: B * pps].to(torch.int32).view(B, pps)
     t = dict(q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=torch.arange(B + 1, dtype=torch.int32),

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collect the round's measurement evidence on a GPU box into <out> (default gpurun_out/prof_r02); the summaries are then
+# copied by hand into profiles/<round>/. Counter passes are separate runs with --kernel-trace only (pool rule).
+#   bash tools/collect_profiles.sh [out]
+set -u
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$REPO/gpurun_out/prof_r02}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+echo "== bench.py (default protocol)"
+python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench.py failed"
+tail -c 3000 $OUT/bench.json
+echo "== rocprofv3 --kernel-trace --stats of bench.py"
+rm -rf $OUT/stats && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --no-cpu-baseline --steps 100 --warmup 20 > $OUT/stats_bench.json 2> $OUT/stats.err
+f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats.csv; cat $OUT/bench_kernel_stats.csv | cut -c1-260; fi
+echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes)"
+python3 $REPO/tools/collect_traffic.py $OUT/traffic > $OUT/traffic.log 2>&1; tail -40 $OUT/traffic.log
+echo "== SQ counters, prefill_pw_kernel at C2"
+MI355_PREFILL=pw python3 $REPO/tools/pmc_collect.py $OUT/pmc_prefill prefill_pw_kernel -- python3 $REPO/tools/bench_prefill.py --iters 5 > $OUT/pmc_prefill.txt 2>&1; cat $OUT/pmc_prefill.txt
+echo "== SQ counters, fp8 decode at C5"
+python3 $REPO/tools/pmc_collect.py $OUT/pmc_decode_fp8 decode_splitkv_kernel -- python3 $REPO/tools/bench_decode.py --batch 16 --kv 32768 --hq 64 --hk 8 --kvdtype fp8 --iters 5 > $OUT/pmc_decode_fp8.txt 2>&1; cat $OUT/pmc_decode_fp8.txt
+echo "== in-kernel clock (diagnostic build)"
+if [ -f $REPO/tools/ab/pwstamp.so ]; then
+  MI355_LIB=$REPO/tools/ab/pwstamp.so MI355_PREFILL=pw python3 $REPO/tools/pw_clock.py 1 4096 > $OUT/pw_clock.log 2>&1
+  MI355_LIB=$REPO/tools/ab/pwstamp.so MI355_PREFILL=pw python3 $REPO/tools/pw_clock.py 1 16384 >> $OUT/pw_clock.log 2>&1
+  grep -v amdgpu.ids $OUT/pw_clock.log
+fi
+echo "== decode step latency in a graph"
+python3 $REPO/tools/decode_latency.py > $OUT/decode_latency.log 2>&1; tail -12 $OUT/decode_latency.log
+echo "== decode microbench C3 / C5"
+python3 $REPO/tools/bench_decode.py > $OUT/decode_c3.log 2>&1; tail -2 $OUT/decode_c3.log
+python3 $REPO/tools/bench_decode.py --batch 16 --kv 32768 --hq 64 --hk 8 --kvdtype fp8 > $OUT/decode_c5.log 2>&1; tail -2 $OUT/decode_c5.log
+rm -rf $OUT/stats/*/*.db $OUT/traffic/pmc_*/*/*.db $OUT/pmc_*/pass*/*/*.db 2>/dev/null
+du -sh $OUT
