@@ -33,6 +33,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace mi355 {
@@ -131,6 +134,12 @@ __device__ __forceinline__ float sum_over_lane_groups(float v) {
   v += lane_xor32(v);
   return v + lane_xor16(v);
 }
+
+// f(integral_constant<0>) ... f(integral_constant<N-1>), in order
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 // tiles one split of a row walks: the row's own tiles dealt evenly over the (host-fixed) number of splits
 __device__ __forceinline__ int split_tiles(int n_tiles, int num_splits) { return max(1, (n_tiles + num_splits - 1) / num_splits); }
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
   for (int c = 0; c < KSTEPS; ++c) asm volatile("" : "+v"(qf[c]));   // retire the Q loads before the loop (see prefill kernel)
 
-  auto tile_body = [&](int tile, u32x4_t (&KR)[2][NLD], u32x4_t (&VR)[2][NLD]) {
+  auto tile_body = [&](int tile, u32x4_t (&KR)[2][NLD], u32x4_t (&VR)[2][NLD]) __attribute__((always_inline)) {
     // ---- park the current tile's rows in LDS, then refill the registers with a later tile --------
     u32x4_t kcur[2][NLD];
 #pragma unroll
@@ -546,10 +555,17 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     }
   };
 
+  // (unrolled by construction, not by "#pragma unroll": when the tile body grew past the unroller's size limit - the
+  // fused cache write did that - the register sets kreg[u] / vreg[u] were indexed at run time and the fp8 loop, the
+  // only one with PF = 2, ran at half its rate: 16 x 32768 keys 370 us against 197)
+  if constexpr (PF == 1) {
+    for (int tile = t0; tile < t1; ++tile) tile_body(tile, kreg[0], vreg[0]);
+  } else
   for (int tile = t0; tile < t1; tile += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
+    static_for<PF>([&](auto U) __attribute__((always_inline)) {
+      constexpr int u = decltype(U)::value;
       if (tile + u < t1) tile_body(tile + u, kreg[u], vreg[u]);
+    });
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
