@@ -229,12 +229,12 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
-def measured_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes of THIS
-    command (tools/collect_traffic.py -> profiles/r02/traffic.json, the guide's gfx950 correction). Hardware counters
-    cannot be read from inside the timed run, so the number comes from that separate, committed pass and is reported
-    only when it was taken on the kernel symbol this run launched AND on the kernel sources this run was built from
-    (the pass records a digest of csrc/, see kernel_source_digest); otherwise null."""
+def measured_traffic(leg, kernel_name):
+    """HBM bytes per launch of the leg's dominant kernel: (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes of
+    THIS command with --legs <leg> (tools/collect_traffic.py -> profiles/r02/traffic.json, the guide's gfx950
+    correction). Hardware counters cannot be read from inside the timed run, so the number comes from that separate,
+    committed pass and is reported only when it was taken on the kernel symbol this run launched AND on the kernel sources
+    this run was built from (the pass records a digest of csrc/, see kernel_source_digest); otherwise null."""
     path = os.path.join(PROFILE_DIR, "traffic.json")
     symbol = KERNEL_SYMBOL.get(kernel_name.split("+")[0])
     if symbol is None or not os.path.exists(path):
@@ -244,7 +244,7 @@ def measured_traffic(kernel_name):
         if doc.get("csrc_sha256") != kernel_source_digest():
             return None                                          # counters of an older kernel: stale, not reported
         prefix, need, forbid = symbol
-        for name, rec in doc["kernels"].items():
+        for name, rec in doc["legs"].get(leg, {}).items():
             if name.startswith(prefix) and need in name and forbid not in name:
                 return rec["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
@@ -254,7 +254,7 @@ def measured_traffic(kernel_name):
 
 def roofline(bound, achieved, peak, unit, w, res, extra):
     r = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-         "traffic": measured_traffic(res["kernel"]), "kernel": res["kernel"], "kernel_us": round(res["per_launch"] * 1e6, 2)}
+         "traffic": measured_traffic(w["kind"], res["kernel"]), "kernel": res["kernel"], "kernel_us": round(res["per_launch"] * 1e6, 2)}
     r.update(extra)
     return r
 
@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--legs", default="prefill,decode,decode_fp8,mixed",
+                    help="comma list of the workloads to run (profiles of ONE kernel: --legs prefill | decode | decode_fp8 | mixed); "
+                         "the driver's default runs all four, the headline value is the prefill leg's")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # inside torch.distributed.run
@@ -299,8 +302,14 @@ def main():
         if distributed:
             dist.barrier()
 
+    legs = [x for x in args.legs.split(",") if x]
+    unknown = set(legs) - {"prefill", "decode", "decode_fp8", "mixed"}
+    if unknown or not legs:
+        raise SystemExit(f"bench.py: --legs takes prefill, decode, decode_fp8, mixed; got {args.legs!r}")
     results = {}
     for kind in ("prefill", "decode", "decode_fp8", "mixed"):
+        if kind not in legs:
+            continue
         w = make_workload(kind, device, seed=0 if kind == "mixed" else rank, rank=rank, world=world)
         call = build_call(w, device)
         call()
@@ -319,21 +328,23 @@ def main():
 
     if rank == 0:
         K = args.steps
-        pf, dc, d8, mx = results["prefill"], results["decode"], results["decode_fp8"], results["mixed"]
-        pf_val = pf["w"]["flops"] * n_gpus * K / pf["wall"] / 1e12
-        pf_ach = pf["w"]["flops"] / pf["per_launch"] / 1e12
-        line = {
-            "metric": "attn fwd TFLOPS (prefill) + KV GB/s (decode), Llama-3-8B GQA seq4k",
-            "value": round(pf_val, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup, "prewarm_s": PREWARM_S,
-            "ms_per_step": round(pf["wall"] / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C2 prefill: Llama-3-8B shape Hq32/Hk8/D128, 1 seq x 4096 tokens per GPU, causal, paged KV (16-token pages)",
-                       "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
-            "roofline": roofline("mfma", pf_ach, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", pf["w"], pf, {
-                "algorithmic_flops_per_launch": pf["w"]["flops"],
-                "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.0-2.2 GHz (in-kernel clock, "
-                        "tools/pw_clock.py, profiles/r02/pw_clock.log)"}),
-        }
+        pf, dc, d8, mx = results.get("prefill"), results.get("decode"), results.get("decode_fp8"), results.get("mixed")
+        line = {"legs": legs}
+        if pf:
+            pf_val = pf["w"]["flops"] * n_gpus * K / pf["wall"] / 1e12
+            pf_ach = pf["w"]["flops"] / pf["per_launch"] / 1e12
+            line = {
+                "metric": "attn fwd TFLOPS (prefill) + KV GB/s (decode), Llama-3-8B GQA seq4k",
+                "value": round(pf_val, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup, "prewarm_s": PREWARM_S,
+                "ms_per_step": round(pf["wall"] / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "C2 prefill: Llama-3-8B shape Hq32/Hk8/D128, 1 seq x 4096 tokens per GPU, causal, paged KV (16-token pages)",
+                           "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
+                "roofline": roofline("mfma", pf_ach, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", pf["w"], pf, {
+                    "algorithmic_flops_per_launch": pf["w"]["flops"],
+                    "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.0-2.2 GHz (in-kernel clock, "
+                            "tools/pw_clock.py, profiles/r02/pw_clock.log)"}),
+            }
 
         def decode_leg(res, label, cfg):
             val = res["w"]["bytes"] * n_gpus * K / res["wall"] / 1e9
@@ -345,20 +356,25 @@ def main():
                         "note": "peak = nominal HBM3E rate; a plain streaming read of 2 GiB reaches 7.15 TB/s on this chip with nt loads, "
                                 "6.2 TB/s with ordinary ones (profiles/r01/hbm_read_reference_point.log)"})}
 
-        line["decode"] = decode_leg(dc, "KV GB/s (paged decode)", "C3 decode: Hq32/Hk8/D128, batch 64 x kv_len 8192 per GPU, bf16, 16-token pages")
-        line["decode_fp8"] = decode_leg(d8, "KV GB/s (paged decode, fp8-e4m3 KV)",
-                                        "C5 decode: Llama-3-70B shape Hq64/Hk8/D128, batch 16 x kv_len 32768 per GPU, fp8-e4m3 KV, bf16 Q, 16-token pages")
-        mx_val = mx["w"]["flops"] * K / mx["wall"] / 1e12          # ONE global batch: strong scaling
-        line["mixed"] = {"metric": "attn fwd TFLOPS (mixed chunked-prefill + decode batch)", "value": round(mx_val, 2), "unit": "TFLOP/s",
-                         "ms_per_step": round(mx["wall"] / K * 1e3, 4), "scaling": "strong",
-                         "kv_gbs": round(mx["w"]["bytes"] * K / mx["wall"] / 1e9, 1),
-                         "config": {"workload": "C4: Granite-3.1-8B shape Hq32/Hk8/D128, 64 sequences (32 decodes ctx 4095, 16 partial prefills 2048+2048, "
-                                                "16 full prefills 4096), 98336 query tokens, ONE batch dealt to the ranks by parallel.shard_batch",
-                                    "global_batch": 64, "parallelism": f"batch-sharded x{n_gpus} (LPT by attention cost), no collective",
-                                    "rank0_share": mx["w"]["local"], "kernel": mx["kernel"]}}
+        if dc:
+            line["decode"] = decode_leg(dc, "KV GB/s (paged decode)", "C3 decode: Hq32/Hk8/D128, batch 64 x kv_len 8192 per GPU, bf16, 16-token pages")
+        if d8:
+            line["decode_fp8"] = decode_leg(d8, "KV GB/s (paged decode, fp8-e4m3 KV)",
+                                            "C5 decode: Llama-3-70B shape Hq64/Hk8/D128, batch 16 x kv_len 32768 per GPU, fp8-e4m3 KV, bf16 Q, 16-token pages")
+        if mx:
+            mx_val = mx["w"]["flops"] * K / mx["wall"] / 1e12          # ONE global batch: strong scaling
+            line["mixed"] = {"metric": "attn fwd TFLOPS (mixed chunked-prefill + decode batch)", "value": round(mx_val, 2), "unit": "TFLOP/s",
+                             "ms_per_step": round(mx["wall"] / K * 1e3, 4), "scaling": "strong",
+                             "kv_gbs": round(mx["w"]["bytes"] * K / mx["wall"] / 1e9, 1),
+                             "config": {"workload": "C4: Granite-3.1-8B shape Hq32/Hk8/D128, 64 sequences (32 decodes ctx 4095, 16 partial prefills 2048+2048, "
+                                                    "16 full prefills 4096), 98336 query tokens, ONE batch dealt to the ranks by parallel.shard_batch",
+                                        "global_batch": 64, "parallelism": f"batch-sharded x{n_gpus} (LPT by attention cost), no collective",
+                                        "rank0_share": mx["w"]["local"], "kernel": mx["kernel"]}}
         if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pf["w"], pf["w"]["out"])
-            line["decode"]["cpu_baseline"] = cpu_baseline(dc["w"], dc["w"]["out"])
+            if pf:
+                line["cpu_baseline"] = cpu_baseline(pf["w"], pf["w"]["out"])
+            if dc:
+                line["decode"]["cpu_baseline"] = cpu_baseline(dc["w"], dc["w"]["out"])
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

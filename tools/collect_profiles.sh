@@ -7,19 +7,24 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$REPO/gpurun_out/prof_r02}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes)"
+python3 $REPO/tools/collect_traffic.py $OUT/traffic > $OUT/traffic.log 2>&1; tail -60 $OUT/traffic.log
+mkdir -p $REPO/profiles/r02 && cp $OUT/traffic/traffic.json $REPO/profiles/r02/traffic.json   # bench.py reports it when it matches the built sources
 echo "== bench.py (default protocol)"
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench.py failed"
 tail -c 3000 $OUT/bench.json
-echo "== rocprofv3 --kernel-trace --stats of bench.py"
-rm -rf $OUT/stats && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --no-cpu-baseline --steps 100 --warmup 20 > $OUT/stats_bench.json 2> $OUT/stats.err
-f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
-if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats.csv; cat $OUT/bench_kernel_stats.csv | cut -c1-260; fi
-echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes)"
-python3 $REPO/tools/collect_traffic.py $OUT/traffic > $OUT/traffic.log 2>&1; tail -40 $OUT/traffic.log
+echo "== rocprofv3 --kernel-trace --stats of bench.py, one leg per run (a kernel symbol serves several legs)"
+for leg in prefill decode decode_fp8 mixed; do
+  rm -rf $OUT/stats_$leg && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$leg -- python3 $REPO/bench.py --no-cpu-baseline --legs $leg > $OUT/stats_bench_$leg.json 2> $OUT/stats_$leg.err
+  f=$(find $OUT/stats_$leg -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats_$leg.csv; cut -c1-230 $OUT/bench_kernel_stats_$leg.csv; fi
+  grep -o '"kernel_us": [0-9.]*' $OUT/stats_bench_$leg.json | head -2
+  rm -rf $OUT/stats_$leg
+done
 echo "== SQ counters, prefill_pw_kernel at C2"
-MI355_PREFILL=pw python3 $REPO/tools/pmc_collect.py $OUT/pmc_prefill prefill_pw_kernel -- python3 $REPO/tools/bench_prefill.py --iters 5 > $OUT/pmc_prefill.txt 2>&1; cat $OUT/pmc_prefill.txt
+PMC_PASSES=0,1,2,3,4 MI355_PREFILL=pw python3 $REPO/tools/pmc_collect.py $OUT/pmc_prefill prefill_pw_kernel -- python3 $REPO/tools/bench_prefill.py --iters 5 > $OUT/pmc_prefill.txt 2>&1; cat $OUT/pmc_prefill.txt
 echo "== SQ counters, fp8 decode at C5"
-python3 $REPO/tools/pmc_collect.py $OUT/pmc_decode_fp8 decode_splitkv_kernel -- python3 $REPO/tools/bench_decode.py --batch 16 --kv 32768 --hq 64 --hk 8 --kvdtype fp8 --iters 5 > $OUT/pmc_decode_fp8.txt 2>&1; cat $OUT/pmc_decode_fp8.txt
+PMC_PASSES=0,1,2,3,4 python3 $REPO/tools/pmc_collect.py $OUT/pmc_decode_fp8 decode_splitkv_kernel -- python3 $REPO/tools/bench_decode.py --batch 16 --kv 32768 --hq 64 --hk 8 --kvdtype fp8 --iters 5 > $OUT/pmc_decode_fp8.txt 2>&1; cat $OUT/pmc_decode_fp8.txt
 echo "== in-kernel clock (diagnostic build)"
 if [ -f $REPO/tools/ab/pwstamp.so ]; then
   MI355_LIB=$REPO/tools/ab/pwstamp.so MI355_PREFILL=pw python3 $REPO/tools/pw_clock.py 1 4096 > $OUT/pw_clock.log 2>&1
@@ -31,5 +36,5 @@ python3 $REPO/tools/decode_latency.py > $OUT/decode_latency.log 2>&1; tail -12 $
 echo "== decode microbench C3 / C5"
 python3 $REPO/tools/bench_decode.py > $OUT/decode_c3.log 2>&1; tail -2 $OUT/decode_c3.log
 python3 $REPO/tools/bench_decode.py --batch 16 --kv 32768 --hq 64 --hk 8 --kvdtype fp8 > $OUT/decode_c5.log 2>&1; tail -2 $OUT/decode_c5.log
-rm -rf $OUT/stats/*/*.db $OUT/traffic/pmc_*/*/*.db $OUT/pmc_*/pass*/*/*.db 2>/dev/null
+rm -rf $OUT/traffic/pmc_* $OUT/pmc_prefill/pass* $OUT/pmc_decode_fp8/pass* 2>/dev/null
 du -sh $OUT
