@@ -191,6 +191,37 @@ def dense_attention_fp64(
     return (out, lse) if return_lse else out
 
 
+def prefill_flash_attention_oracle(q, k, v, cu_seqlens_q, cu_seqlens_k, sm_scale, block_n: int = 16):
+    """The reference's non-paged variable-length prefill op in its causal form (attn_fwd via
+    triton_wrapper_forward_prefill, LIB/kernels/triton_flash_attention.py:1326-1484): per sequence and query head, keys
+    in blocks of BLOCK_N with an online softmax in f32, the causal mask aligned bottom-right (query t of a sequence
+    sees keys j <= t + seqlen_k - seqlen_q, :954-960), P rounded to V's type before P.V, grouped-query heads
+    (k head = q head // (HQ // HK), :1007). q [total_q, Hq, D]; k, v [total_k, Hk, D]. Returns f32 [total_q, Hq, D]."""
+    T, Hq, D = q.shape
+    G = Hq // k.shape[1]
+    out = torch.zeros(T, Hq, D, dtype=torch.float32)
+    cq, ck = [int(x) for x in cu_seqlens_q], [int(x) for x in cu_seqlens_k]
+    for i in range(len(cq) - 1):
+        q0, q1, k0, k1 = cq[i], cq[i + 1], ck[i], ck[i + 1]
+        lq, lk = q1 - q0, k1 - k0
+        if lq <= 0:
+            continue
+        last = torch.arange(lq) + (lk - lq)                         # last visible key of each query row
+        for hq in range(Hq):
+            h = hq // G
+            Q = q[q0:q1, hq].to(torch.float32)
+            M = torch.full((lq,), float("-inf"))
+            L = torch.zeros(lq)
+            acc = torch.zeros(lq, D)
+            for j0 in range(0, lk, block_n):
+                j1 = min(j0 + block_n, lk)
+                S = (Q @ k[k0 + j0:k0 + j1, h].to(torch.float32).T) * sm_scale
+                S = S.masked_fill(torch.arange(j0, j1)[None, :] > last[:, None], float("-inf"))
+                M, L, acc = _tile_update(S, v[k0 + j0:k0 + j1, h].to(torch.float32), M, L, acc, v.dtype)
+            out[q0:q1, hq] = torch.where(L[:, None] > 0, acc / L[:, None], torch.zeros_like(acc))
+    return out
+
+
 def reshape_and_cache_flash_oracle(key, value, key_cache, value_cache, slot_mapping, k_scale=1.0, v_scale=1.0):
     """In-place scatter (scripts/vllm_utils.py:377-401); slot < 0 = padding (triton_attn.py:149-151);
     fp8 caches store saturating fp8(x / scale)."""

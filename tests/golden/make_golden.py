@@ -49,10 +49,10 @@ def install_stubs():
             self.fn = fn
 
         def __getitem__(self, grid):
-            def run(**kwargs):
+            def run(*args, **kwargs):
                 kwargs.update(TILE)
                 g = grid(kwargs) if callable(grid) else grid
-                return self.fn[g](**kwargs)
+                return self.fn[g](*args, **kwargs)
             return run
 
     dj.jitcache = lambda **kw: (lambda fn: fn)
@@ -238,6 +238,41 @@ def cache_cases():
         save(name, dict(kind="cache_write"), key=key, value=value, slot_mapping=slots, k_cache_out=kc, v_cache_out=vc)
 
 
+def flash_cases():
+    """`prefill_flash_attention` = triton_wrapper_forward_prefill (triton_flash_attention.py:1326-1484, exported at
+    kernels/__init__.py:65-67): the non-paged variable-length prefill op, causal with the bottom-right aligned mask.
+    Its autotuner is triton_dejavu's (stubbed: fixed tile) and its wrapper asks the device for its name and CU count
+    (stand-in values: there is no GPU in the build container); the kernel itself is the reference's, run by the interpreter."""
+    global TILE
+    saved = TILE
+    TILE = {"BLOCK_M": 16, "BLOCK_N": 16, "PRE_LOAD_V": False, "GRID_CU_MULTIP": 2}
+
+    class _Props:
+        multi_processor_count = 4
+
+    torch.cuda.get_device_properties = lambda *a, **k: _Props()
+    fa = load_by_path("ibm_triton_lib.kernels.triton_flash_attention", f"{LIBK}/triton_flash_attention.py")
+    try:
+        for name, dtype, hq, hk, d, q_lens, k_lens, seed in (
+            ("flash_varlen_causal_gqa2_d64_fp32", torch.float32, 4, 2, 64, [5, 17, 1, 33], [9, 17, 33, 40], 61),
+            ("flash_varlen_causal_gqa4_d128_fp16", torch.float16, 8, 2, 128, [40, 1, 19, 70], [70, 45, 19, 70], 62),
+            ("flash_varlen_causal_mha_d64_fp16", torch.float16, 4, 4, 64, [33, 3, 16], [33, 35, 64], 63),
+        ):
+            g = torch.Generator().manual_seed(seed)
+            cu_q = torch.tensor([0] + torch.tensor(q_lens).cumsum(0).tolist(), dtype=torch.int32)
+            cu_k = torch.tensor([0] + torch.tensor(k_lens).cumsum(0).tolist(), dtype=torch.int32)
+            q = (torch.rand(int(cu_q[-1]), hq, d, generator=g) * 2 - 1).to(dtype)
+            k = (torch.rand(int(cu_k[-1]), hk, d, generator=g) * 2 - 1).to(dtype)
+            v = (torch.rand(int(cu_k[-1]), hk, d, generator=g) * 2 - 1).to(dtype)
+            scale = 1.0 / (d ** 0.5)
+            out = fa.triton_wrapper_forward_prefill(q, k, v, max(q_lens), max(k_lens), cu_q, cu_k, causal=True, sm_scale=scale)
+            out = out[0] if isinstance(out, tuple) else out
+            save(name, dict(kind="flash_varlen", scale=scale, max_seqlen_q=max(q_lens), max_seqlen_k=max(k_lens), causal=True),
+                 q=q, k=k, v=v, cu_seqlens_q=cu_q, cu_seqlens_k=cu_k, out=out)
+    finally:
+        TILE = saved
+
+
 def main():
     only = sys.argv[1:]            # optional name prefixes: regenerate just those fixtures
     if only:
@@ -312,6 +347,7 @@ def main():
 
     legacy_cases()
     cache_cases()
+    flash_cases()
 
 
 if __name__ == "__main__":

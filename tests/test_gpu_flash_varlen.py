@@ -72,3 +72,24 @@ def test_varlen_unsupported_modes_raise():
         prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=True, bias=torch.zeros(1, device=dev))
     with pytest.raises(NotImplementedError):
         prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=True, do_not_return_softmax_encodings=False)
+
+
+import golden_io  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_io.names("flash_varlen"))
+def test_varlen_prefill_against_the_reference_kernels_outputs(name):
+    """Fixtures written by the reference's own attn_fwd (triton_wrapper_forward_prefill under the Triton interpreter,
+    tests/golden/make_golden.py::flash_cases): fp32 on the shape-agnostic kernel, fp16 on the MFMA prefill kernels."""
+    from mi355_attn import _lib
+    from mi355_attn.kernels import prefill_flash_attention
+
+    meta, t = golden_io.load(name)
+    dev = torch.device("cuda:0")
+    out = prefill_flash_attention(t["q"].to(dev), t["k"].to(dev), t["v"].to(dev), meta["max_seqlen_q"], meta["max_seqlen_k"],
+                                  t["cu_seqlens_q"].to(dev), t["cu_seqlens_k"].to(dev), causal=True, sm_scale=meta["scale"])
+    torch.cuda.synchronize()
+    if t["q"].dtype == torch.float16:
+        assert _lib.last_kernel().startswith("prefill_mfma"), _lib.last_kernel()
+    atol, rtol = golden_io.tolerance(t["q"].dtype)
+    torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol)

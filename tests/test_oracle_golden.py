@@ -83,3 +83,13 @@ def test_cache_write_oracle_skips_negative_slots_and_quantises():
     assert torch.count_nonzero(kc.float()[0, 1]) == 0  # untouched
     assert kc.float().abs().max() <= 448.0             # saturated, never inf/nan
     torch.testing.assert_close(vc.float()[1, 1], (value[3] / 2.0).to(torch.float8_e4m3fn).float())
+
+
+@pytest.mark.parametrize("name", golden_io.names("flash_varlen"))
+def test_prefill_flash_attention_oracle(name):
+    """The oracle's restatement of the reference's non-paged varlen prefill op against the outputs of the reference's own
+    attn_fwd kernel (run under the Triton interpreter by tests/golden/make_golden.py::flash_cases)."""
+    meta, t = golden_io.load(name)
+    out = orc.prefill_flash_attention_oracle(t["q"], t["k"], t["v"], t["cu_seqlens_q"], t["cu_seqlens_k"], meta["scale"])
+    atol, rtol = golden_io.tolerance(t["q"].dtype)
+    torch.testing.assert_close(out, t["out"].float(), atol=atol, rtol=rtol)
