@@ -979,7 +979,10 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   a.lse_split_stride = lse_split_stride;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
-  a.num_qblocks = p.num_tokens / a.block_q + p.num_seqs;   // static upper bound, as the reference (:886-889,:935-943)
+  // static upper bound, as the reference (:886-889,:935-943); with ONE sequence the bound is exact without the "+ 1" (its
+  // Q blocks are those of num_tokens), and an empty item at the head of the list would shift the boustrophedon deal by one:
+  // slot 0 would end up with 3 tiles and every other slot with 67 instead of 65 (1 x 4096)
+  a.num_qblocks = p.num_seqs == 1 ? (p.num_tokens + a.block_q - 1) / a.block_q : p.num_tokens / a.block_q + p.num_seqs;
   // one workgroup per CU (it holds exactly one), in whole sets of num_kv_heads; fewer when there are fewer items
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
