@@ -127,10 +127,14 @@ def test_workspace_bytes_of_the_prefill_paths(lib):
     buf = np.zeros(64, dtype=np.uint8)
     addr = (buf.ctypes.data + 15) & ~15
     counters = 256 << 10
-    # C2: one 4096-token prefill fills the chip by itself -> no scratch
+    # C2: one 4096-token prefill fills the chip by itself -> no partials, only the counter region (prefill_pw_kernel
+    # draws its work items from a per-head ticket counter there)
     p = _c3_like_params(lib, addr)
     p.num_tokens, p.num_seqs, p.max_seqlen_q, p.max_seqlen_k = 4096, 1, 4096, 4096
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters
+    p.q_dtype = p.kv_dtype = lib.dtype_code(torch.float16)           # f16 stays on the 8-wave kernel: no scratch at all
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+    p.q_dtype = p.kv_dtype = lib.dtype_code(torch.bfloat16)
     # a 512-token chunk against 8192 keys: (512/32 + 1) * 8 = 136 workgroups -> 4 key splits of partial out (bf16) + lse (f32)
     p.num_tokens, p.max_seqlen_q, p.max_seqlen_k = 512, 512, 8192
     n = h.mi355_attn_workspace_bytes(C.byref(p))

@@ -55,12 +55,17 @@ def test_prefill_64_rows_per_wave_kernel_on_small_shapes():
 
 def test_prefill_64_rows_per_wave_kernel_walking_many_items_per_workgroup():
     """Two workgroups per KV head (MI355_PW_SLOTS): every workgroup walks many work items - several sequences, empty Q
-    blocks, key splits - with the next item's loads in flight over the current item's output."""
+    blocks, key splits - with the next item's loads in flight over the current item's output; batches of several
+    sequences draw their items from the ticket counters in the workspace (empty items included: the retry path)."""
     _run({"MI355_PREFILL": "pw", "MI355_PW_SLOTS": "2"},
          ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
           "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_prefill.py::test_prefill_key_split_with_rows_outside_the_fixed_reference_range",
           "tests/test_gpu_prefill_ksplit.py", "tests/test_gpu_fuzz.py"],
          keyword="(mixed and 128 and dtype0) or page_sizes or strided or outside or ksplit or key_split or agree")
+    # the same walk with the static deal for every batch (several sequences normally draw their items from ticket counters)
+    _run({"MI355_PREFILL": "pw", "MI355_PW_SLOTS": "2", "MI355_PW_TICKETS": "0"},
+         ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill_ksplit.py", "tests/test_gpu_fuzz.py"],
+         keyword="(mixed and 128 and dtype0) or ksplit or key_split or agree")
     _run({"MI355_PREFILL": "pw", "MI355_PW_SLOTS": "3", "MI355_PREFILL_KEY_SPLITS": "1"},
          ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties",
           "tests/test_gpu_prefill.py::test_prefill_rows_whose_scores_leave_the_fixed_reference_range"],

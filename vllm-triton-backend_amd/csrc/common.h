@@ -306,7 +306,8 @@ int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStre
 bool prefill_supported(const mi355_attn_params& p);
 // key-split launch context (prefill_mfma.hip: plan_key_splits / launch_prefill_ws); nullptr = one workgroup walks all keys
 struct KeySplitCtx { int splits, tiles_per_split; bool wide; int64_t out_split_stride, lse_split_stride; };
-int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks = nullptr);
+// counters: the zero-filled head of the caller's workspace (>= 256 KiB) or null
+int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks = nullptr, int* counters = nullptr);
 size_t prefill_workspace_bytes(const mi355_attn_params& p);                                   // key-split partials, 0 if none
 int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream);
 const char* mi355_last_kernel_name();
@@ -316,7 +317,8 @@ size_t repack_scratch_bytes(const mi355_attn_params& p, size_t head);
 mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, size_t head);
 int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool skip_single, hipStream_t stream);
 bool prefill_pw_applicable(const mi355_attn_params& p);    // beyond prefill_supported()
-int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, hipStream_t stream);
+int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream);
+bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks);   // launch_prefill would hand this call to prefill_pw_kernel
 
 inline int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return MI355_OK;

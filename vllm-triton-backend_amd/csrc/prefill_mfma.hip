@@ -1176,7 +1176,8 @@ static KeySplitLayout key_split_layout(const mi355_attn_params& p, int splits) {
 size_t prefill_workspace_bytes(const mi355_attn_params& p) {
   if (!prefill_supported(p)) return 0;
   const int splits = plan_key_splits(p).splits;
-  return splits > 1 ? key_split_layout(p, splits).total : 0;
+  if (splits > 1) return key_split_layout(p, splits).total;
+  return prefill_pw_selected(p, nullptr) ? kWsCounterBytes : 0;     // the ticket counters of prefill_pw_kernel's item deal
 }
 
 struct MergeArgs {
@@ -1300,7 +1301,18 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, co
   return rc;
 }
 
-int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
+// Whether launch_prefill hands the call to prefill_pw_kernel (prefill_pw.hip): bf16, D = 128, plain, 16-bit cache, and
+// either >= 2048 keys or a key-split plan on the wide kernel. MI355_PREFILL=pw | d8 | d4 | v1 pins a kernel (measurements).
+bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
+  static const char* variant = getenv("MI355_PREFILL");
+  const bool v1 = variant && variant[0] == 'v' && variant[1] == '1';
+  if (!prefill_supported(p) || !prefill_pw_applicable(p) || v1 || (variant && variant[0] != 'p')) return false;
+  const bool pinned = variant && variant[0] == 'p';
+  const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= 2048;
+  return pinned ? (!ks || ks->wide) : use_pw;
+}
+
+int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks, int* counters) {
   if (!prefill_supported(p)) {
     set_error("prefill kernel does not support this configuration");
     return MI355_ERR_UNSUPPORTED;
@@ -1315,12 +1327,8 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
   // 1 x 4096 1153 | 1068 | 933, 16 x 4096 1129 | 1032 | 978, 1 x 16384 1325 | 1188 | 1095, 1 x 3072 996 | 915 | 924,
   // 2 x 2048 962 | 920 | 849, 1 x 2048 670 | 624 | 674; below that a workgroup's prologue and epilogue (~9 us at one
   // workgroup per CU) outweigh its few tiles: 4 x 1024 628 | 636 | 663, 8 x 512 419 | 451 | 453, 1 x 1024 274 | 273 | 329).
-  if (prefill_pw_applicable(p) && !v1 && (!variant || variant[0] == 'p')) {
-    const bool pinned = variant && variant[0] == 'p';
-    const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= 2048;
-    if (pinned ? (!ks || ks->wide) : use_pw)
-      return launch_prefill_pw(p, ks ? ks->splits : 1, ks ? ks->out_split_stride : 0, ks ? ks->lse_split_stride : 0, stream);
-  }
+  if (prefill_pw_selected(p, ks))
+    return launch_prefill_pw(p, ks ? ks->splits : 1, ks ? ks->out_split_stride : 0, ks ? ks->lse_split_stride : 0, counters, stream);
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped
@@ -1372,7 +1380,8 @@ int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hip
     return MI355_ERR_UNSUPPORTED;
   }
   const KeySplitPlan plan = plan_key_splits(p);
-  if (plan.splits <= 1) return launch_prefill(p, stream);
+  int* const counters = (ws && ws_bytes >= kWsCounterBytes) ? (int*)ws : nullptr;   // zero between calls (decode_splitkv.hip)
+  if (plan.splits <= 1) return launch_prefill(p, stream, nullptr, counters);
   const KeySplitLayout lay = key_split_layout(p, plan.splits);
   if (!ws || ws_bytes < lay.total) {
     set_error("workspace of %zu bytes is smaller than the %zu the key-split prefill needs (mi355_attn_workspace_bytes)", ws_bytes, lay.total);
@@ -1385,7 +1394,7 @@ int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hip
   pp.lse = (float*)((char*)ws + lay.lse_off);
   pp.lse_stride_token = p.num_q_heads;
   const KeySplitCtx ks = {plan.splits, plan.tiles_per_split, plan.wide, lay.out_split_stride, lay.lse_split_stride};
-  int rc = launch_prefill(pp, stream, &ks);
+  int rc = launch_prefill(pp, stream, &ks, counters);
   if (rc != MI355_OK) return rc;
   MergeArgs m;
   m.p = p;

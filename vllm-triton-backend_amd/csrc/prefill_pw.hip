@@ -68,7 +68,9 @@ constexpr int kAK = 192;   // K[kb][ks]   : kAK + 32 kb + 4 ks   (4 registers)
 // outside the rings because the next Q block's first tiles are already landing in them while O leaves.
 constexpr int kSlotBytes = 16384, kLdsK = 0, kLdsV = 3 * kSlotBytes, kLdsO = 6 * kSlotBytes;
 constexpr int kPwORS = 256 + 16;     // padded row stride of the parked O rows
-constexpr int kPwLds = kLdsO + 4 * 32 * kPwORS;
+constexpr int kLdsT = kLdsO + 4 * 32 * kPwORS;   // two ints: the item index wave 0 drew, published to the workgroup
+constexpr int kPwLds = kLdsT + 16;
+constexpr size_t kPwCounterBytes = (size_t)256 << 10;   // the counter region at the head of every workspace (include/mi355_attn.h)
 
 struct PwArgs {
   mi355_attn_params p;
@@ -78,6 +80,7 @@ struct PwArgs {
   int key_splits;  // a work item (Q block, KV head, s) attends the s-th even share of its Q block's key tiles (prefill_mfma.hip)
   int num_qblocks; // static upper bound of the Q blocks of the batch (num_tokens / block_q + num_seqs)
   int g_shift, bq_shift;   // log2 of group / block_q when they are powers of two, else -1 (divisions become shifts)
+  int* tickets;    // [2 * num_kv_heads] zero on entry, zero on exit (head of the caller's workspace), or null: static deal
   int slots;       // workgroups per KV head: the grid is slots * num_kv_heads workgroups, each walking several items
   int64_t out_split_stride, lse_split_stride;
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   struct SeamArgs {                    // read in one batch of scalar loads at the start of an item's set-up
     const uint16_t* q; uint16_t* out; float* lse;
     const int32_t *cu, *sk, *bt;
+    int* tickets;
     int q_st, q_sh, out_st, out_sh;    // elements; the host admits [0, 2^22)
     int64_t lse_st, bt_stride, out_split_stride, lse_split_stride;
     int num_seqs, key_splits, num_qblocks, slots, G, BQ, g_shift, bq_shift, page_shift, skip_decodes, only_decodes, num_kv_heads;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     kp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
     sa.q = (const uint16_t*)kp->p.q; sa.out = (uint16_t*)kp->p.out; sa.lse = kp->p.lse;
-    sa.cu = kp->p.cu_seqlens_q; sa.sk = kp->p.seqused_k; sa.bt = kp->p.block_table;
+    sa.cu = kp->p.cu_seqlens_q; sa.sk = kp->p.seqused_k; sa.bt = kp->p.block_table; sa.tickets = kp->tickets;
     sa.q_st = (int)kp->p.q_stride_token; sa.q_sh = (int)kp->p.q_stride_head; sa.out_st = (int)kp->p.out_stride_token; sa.out_sh = (int)kp->p.out_stride_head;
     sa.lse_st = kp->p.lse_stride_token; sa.bt_stride = kp->p.block_table_stride;
     sa.out_split_stride = kp->out_split_stride; sa.lse_split_stride = kp->lse_split_stride;
@@ -301,12 +305,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // ballot. With a single sequence the first block-table entries ride the same trip, speculatively (checked when the
   // first tiles are requested).
   int spec_pg[4] = {0, 0, 0, 0}, spec_off[4] = {0, 0, 0, 0};
-  auto setup = [&](Item& I, int& round) -> bool {       // the next non-empty item of this workgroup; false: none left
-    while (true) {
-      const int items_per_head = sa.num_qblocks * sa.key_splits;
-      const int idx = round * sa.slots + ((round & 1) ? sa.slots - 1 - slot : slot);
-      if (idx >= items_per_head) return false;
-      ++round;
+  auto setup_idx = [&](Item& I, int idx) -> bool {       // item idx of this KV head's list; false: it is empty
+    {
       const int BQ = sa.BQ;
       const int qb_rank = sa.key_splits == 1 ? idx : idx / sa.key_splits;
       const int qblock = sa.num_qblocks - 1 - qb_rank;      // heaviest first
@@ -343,9 +343,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         q_len = sa.cu[sq + 1] - q_start;
         seq_len = sa.sk[sq];
       }
-      if (seq < 0) continue;
+      if (seq < 0) return false;
       const int qb_local = qblock - (div_bq(q_start) + seq);
-      if (qb_local * BQ >= q_len || (sa.skip_decodes && q_len == 1) || (sa.only_decodes && q_len != 1)) continue;
+      if (qb_local * BQ >= q_len || (sa.skip_decodes && q_len == 1) || (sa.only_decodes && q_len != 1)) return false;
       I.seq = seq; I.q_start = q_start; I.q_len = q_len; I.seq_len = seq_len;
       I.ctx_len = seq_len - q_len;
       I.tok0 = qb_local * BQ;
@@ -374,6 +374,53 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         I.bt64 = ((uint64_t)hi << 32) | lo;
       }
       return true;
+    }
+  };
+
+  // ---- which item next -----------------------------------------------------------------------------------
+  // Static deal (no ticket counters): round j hands item j S + s to slot s for even j, j S + S-1-s for odd j.
+  // Dynamic deal: the first item of slot s is item s; every further one is S + a ticket drawn from a per-head counter in
+  // the caller's workspace (relaxed agent-scope fetch_add by wave 0, lane 0). The ticket is drawn LATE - when the item's
+  // steady tiles are done and only its last few remain (a draw at the start of an item hands out the second items at
+  // time zero in arrival order, i.e. a random static deal: 146 us instead of 119 at 1 x 4096) - early enough to be back
+  // at the seam, and handed to the other waves through two alternating LDS words behind the barrier the seam has
+  // anyway. CUs that run slower (the clock differs by up to 15 % between them under the power limit) simply take fewer
+  // items. Every workgroup ends by drawing one ticket past the list; the last one to finish zeroes the counters.
+  const bool dynamic = sa.tickets != nullptr;
+  int round = 0;               // static deal
+  int ticket_v = 0;            // dynamic deal: wave 0 / lane 0's draw, in flight or landed
+  int attempt = 0;             // publications so far (workgroup-uniform)
+  volatile int* const lds_idx = (volatile int*)(smem + kLdsT);
+  auto draw = [&]() __attribute__((always_inline)) {
+    if (wave == 0 && lane_o == 0) ticket_v = __hip_atomic_fetch_add(sa.tickets + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto publish = [&]() __attribute__((always_inline)) {        // (the compiler waits for the draw here: it landed long ago)
+    if (wave == 0 && lane_o == 0) lds_idx[attempt & 1] = sa.slots + ticket_v;
+  };
+  auto read_published = [&]() __attribute__((always_inline)) {
+    const int v = lds_idx[attempt & 1];
+    ++attempt;
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  // the next non-empty item; `idx` = an index already in hand (the slot's first item, or one read behind the seam's
+  // barrier) when have_idx. false: the list is exhausted
+  auto acquire = [&](Item& I, int idx, bool have_idx) -> bool {
+    const int items_per_head = sa.num_qblocks * sa.key_splits;
+    while (true) {
+      if (!have_idx) {
+        if (dynamic) {             // (an empty item: the next ticket is needed at once)
+          draw();
+          publish();
+          __syncthreads();
+          idx = read_published();
+        } else {
+          idx = round * sa.slots + ((round & 1) ? sa.slots - 1 - slot : slot);
+          ++round;
+        }
+      }
+      have_idx = false;
+      if (idx >= items_per_head) return false;
+      if (setup_idx(I, idx)) return true;
     }
   };
 
@@ -554,12 +601,21 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
 
   Item cur;
-  int round = 0;
 #ifdef MI355_PW_STAMP
   unsigned long long st_entry;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry) :: "memory");
 #endif
-  if (!setup(cur, round)) return;
+  // counters back to zero: the last workgroup of this KV head to get here has seen every other one's final draw land
+  auto finish = [&]() __attribute__((always_inline)) {
+    if (dynamic && wave == 0 && lane_o == 0) {
+      int* const done = sa.tickets + sa.num_kv_heads + head;
+      if (__hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sa.slots - 1) {
+        __hip_atomic_store(sa.tickets + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (!acquire(cur, dynamic ? slot : 0, dynamic)) { finish(); return; }
   issue_q(cur);
   issue_first_tiles(cur);
   zero_o_and_convert_q(cur);
@@ -829,6 +885,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   while (true) {
     reset_state();
+    bool drawn = false;
     const int tile_lo = cur.tile_lo, tile_hi = cur.tile_hi;
     // (every load behind the item - its query rows and its first tiles - has landed: zero_o_and_convert_q waited)
     if (tile_hi > tile_lo) {
@@ -855,6 +912,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         iteration(ic<2>{}, ic<1>{}, t + 2);
         t += 3;
       }
+      if (dynamic) { draw(); drawn = true; }      // the next item's ticket: a few tiles before this item ends
       // The workgroup walks tile_hi tiles, but a wave's 64 rows see no key past their last row's limit: the tiles from
       // own_hi on are wholly masked for it (G < 4: up to three of a Q block's last four). It computes nothing for
       // them - it only keeps staging its share of the K/V tiles the other waves still need.
@@ -917,10 +975,14 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     PW_SEAM_STAMP(3);
     refresh_lane();
     Item nxt;
-    const bool more = setup(nxt, round);
-    PW_SEAM_STAMP(4);
+    if (dynamic) {
+      if (!drawn) draw();          // (an item without tiles)
+      publish();
+    }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA results readable; no LDS-DMA of this item in flight
     __syncthreads();                                                          // every wave is done with the rings
+    PW_SEAM_STAMP(4);
+    const bool more = dynamic ? acquire(nxt, read_published(), true) : acquire(nxt, 0, false);
     PW_SEAM_STAMP(5);
     if (more) {
       issue_q(nxt);
@@ -947,6 +1009,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     zero_o_and_convert_q(nxt);
     cur = nxt;
   }
+  finish();
 }
 
 
@@ -966,7 +1029,7 @@ bool prefill_pw_applicable(const mi355_attn_params& p) {
 }
 
 template <typename T>
-static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, hipStream_t stream) {
+static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream) {
   PwArgs a;
   a.p = p;
   a.group = p.num_q_heads / p.num_kv_heads;
@@ -994,12 +1057,16 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   }
   static const int slots_env = [] { const char* e = getenv("MI355_PW_SLOTS"); return e ? atoi(e) : 0; }();   // measurements only
   const int items_per_head = a.num_qblocks * key_splits;
-  // One sequence: about one workgroup per CU, each walking several items (the boustrophedon deal is balanced for causal
-  // weights that fall linearly along the list; 1 x 4096: 116.7 us vs 118.5 with one item per workgroup, 2 x 4096 229 vs
-  // 234). Several sequences: the weights are a sawtooth and a static deal loses more than the seams gain (4 x 2048:
-  // 143.5 vs 135.7 us, 16 x 4096: 2011 vs 1881) - one item per workgroup, dealt by the hardware as CUs fall free.
+  // About one workgroup per CU, each walking several items. ONE sequence: the static boustrophedon deal - balanced by
+  // construction for causal weights that fall linearly along the list, and better than any greedy deal (1 x 4096: 112.5 us;
+  // tickets 115.0; one item per workgroup, dealt by the hardware, 118.5; 1 x 16384: 1574 vs 1587). SEVERAL sequences
+  // make the weights a sawtooth, and a static deal loses more than the seams gain (4 x 2048: 143.5 us): there the items
+  // are dealt by ticket counters in the zero-filled head of the caller's workspace (2 x 4096: 224.8 us vs 231.6 with one
+  // item per workgroup, 16 x 4096 1835 vs 1863, 8 x 2048 262.9 vs 268.7), and without a workspace one item per workgroup.
+  static const bool tickets_off = [] { const char* e = getenv("MI355_PW_TICKETS"); return e && e[0] == '0'; }();   // measurements only
+  a.tickets = (counters && !tickets_off && p.num_seqs > 1 && 2 * p.num_kv_heads * sizeof(int) <= kPwCounterBytes) ? counters : nullptr;
   const int per_cu = std::max(1, cus / p.num_kv_heads);
-  a.slots = std::max(1, std::min(items_per_head, slots_env > 0 ? slots_env : (p.num_seqs == 1 ? per_cu : items_per_head)));
+  a.slots = std::max(1, std::min(items_per_head, slots_env > 0 ? slots_env : ((a.tickets || p.num_seqs == 1) ? per_cu : items_per_head)));
   const size_t lds = kPwLds;
   static std::atomic<uint64_t> lds_opt_in{0};
   const int rc0 = ensure_dynamic_lds((const void*)prefill_pw_kernel<T>, (int)kPwLds, lds_opt_in, "hipFuncSetAttribute(prefill_pw)");
@@ -1010,8 +1077,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   return rc;
 }
 
-int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, hipStream_t stream) {
-  return launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, stream);
+int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream) {
+  return launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream);
 }
 
 }  // namespace mi355
