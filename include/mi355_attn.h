@@ -201,9 +201,10 @@ MI355_API const char* mi355_last_kernel(void);
  * Replaces the three per-call torch.empty scratch tensors at triton_unified_attention.py:950-971
  * (decode partials; here also the partials of a key-split prefill and the scratch cache of the repack path).
  * The workspace must be ZERO-FILLED ONCE by its owner after allocation: its first 256 KiB hold the
- * arrival counters of the in-kernel split merge, which every call leaves at zero again (a call
- * that was aborted mid-kernel does not: zero-fill again after a device error). One workspace
- * serves one stream at a time.
+ * arrival counters of the in-kernel split merge and the work-item ticket counters of the bf16 prefill
+ * kernel, which every call leaves at zero again (a call that was aborted mid-kernel does not: zero-fill
+ * again after a device error). One workspace serves one stream at a time. A prefill call whose answer is
+ * exactly those 256 KiB also runs WITHOUT a workspace (NULL, 0): its work items are then dealt statically.
  */
 MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
 
