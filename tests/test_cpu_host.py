@@ -74,6 +74,13 @@ def test_argument_validation_without_a_gpu(lib):
         lib.check(lib.MI355_ERR_UNSUPPORTED, "x")
     with pytest.raises(RuntimeError):
         lib.check(lib.MI355_ERR_HIP, "x")
+    buf = np.zeros(64, dtype=np.uint8)
+    q = _c3_like_params(lib, (buf.ctypes.data + 15) & ~15)
+    q.num_tokens, q.num_seqs, q.max_seqlen_q = 64, 64, 1
+    q.max_seqlen_k = -1                                                                  # a bound may be 0 (none given), never negative
+    assert h.mi355_attn_workspace_bytes(C.byref(q)) == 0
+    assert h.mi355_unified_attention(C.byref(q), None, 0, None) == lib.MI355_ERR_BAD_ARG
+    assert "max_seqlen_k" in lib.last_error()
     c = lib.CacheParams()
     assert h.mi355_reshape_and_cache_flash(None, None) == lib.MI355_ERR_BAD_ARG
     assert h.mi355_reshape_and_cache_flash(C.byref(c), None) == lib.MI355_OK             # zero tokens

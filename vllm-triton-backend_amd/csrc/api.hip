@@ -48,6 +48,10 @@ static int validate(const mi355_attn_params* p) {
     return MI355_ERR_BAD_ARG;
   }
   if (p->sliding_window < 0) { set_error("sliding_window must be >= 0"); return MI355_ERR_BAD_ARG; }
+  if (p->max_seqlen_q < 0 || p->max_seqlen_k < 0) {      // bounds, not exact: 0 = none given (the kernels read every row to its own length)
+    set_error("max_seqlen_q %d / max_seqlen_k %d must not be negative", p->max_seqlen_q, p->max_seqlen_k);
+    return MI355_ERR_BAD_ARG;
+  }
   if (p->lse && p->lse_stride_token < p->num_q_heads) { set_error("lse_stride_token %lld is smaller than num_q_heads %d", (long long)p->lse_stride_token, p->num_q_heads); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
   if (p->write_new_kv) {
