@@ -2,7 +2,7 @@
 (`triton_wrapper_forward_prefill`, LIB/kernels/triton_flash_attention.py:1326-1484, exported at
 LIB/kernels/__init__.py:65-67), served by the paged MFMA kernels: K/V are laid out as 16-token pages in a scratch cache
 (one pass of `reshape_and_cache_flash`, pages of a sequence contiguous) and `unified_attention` runs over them.
-Everything is device-side torch arithmetic on `cu_seqlens_*`: no host synchronisation.
+Everything is device-side torch arithmetic on `cu_seqlens_*`: no host synchronisation; the scratch cache is kept between calls.
 
 Served: the "thd" variable-length layout (`q [total_q, Hq, D]`, `k, v [total_k, Hk, D]`), causal masking with the
 reference's bottom-right alignment (query t of a sequence sees keys j <= t + seqlen_k - seqlen_q, :954-960),
@@ -18,6 +18,23 @@ from .cache import reshape_and_cache_flash
 from .unified import unified_attention
 
 _PAGE = 16
+_scratch: dict = {}
+
+
+def _scratch_cache(dev, num_pages, hk, d, dtype):
+    """The paged scratch K/V of a call, kept per (device, stream, heads, head size, dtype) and grown geometrically: a
+    serving loop calls this op with the same shapes over and over, and a per-call torch.empty pair would go through the
+    caching allocator every time (and move under a captured graph). Stream-ordered reuse: the next call's cache write is
+    enqueued behind this call's attention on the same stream."""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream, hk, d, dtype)
+    buf = _scratch.get(key)
+    if buf is None or buf.shape[1] < num_pages:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("prefill_flash_attention: run one eager call of the largest shape before graph capture")
+        grow = max(num_pages, 2 * (buf.shape[1] if buf is not None else 0))
+        buf = torch.empty((2, grow, _PAGE, hk, d), dtype=dtype, device=dev)
+        _scratch[key] = buf
+    return buf[0, :num_pages], buf[1, :num_pages]
 
 
 def prefill_flash_attention(
@@ -58,8 +75,7 @@ def prefill_flash_attention(
     tok_pos = torch.arange(total_k, device=dev) - cu_k[tok_seq]
     slot_mapping = page_base[tok_seq] * _PAGE + tok_pos
     num_pages = total_k // _PAGE + num_seqs                      # host-known upper bound of sum(ceil(len / 16))
-    k_cache = torch.empty((num_pages, _PAGE, hk, d), dtype=k.dtype, device=dev)
-    v_cache = torch.empty_like(k_cache)
+    k_cache, v_cache = _scratch_cache(dev, num_pages, hk, d, k.dtype)
     reshape_and_cache_flash(k, v, k_cache, v_cache, slot_mapping, "auto", None, None)
     max_pages = (int(max_seqlen_k) + _PAGE - 1) // _PAGE
     block_table = (page_base[:, None] + torch.arange(max_pages, device=dev)[None, :]).clamp_(max=num_pages - 1).to(torch.int32)
