@@ -100,6 +100,15 @@ __device__ __forceinline__ void a_exp2x2(float& r0, float& r1, float x0, float x
   asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
 }
 
+// -DPW_ABL_MFMA16 (timing experiment only, results are garbage): every P.V matrix instruction as TWO 16x16x32 ones of
+// the same total FLOPs, to see what clock the chip holds under that shape (MI355X_MICROARCH.md, DVFS give-back item 7)
+#ifdef PW_ABL_MFMA16
+#define PW_PV_ASM(MFMA)                                                                                             \
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]\n\tv_mfma_f32_16x16x32_bf16 a[%c4:%c5], %0, %1, a[%c4:%c5]" \
+               :: "v"(v), "v"(pf), "n"(OA), "n"(OA + 3), "n"(OA + 4), "n"(OA + 7));
+#else
+#define PW_PV_ASM(MFMA) asm volatile(MFMA " a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pf), "n"(OA), "n"(OA + 15));
+#endif
 template <typename T> struct pw_ops;
 #define MI355_DEF_PW_OPS(TAG, MFMA, CVT)                                                                          \
   template <> struct pw_ops<TAG> {                                                                                \
@@ -113,7 +122,7 @@ template <typename T> struct pw_ops;
     }                                                                                                             \
     /* O(AGPR) += V(VGPR) . P(VGPR) */                                                                             \
     template <int OA> static __device__ __forceinline__ void pv(const wu32x4_t& v, const wu32x4_t& pf) {          \
-      asm volatile(MFMA " a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pf), "n"(OA), "n"(OA + 15));              \
+      PW_PV_ASM(MFMA)                                                                                              \
     }                                                                                                             \
     static __device__ __forceinline__ uint32_t cvt(float lo, float hi) {                                          \
       uint32_t r; asm volatile(CVT " %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r;                          \
