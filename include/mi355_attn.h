@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 300 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 301 /* major*10000 + minor*100 + patch */
 
 #if defined(__GNUC__)
 #define MI355_API __attribute__((visibility("default")))
@@ -155,7 +155,10 @@ typedef struct mi355_attn_params {
    * layout and the matrix-core decode kernel (mi355_decode_write_fusable() answers for a parameter block); the caches
    * are written although the struct declares them const. */
   int32_t write_new_kv;
-  int32_t reserved2;
+  /* 0 (every op of the reference's backend path): causal - query t of a sequence sees keys j <= t + seqused_k - query_len.
+   * 1: every query row sees ALL seqused_k keys of its sequence (prefill_flash_attention(causal=False),
+   * triton_flash_attention.py:1326-1484; no sliding window / ALiBi with it). Served by the shape-agnostic kernel. */
+  int32_t non_causal;
 } mi355_attn_params;
 
 /*

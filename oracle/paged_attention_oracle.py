@@ -191,8 +191,8 @@ def dense_attention_fp64(
     return (out, lse) if return_lse else out
 
 
-def prefill_flash_attention_oracle(q, k, v, cu_seqlens_q, cu_seqlens_k, sm_scale, block_n: int = 16):
-    """The reference's non-paged variable-length prefill op in its causal form (attn_fwd via
+def prefill_flash_attention_oracle(q, k, v, cu_seqlens_q, cu_seqlens_k, sm_scale, block_n: int = 16, causal: bool = True):
+    """The reference's non-paged variable-length prefill op, causal or not (attn_fwd via
     triton_wrapper_forward_prefill, LIB/kernels/triton_flash_attention.py:1326-1484): per sequence and query head, keys
     in blocks of BLOCK_N with an online softmax in f32, the causal mask aligned bottom-right (query t of a sequence
     sees keys j <= t + seqlen_k - seqlen_q, :954-960), P rounded to V's type before P.V, grouped-query heads
@@ -206,7 +206,7 @@ def prefill_flash_attention_oracle(q, k, v, cu_seqlens_q, cu_seqlens_k, sm_scale
         lq, lk = q1 - q0, k1 - k0
         if lq <= 0:
             continue
-        last = torch.arange(lq) + (lk - lq)                         # last visible key of each query row
+        last = torch.arange(lq) + (lk - lq) if causal else torch.full((lq,), lk - 1)   # last visible key of each query row
         for hq in range(Hq):
             h = hq // G
             Q = q[q0:q1, hq].to(torch.float32)

@@ -253,10 +253,12 @@ def flash_cases():
     torch.cuda.get_device_properties = lambda *a, **k: _Props()
     fa = load_by_path("ibm_triton_lib.kernels.triton_flash_attention", f"{LIBK}/triton_flash_attention.py")
     try:
-        for name, dtype, hq, hk, d, q_lens, k_lens, seed in (
-            ("flash_varlen_causal_gqa2_d64_fp32", torch.float32, 4, 2, 64, [5, 17, 1, 33], [9, 17, 33, 40], 61),
-            ("flash_varlen_causal_gqa4_d128_fp16", torch.float16, 8, 2, 128, [40, 1, 19, 70], [70, 45, 19, 70], 62),
-            ("flash_varlen_causal_mha_d64_fp16", torch.float16, 4, 4, 64, [33, 3, 16], [33, 35, 64], 63),
+        for name, dtype, hq, hk, d, q_lens, k_lens, seed, causal in (
+            ("flash_varlen_causal_gqa2_d64_fp32", torch.float32, 4, 2, 64, [5, 17, 1, 33], [9, 17, 33, 40], 61, True),
+            ("flash_varlen_causal_gqa4_d128_fp16", torch.float16, 8, 2, 128, [40, 1, 19, 70], [70, 45, 19, 70], 62, True),
+            ("flash_varlen_causal_mha_d64_fp16", torch.float16, 4, 4, 64, [33, 3, 16], [33, 35, 64], 63, True),
+            ("flash_varlen_noncausal_gqa2_d64_fp32", torch.float32, 4, 2, 64, [5, 17, 1, 33], [9, 17, 33, 40], 64, False),
+            ("flash_varlen_noncausal_gqa4_d128_fp16", torch.float16, 8, 2, 128, [40, 1, 19, 70], [70, 45, 19, 70], 65, False),
         ):
             g = torch.Generator().manual_seed(seed)
             cu_q = torch.tensor([0] + torch.tensor(q_lens).cumsum(0).tolist(), dtype=torch.int32)
@@ -265,9 +267,9 @@ def flash_cases():
             k = (torch.rand(int(cu_k[-1]), hk, d, generator=g) * 2 - 1).to(dtype)
             v = (torch.rand(int(cu_k[-1]), hk, d, generator=g) * 2 - 1).to(dtype)
             scale = 1.0 / (d ** 0.5)
-            out = fa.triton_wrapper_forward_prefill(q, k, v, max(q_lens), max(k_lens), cu_q, cu_k, causal=True, sm_scale=scale)
+            out = fa.triton_wrapper_forward_prefill(q, k, v, max(q_lens), max(k_lens), cu_q, cu_k, causal=causal, sm_scale=scale)
             out = out[0] if isinstance(out, tuple) else out
-            save(name, dict(kind="flash_varlen", scale=scale, max_seqlen_q=max(q_lens), max_seqlen_k=max(k_lens), causal=True),
+            save(name, dict(kind="flash_varlen", scale=scale, max_seqlen_q=max(q_lens), max_seqlen_k=max(k_lens), causal=causal),
                  q=q, k=k, v=v, cu_seqlens_q=cu_q, cu_seqlens_k=cu_k, out=out)
     finally:
         TILE = saved

@@ -67,7 +67,7 @@ def test_varlen_unsupported_modes_raise():
     q = torch.zeros(16, 4, 64, dtype=torch.bfloat16, device=dev)
     cu = torch.tensor([0, 16], dtype=torch.int32, device=dev)
     with pytest.raises(NotImplementedError):
-        prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=False)
+        prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=False, bias=torch.zeros(1, device=dev))
     with pytest.raises(NotImplementedError):
         prefill_flash_attention(q, q, q, 16, 16, cu, cu, causal=True, bias=torch.zeros(1, device=dev))
     with pytest.raises(NotImplementedError):
@@ -87,9 +87,11 @@ def test_varlen_prefill_against_the_reference_kernels_outputs(name):
     meta, t = golden_io.load(name)
     dev = torch.device("cuda:0")
     out = prefill_flash_attention(t["q"].to(dev), t["k"].to(dev), t["v"].to(dev), meta["max_seqlen_q"], meta["max_seqlen_k"],
-                                  t["cu_seqlens_q"].to(dev), t["cu_seqlens_k"].to(dev), causal=True, sm_scale=meta["scale"])
+                                  t["cu_seqlens_q"].to(dev), t["cu_seqlens_k"].to(dev), causal=meta["causal"], sm_scale=meta["scale"])
     torch.cuda.synchronize()
-    if t["q"].dtype == torch.float16:
+    if t["q"].dtype == torch.float16 and meta["causal"]:
         assert _lib.last_kernel().startswith("prefill_mfma"), _lib.last_kernel()
+    if not meta["causal"]:
+        assert _lib.last_kernel() == "generic", _lib.last_kernel()      # the correctness path: no MFMA kernel without the causal mask
     atol, rtol = golden_io.tolerance(t["q"].dtype)
     torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol)

@@ -90,6 +90,6 @@ def test_prefill_flash_attention_oracle(name):
     """The oracle's restatement of the reference's non-paged varlen prefill op against the outputs of the reference's own
     attn_fwd kernel (run under the Triton interpreter by tests/golden/make_golden.py::flash_cases)."""
     meta, t = golden_io.load(name)
-    out = orc.prefill_flash_attention_oracle(t["q"], t["k"], t["v"], t["cu_seqlens_q"], t["cu_seqlens_k"], meta["scale"])
+    out = orc.prefill_flash_attention_oracle(t["q"], t["k"], t["v"], t["cu_seqlens_q"], t["cu_seqlens_k"], meta["scale"], causal=meta["causal"])
     atol, rtol = golden_io.tolerance(t["q"].dtype)
     torch.testing.assert_close(out, t["out"].float(), atol=atol, rtol=rtol)

@@ -54,6 +54,10 @@ static int validate(const mi355_attn_params* p) {
   }
   if (p->lse && p->lse_stride_token < p->num_q_heads) { set_error("lse_stride_token %lld is smaller than num_q_heads %d", (long long)p->lse_stride_token, p->num_q_heads); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
+  if (p->non_causal && (p->sliding_window > 0 || p->alibi_slopes || p->write_new_kv || p->k_new)) {
+    set_error("non_causal attention takes neither a sliding window, ALiBi slopes nor linear new-token K/V");
+    return MI355_ERR_UNSUPPORTED;
+  }
   if (p->write_new_kv) {
     if (!p->k_new || !p->v_new) { set_error("write_new_kv needs k_new / v_new"); return MI355_ERR_BAD_ARG; }
     if (p->max_seqlen_q != 1 || p->num_tokens != p->num_seqs || p->skip_decodes || p->only_decodes) {
@@ -73,6 +77,7 @@ enum class Path { Generic, Decode, Prefill, PrefillPlusDecode, Repacked };
 static Path choose(const mi355_attn_params& p) {
   const int sel = p.kernel_select;
   if (p.write_new_kv) return Path::Decode;     // validated: the fused decode kernel takes it
+  if (p.non_causal) return Path::Generic;      // every MFMA kernel is built around the causal mask
   if (sel == MI355_SELECT_GENERIC) return Path::Generic;
   // legacy ops: cache in the v0 layout and/or new keys in linear tensors - gathered into a flash-layout scratch
   // cache first, then the kernels below run on that (repack.hip)

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void generic_attn_kernel(const GenericArgs a) {
   const int seq_len = p.seqused_k[seq];
   const int ctx_len = seq_len - q_len;
   const int q_pos = token - q_start;          // position inside the query
-  int n_keys = ctx_len + q_pos + 1;           // causal: keys j <= ctx + q_pos
+  int n_keys = p.non_causal ? seq_len : ctx_len + q_pos + 1;   // causal: keys j <= ctx + q_pos
   if (n_keys > seq_len) n_keys = seq_len;
   const int kv_head = head / (p.num_q_heads / p.num_kv_heads);
   const bool use_new = (p.k_new != nullptr) && (q_len > 1);

@@ -96,7 +96,7 @@ class AttnParams(C.Structure):
         ("lse", C.c_void_p),
         ("lse_stride_token", C.c_int64),
         ("write_new_kv", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("non_causal", C.c_int32),
     ]
 
 

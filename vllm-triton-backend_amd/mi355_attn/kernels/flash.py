@@ -5,9 +5,10 @@ LIB/kernels/__init__.py:65-67), served by the paged MFMA kernels: K/V are laid o
 Everything is device-side torch arithmetic on `cu_seqlens_*`: no host synchronisation; the scratch cache is kept between calls.
 
 Served: the "thd" variable-length layout (`q [total_q, Hq, D]`, `k, v [total_k, Hk, D]`), causal masking with the
-reference's bottom-right alignment (query t of a sequence sees keys j <= t + seqlen_k - seqlen_q, :954-960),
-grouped-query heads. Not served (raise `NotImplementedError`, nothing silently ignored): non-causal attention, `bias`,
-softmax encodings, dropout.
+reference's bottom-right alignment (query t of a sequence sees keys j <= t + seqlen_k - seqlen_q, :954-960) on the MFMA
+kernels, non-causal attention (every query row sees its sequence's whole key range) on the shape-agnostic kernel - a
+correctness path, not a fast one -, grouped-query heads. Not served (raise `NotImplementedError`, nothing silently
+ignored): `bias`, softmax encodings, dropout.
 """
 
 from __future__ import annotations
@@ -15,7 +16,7 @@ from __future__ import annotations
 import torch
 
 from .cache import reshape_and_cache_flash
-from .unified import unified_attention
+from .unified import fill_attn_params, launch, unified_attention
 
 _PAGE = 16
 _scratch: dict = {}
@@ -54,8 +55,6 @@ def prefill_flash_attention(
 ):
     if not q.is_cuda:
         raise RuntimeError("mi355_attn.prefill_flash_attention needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
-    if not causal:
-        raise NotImplementedError("prefill_flash_attention: only causal attention is served by the paged kernels")
     if bias is not None:
         raise NotImplementedError("prefill_flash_attention: bias is not supported")
     if not do_not_return_softmax_encodings:
@@ -80,10 +79,17 @@ def prefill_flash_attention(
     max_pages = (int(max_seqlen_k) + _PAGE - 1) // _PAGE
     block_table = (page_base[:, None] + torch.arange(max_pages, device=dev)[None, :]).clamp_(max=num_pages - 1).to(torch.int32)
     out = in_place_output if in_place_output is not None else torch.empty_like(q)
-    unified_attention(
-        q=q, k=k_cache, v=v_cache, out=out, cu_seqlens_q=cu_seqlens_q.to(torch.int32), max_seqlen_q=int(max_seqlen_q),
-        seqused_k=lens.to(torch.int32), max_seqlen_k=int(max_seqlen_k), avg_seqlen_q=0.0, avg_seqlen_k=0.0,
-        softmax_scale=float(sm_scale), causal=True, window_size=(-1, -1), block_table=block_table, softcap=0.0,
-        q_descale=None, k_descale=None, v_descale=None,
-    )
+    if causal:
+        unified_attention(
+            q=q, k=k_cache, v=v_cache, out=out, cu_seqlens_q=cu_seqlens_q.to(torch.int32), max_seqlen_q=int(max_seqlen_q),
+            seqused_k=lens.to(torch.int32), max_seqlen_k=int(max_seqlen_k), avg_seqlen_q=0.0, avg_seqlen_k=0.0,
+            softmax_scale=float(sm_scale), causal=True, window_size=(-1, -1), block_table=block_table, softcap=0.0,
+            q_descale=None, k_descale=None, v_descale=None,
+        )
+    else:
+        # `unified_attention` keeps the reference op's "only causal" assert; the parameter block has the switch
+        p, keep = fill_attn_params(q, k_cache, v_cache, out, cu_seqlens_q.to(torch.int32), int(max_seqlen_q), lens.to(torch.int32),
+                                   int(max_seqlen_k), float(sm_scale), (-1, -1), block_table, 0.0, None, None, None, None, non_causal=True)
+        launch(p, q.device)
+        del keep
     return out

@@ -34,7 +34,7 @@ def fill_attn_params(
     q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_size,
     block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection,
     k_new=None, v_new=None, skip_decodes=False, only_decodes=False, num_segments=0,
-    legacy_v0_layout=False, lse=None, write_new_kv=False,
+    legacy_v0_layout=False, lse=None, write_new_kv=False, non_causal=False,
 ):
     """Build the C struct. Returns (params, keepalive) — keepalive holds temporaries whose device
     memory the struct points to."""
@@ -111,6 +111,7 @@ def fill_attn_params(
         raise ValueError(f"force_selection must be None, 2, 3 or 9, got {force_selection}") from None
     p.num_segments = int(num_segments)
     p.write_new_kv = int(bool(write_new_kv))
+    p.non_causal = int(bool(non_causal))
     if lse is not None:
         if lse.dtype != torch.float32 or lse.dim() != 2 or lse.shape[0] != q.shape[0] or lse.shape[1] != q.shape[1] or lse.stride(1) != 1:
             raise ValueError("softmax_lse must be a float32 [num_tokens, num_heads] tensor with contiguous heads")
