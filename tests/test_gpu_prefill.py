@@ -328,3 +328,24 @@ def test_mixed_c4_full_size_sampled_rows():
               cu_seqlens_q=loc.cu_seqlens_q, seqused_k=loc.seqused_k)
     out_l, _ = gpu_util.run_unified(dl, scale)
     torch.testing.assert_close(out_l.float(), out[loc.token_index.to(dev)].float(), atol=2e-3, rtol=1.6e-2)
+
+
+@pytest.mark.parametrize("query_lens,kv_lens,pad", [([2500], [2500], 60), ([700], [2300], 68), ([1200, 900], [2400, 2100], 77)])
+def test_prefill_with_padding_tokens_behind_the_last_sequence(query_lens, kv_lens, pad):
+    """vLLM pads num_tokens (graph sizes): q / out carry rows behind cu_seqlens_q[-1] that belong to no sequence. They must
+    stay untouched, and the real rows must not care - also on the 64-rows-per-wave kernel, whose single-sequence item
+    list is sized from num_tokens (some of its Q blocks are then empty or partly padding)."""
+    import gpu_util
+
+    inp = orc.make_paged_inputs(91, query_lens, kv_lens, 8, 2, 128, 16, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    T = inp["q"].shape[0]
+    d = gpu_util.to_dev(inp)
+    g = torch.Generator().manual_seed(5)
+    d["q"] = torch.cat([d["q"], (torch.rand(pad, 8, 128, generator=g) * 2 - 1).to(torch.bfloat16).to(gpu_util.DEV)])
+    out, kernel = gpu_util.run_unified(d, inp["scale"])
+    assert kernel.startswith("prefill_mfma"), kernel
+    assert torch.isnan(out[T:]).all(), "rows of padding tokens were written"
+    assert not torch.isnan(out[:T]).any()
+    torch.testing.assert_close(out[:T].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
