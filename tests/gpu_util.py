@@ -12,6 +12,20 @@ def to_dev(d):
     return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
 
 
+def oracle_row(orc, q_row, k, v, bt_row, n_keys, scale, **kw):
+    """The oracle for ONE query token over the first n_keys keys of one sequence of a BIG cache. The sequence's pages are
+    gathered into a small contiguous cache first (identity block table): the oracle's per-head gathers out of a
+    multi-gigabyte host tensor cost tens of seconds per row on the GPU box's host (0.1 s this way)."""
+    pages = bt_row.reshape(-1)[: (n_keys + k.shape[1] - 1) // k.shape[1]].long()
+    kc, vc = k[pages].contiguous(), v[pages].contiguous()
+    if kc.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+        # the oracle's dequantisation, (fp8 -> f32) * scale -> query dtype, once per cache instead of once per query head
+        kc = orc._dequant(kc, kw.pop("k_scale", 1.0), q_row.dtype).to(q_row.dtype)
+        vc = orc._dequant(vc, kw.pop("v_scale", 1.0), q_row.dtype).to(q_row.dtype)
+    ident = torch.arange(pages.numel(), dtype=torch.int32).view(1, -1)
+    return orc.unified_attention_oracle(q_row, kc, vc, torch.tensor([0, 1], dtype=torch.int32), torch.tensor([n_keys], dtype=torch.int32), ident, scale, **kw)
+
+
 def run_unified(t, scale, *, window=0, softcap=0.0, kv_scale=None, v_scale=None, force=None, out=None, lse=None):
     """t: dict with q, k_cache, v_cache, cu_seqlens_q, seqused_k, block_table[, alibi_slopes] on DEV."""
     q = t["q"]

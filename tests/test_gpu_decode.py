@@ -182,9 +182,7 @@ def test_decode_c3_full_size_properties():
     assert kernel == "decode_splitkv"
     # (3) sample rows vs oracle
     for i in (0, 37, 63):
-        sub = dict(q=q[i:i + 1], k_cache=k, v_cache=v, block_table=bt[i:i + 1], cu_seqlens_q=torch.tensor([0, 1], dtype=torch.int32),
-                   seqused_k=torch.tensor([kv], dtype=torch.int32))
-        ref = orc.unified_attention_oracle(sub["q"], k, v, sub["cu_seqlens_q"], sub["seqused_k"], sub["block_table"], scale, mode="3d")
+        ref = gpu_util.oracle_row(orc, q[i:i + 1], k, v, bt[i], kv, scale, mode="3d")
         torch.testing.assert_close(out[i:i + 1].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
     # (2) page permutation invariance, bit-exact
     perm = torch.randperm(nb, generator=g)
@@ -230,8 +228,7 @@ def test_decode_c5_full_size_properties():
     assert not torch.isnan(out).any()
     atol, rtol = golden_io.tolerance(torch.bfloat16, torch.float8_e4m3fn)
     for i in (0, 9, 15):
-        ref = orc.unified_attention_oracle(q[i:i + 1], k, v, torch.tensor([0, 1], dtype=torch.int32), torch.tensor([kv], dtype=torch.int32), bt[i:i + 1],
-                                           scale, k_scale=ks, v_scale=vs, mode="3d")
+        ref = gpu_util.oracle_row(orc, q[i:i + 1], k, v, bt[i], kv, scale, k_scale=ks, v_scale=vs, mode="3d")
         torch.testing.assert_close(out[i:i + 1].float().cpu(), ref.float(), atol=atol, rtol=rtol)
     perm = torch.randperm(nb, generator=g)
     inv = torch.empty_like(perm)
@@ -253,8 +250,7 @@ def test_decode_c5_full_size_properties():
     d4["seqused_k"] = torch.tensor(lens, dtype=torch.int32, device=dev)
     out4, _ = _run_with_max_k(d4, scale, kv, ks, vs)
     for i in (1, 2, 3, 4, 13):
-        ref = orc.unified_attention_oracle(q[i:i + 1], k, v, torch.tensor([0, 1], dtype=torch.int32), torch.tensor([lens[i]], dtype=torch.int32),
-                                           bt[i:i + 1], scale, k_scale=ks, v_scale=vs, mode="3d")
+        ref = gpu_util.oracle_row(orc, q[i:i + 1], k, v, bt[i], lens[i], scale, k_scale=ks, v_scale=vs, mode="3d")
         torch.testing.assert_close(out4[i:i + 1].float().cpu(), ref.float(), atol=atol, rtol=rtol)
 
 

@@ -168,9 +168,7 @@ def test_prefill_c2_full_size_properties():
     assert not torch.isnan(out).any()
     # sampled query tokens vs the oracle: token at position pos == decode with kv_len pos+1
     for pos in (0, 1, 63, 64, 1000, 2047, 4095):
-        sub_cu = torch.tensor([0, 1], dtype=torch.int32)
-        ref = orc.unified_attention_oracle(q[pos:pos + 1], k, v, sub_cu, torch.tensor([pos + 1], dtype=torch.int32), bt, scale, mode="2d",
-                                           block_n=64)
+        ref = gpu_util.oracle_row(orc, q[pos:pos + 1], k, v, bt[0], pos + 1, scale, mode="2d", block_n=64)
         torch.testing.assert_close(out[pos:pos + 1].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
     # page permutation invariance, bit-exact
     perm = torch.randperm(nb, generator=g)
@@ -312,8 +310,7 @@ def test_mixed_c4_full_size_sampled_rows():
     def check_token(s_idx, tok, got):
         pos = kvlens[s_idx] - qlens[s_idx] + tok               # absolute position: sees keys 0 .. pos
         t = cul[s_idx] + tok
-        ref = orc.unified_attention_oracle(q[t:t + 1], k, v, torch.tensor([0, 1], dtype=torch.int32), torch.tensor([pos + 1], dtype=torch.int32),
-                                           bt[s_idx:s_idx + 1], scale, mode="2d", block_n=64)
+        ref = gpu_util.oracle_row(orc, q[t:t + 1], k, v, bt[s_idx], pos + 1, scale, mode="2d", block_n=64)
         torch.testing.assert_close(got.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
 
     kinds = {"dec": [i for i in range(S) if qlens[i] == 1], "part": [i for i in range(S) if qlens[i] == 2048], "full": [i for i in range(S) if qlens[i] == 4096]}
