@@ -185,9 +185,33 @@ def timed_steps(call, steps, warmup, device, distributed):
     return wall, e0.elapsed_time(e1) * 1e-3 / steps
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the cgroup CPU quota (a one-GPU job on the GPU box sees 256 CPUs and is given
+    16), else the affinity mask, else the CPU count."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        if q > 0:
+            return max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
+    except (OSError, ValueError):
+        pass
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(w, out_gpu):
-    """Reference-style CPU SDPA path on this box's host cores, on the same inputs (rank 0, N=1)."""
+    """Reference-style CPU SDPA path on this box's host cores, on the same inputs (rank 0, N=1). One torch thread per CPU
+    the job is GIVEN (more only fight over the quota: 128 threads on a 16-CPU share ran the same SDPA 2.7x slower)."""
     import torch
+
+    torch.set_num_threads(min(torch.get_num_threads(), host_cpu_share()))
 
     from oracle.cpu_sdpa_baseline import time_paged_sdpa_cpu
 
