@@ -72,6 +72,20 @@ def test_prefill_64_rows_per_wave_kernel_walking_many_items_per_workgroup():
          keyword="(mixed and 128 and dtype0) or c2_full or leave")
 
 
+def test_prefill_64_rows_per_wave_kernel_on_the_16x16x32_matrix_instruction():
+    """The kernel's second instantiation (MI355_PW_M16=1: both contractions on v_mfma_f32_16x16x32_bf16, an A/B lever -
+    DESIGN.md 8): the same parity cases, many items per workgroup, the per-row routine, the C2 size."""
+    _run({"MI355_PREFILL": "pw", "MI355_PW_M16": "1", "MI355_PREFILL_KEY_SPLITS": "1"},
+         ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
+          "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_prefill.py::test_prefill_rows_whose_scores_leave_the_fixed_reference_range",
+          "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties", "tests/test_gpu_fuzz.py"],
+         keyword="(mixed and 128 and dtype0) or page_sizes or strided or leave or agree or c2_full")
+    _run({"MI355_PREFILL": "pw", "MI355_PW_M16": "1", "MI355_PW_SLOTS": "2"},
+         ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_key_split_with_rows_outside_the_fixed_reference_range",
+          "tests/test_gpu_prefill_ksplit.py", "tests/test_gpu_fuzz.py"],
+         keyword="(mixed and 128 and dtype0) or outside or ksplit or key_split or agree")
+
+
 def test_prefill_8_wave_kernel_with_rows_outside_its_first_reference():
     _run({"MI355_PREFILL": "d8", "MI355_PREFILL_KEY_SPLITS": "1"},
          ["tests/test_gpu_prefill.py::test_prefill_rows_whose_scores_leave_the_fixed_reference_range"])
