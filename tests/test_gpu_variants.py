@@ -73,8 +73,9 @@ def test_prefill_64_rows_per_wave_kernel_walking_many_items_per_workgroup():
 
 
 def test_prefill_64_rows_per_wave_kernel_on_the_16x16x32_matrix_instruction():
-    """The kernel's second instantiation (MI355_PW_M16=1: both contractions on v_mfma_f32_16x16x32_bf16, an A/B lever -
-    DESIGN.md 8): the same parity cases, many items per workgroup, the per-row routine, the C2 size."""
+    """The kernel's 16x16x32 instantiation (both contractions on v_mfma_f32_16x16x32_bf16, row sums on the matrix pipe;
+    the dispatcher's choice from 4096 keys on) pinned on the small parity shapes: many items per workgroup, the per-row
+    routine, the C2 size; and the 32x32x16 instantiation pinned where the dispatcher would pick the other one."""
     _run({"MI355_PREFILL": "pw", "MI355_PW_M16": "1", "MI355_PREFILL_KEY_SPLITS": "1"},
          ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes",
           "tests/test_gpu_prefill.py::test_prefill_strided_q_and_out", "tests/test_gpu_prefill.py::test_prefill_rows_whose_scores_leave_the_fixed_reference_range",
@@ -84,6 +85,8 @@ def test_prefill_64_rows_per_wave_kernel_on_the_16x16x32_matrix_instruction():
          ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_key_split_with_rows_outside_the_fixed_reference_range",
           "tests/test_gpu_prefill_ksplit.py", "tests/test_gpu_fuzz.py"],
          keyword="(mixed and 128 and dtype0) or outside or ksplit or key_split or agree")
+    _run({"MI355_PREFILL": "pw", "MI355_PW_M16": "0"},
+         ["tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties", "tests/test_gpu_prefill_ksplit.py"])
 
 
 def test_prefill_8_wave_kernel_with_rows_outside_its_first_reference():

@@ -99,6 +99,12 @@ __device__ __forceinline__ float a_add(float x, float y) { float r; asm volatile
 __device__ __forceinline__ void a_exp2x2(float& r0, float& r1, float x0, float x1) {
   asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1));
 }
+// the same into hand-owned registers (named as inputs, see the state block of prefill_pw_kernel)
+__device__ __forceinline__ void a_exp2x2_ho(float r0, float r1, float x0, float x1) {
+  asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" :: "v"(r0), "v"(r1), "v"(x0), "v"(x1));
+}
+// a value the compiler knows nothing about from here on (it stays where it is: no instruction)
+template <typename V> __device__ __forceinline__ void pw_launder(V& v) { asm volatile("" : "+v"(v)); }
 
 // -DPW_ABL_MFMA16 (timing experiment only, results are garbage): every P.V matrix instruction as TWO 16x16x32 ones of
 // the same total FLOPs, to see what clock the chip holds under that shape (MI355X_MICROARCH.md, DVFS give-back item 7)
@@ -126,6 +132,18 @@ template <typename T> struct pw_ops;
     template <int KA, int QA> static __device__ __forceinline__ void qk_acc_masked(wf32x16_t& s) {                \
       asm volatile("s_nop 1\n\t" MFMA " %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3)); \
     }                                                                                                             \
+    /* The forms the tile loop uses: the registers of S, of the row sums and of P are named as INPUTS although the */ \
+    /* statement writes them ("hand-owned", see the state block of prefill_pw_kernel). */                           \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_zero_ho(const wf32x16_t& s) {             \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], 0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));   \
+    }                                                                                                             \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_acc_ho(const wf32x16_t& s) {              \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], %0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));  \
+    }                                                                                                             \
+    static __device__ __forceinline__ void sum_pack_ho(float s0, float s1, uint32_t pk, float lo, float hi) {     \
+      asm volatile("v_add_f32 %0, %0, %3\n\tv_add_f32 %1, %1, %4\n\t" CVT " %2, %3, %4"                           \
+                   :: "v"(s0), "v"(s1), "v"(pk), "v"(lo), "v"(hi));                                                 \
+    }                                                                                                             \
     /* O(AGPR) += V(VGPR) . P(VGPR) */                                                                             \
     template <int OA> static __device__ __forceinline__ void pv(const wu32x4_t& v, const wu32x4_t& pf) {          \
       PW_PV_ASM(MFMA)                                                                                              \
@@ -150,6 +168,20 @@ struct pw_ops16 {
   }
   template <int KA, int QA> static __device__ __forceinline__ void qk_acc(wf32x4_t& s) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+  }
+  // hand-owned forms (see the state block of prefill_pw_kernel): the written registers are named as inputs
+  template <int KA, int QA> static __device__ __forceinline__ void qk_zero_ho(const wf32x4_t& s) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+  }
+  template <int KA, int QA> static __device__ __forceinline__ void qk_acc_ho(const wf32x4_t& s) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+  }
+  // row sums on the matrix pipe: l += 1 . P^T (A = sixteen rows of ones: every register of l holds the row's whole sum)
+  static __device__ __forceinline__ void lsum_ho(const wf32x4_t& l, const wu32x4_t& ones, const wu32x4_t& pf) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" :: "v"(l), "v"(ones), "v"(pf));
+  }
+  static __device__ __forceinline__ void pack_ho(uint32_t pk, float lo, float hi) {
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" :: "v"(pk), "v"(lo), "v"(hi));
   }
   template <int KA, int QA> static __device__ __forceinline__ void qk_acc_masked(wf32x4_t& s) {      // (see pw_ops)
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
@@ -329,8 +361,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     uint64_t bt64;                     // this sequence's block-table row
     uint16_t* out_base;
     float* lse_base;
-    int lim[4];                        // per lane: last visible key of its query rows, -1 = padding row. [sb] for the two 32-row
-                                       // sub-blocks; M16: [2 x + rt], four rows per lane
   };
   const int head = (int)(blockIdx.x % p.num_kv_heads);
   const int slot = (int)(blockIdx.x / p.num_kv_heads);
@@ -386,12 +416,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       I.seq = seq; I.q_start = q_start; I.q_len = q_len; I.seq_len = seq_len;
       I.ctx_len = seq_len - q_len;
       I.tok0 = qb_local * BQ;
-#pragma unroll
-      for (int sb = 0; sb < (M16 ? 4 : 2); ++sb) {
-        const int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + qr_o;
-        const int tok = I.tok0 + div_g(m_row);
-        I.lim[sb] = ((m_row < BQ * sa.G) && (tok < q_len)) ? min(I.ctx_len + tok, seq_len - 1) : -1;
-      }
       I.w_tok_lo = I.tok0 + div_g(wave * 64);
       const int wg_tok_hi = min(I.tok0 + BQ - 1, q_len - 1);
       const int n_keys_wg = max(0, min(I.ctx_len + wg_tok_hi + 1, seq_len));
@@ -462,6 +486,14 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
 
   // this lane's query row of sub-block sb (recomputed where it is needed: nothing of it lives through the tile loop)
+  // last visible key of this lane's query row in sub-block sb (two 32-row sub-blocks; M16: sb = 2 x + rt, four 16-row
+  // tiles), -1 = a padding row. Recomputed where it is needed (Q conversion, the mask, the output) rather than kept in
+  // registers across the tile loop.
+  auto row_lim = [&](const Item& I, int sb) __attribute__((always_inline)) {
+    const int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + (lane_o & 31);
+    const int tok = I.tok0 + div_g(m_row);
+    return ((m_row < sa.BQ * sa.G) && (tok < I.q_len)) ? min(I.ctx_len + tok, I.seq_len - 1) : -1;
+  };
   auto row_of = [&](const Item& I, int sb, int& tok_local, int& hq) __attribute__((always_inline)) {
     const int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + (lane_o & 31);   // M16: sb = 2 x + rt
     tok_local = I.tok0 + div_g(m_row);
@@ -633,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       sfor<8>([&](auto KS) {
         // (M16: qraw[x][4 rt + ks] is Q'[x][rt][ks], whose registers are kAQ + 32 x + 16 rt + 4 ks: the same index arithmetic)
         constexpr int sb = decltype(SB)::value, ks = decltype(KS)::value;
-        const wu32x4_t v = I.lim[M16 ? 2 * sb + (ks >> 2) : sb] >= 0 ? qraw[sb][ks] : wu32x4_t{0, 0, 0, 0};
+        const wu32x4_t v = row_lim(I, M16 ? 2 * sb + (ks >> 2) : sb) >= 0 ? qraw[sb][ks] : wu32x4_t{0, 0, 0, 0};
         sfor<4>([&](auto E) {
           constexpr int e = decltype(E)::value;
           acc_write<kAQ + 32 * sb + 4 * ks + e>(pw_pack<T>(pw_lo<T>(v[e]) * scale2, pw_hi<T>(v[e]) * scale2));
@@ -643,42 +675,72 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
 
   // ---- state -------------------------------------------------------------------------------------------
+  // HAND-OWNED REGISTERS (32x32x16 instantiation). hipcc pads one s_nop between two asm statements when the second reads
+  // a register the first wrote and none of its own instructions sits between them - and in the tile loop every
+  // instruction is an asm statement and every one costs this wave four issue cycles (tools/probes/issue_model.hip):
+  // ~45 pads per tile, 6 % of it. So the tile loop's statements name S, the exponentials' ring, the row sums and P
+  // as INPUTS and write them all the same: to the compiler these are values that an empty asm statement defined once
+  // per work item (pw_launder: nothing to rematerialise, nothing known about the content) and that are only ever
+  // read, so each keeps one home register - which is all the loop needs from the compiler. Its own code touches them
+  // in two places: the mask (it writes S, and qk_acc_masked defines S again) and the output (it reads the row sums).
+  // tests/test_cpu_host.py counts the pads and the register copies left in the steady loop.
   wf32x16_t S[2][2];          // [sub-block][32-key block]: S^T of the tile in flight
-  uint32_t pw[2][16];         // P^T as packed pairs; dwords 4 sk .. 4 sk + 3 = B operand of k-step sk
-  wu32x4_t vfr[4][4];         // transposed V fragments [output block b][k-step sk]
-  float e0[2][16], e1[2][16];
+  wu32x4_t pwv[2][4];         // P^T as packed pairs [sub-block][k-step sk]: the B operand of that step
+  float er0[3], er1[3];       // exponentials between their v_exp and their sum + pack: a ring of three pairs (word j's are
+                              // written at block 2 j - 2 and read at 2 j + 3, word j + 3's written at 2 j + 4; the two
+                              // sub-blocks' streams never interleave: B's ends with segment 1, A's runs over segments 2 and 3)
+  wu32x4_t vfr[4][4];         // transposed V fragments [output block b][k-step sk] (ordinary outputs of their LDS reads)
+  float e0[2][16], e1[2][16]; // (M16)
   float ps0[2] = {0.0f, 0.0f}, ps1[2] = {0.0f, 0.0f};   // running row sums (two chains)
   // M16: S16[x][rt][kt] (keys 16 kt + 4 g4 + r of row 32 x + 16 rt + r16), pw16[x][rt][c] (the B operand of the P.V step
   // over keys 32 c ..: dwords (kt = 2c: r 0,1 | r 2,3 | kt = 2c + 1: r 0,1 | r 2,3)), vfr16[db][c], row sums per (x, rt)
+  // (hand-owned as well; the row sums come off the matrix pipe: L16[x][rt] += 1 . P^T, two instructions per tile each)
   wf32x4_t S16[2][2][4];
-  uint32_t pw16[2][2][2][4];
+  wu32x4_t pwv16[2][2][2];
   wu32x4_t vfr16[8][2];
-  float qs0[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, qs1[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+  wf32x4_t L16[2][2];
+  wu32x4_t ones16;
   auto reset_state = [&]() __attribute__((always_inline)) {
     if constexpr (M16) {
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          qs0[x][rt] = 0.0f; qs1[x][rt] = 0.0f;
+          L16[x][rt] = wf32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+          pw_launder(L16[x][rt]);
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) S16[x][rt][kt] = wf32x4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          for (int kt = 0; kt < 4; ++kt) { S16[x][rt][kt] = wf32x4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; pw_launder(S16[x][rt][kt]); }
 #pragma unroll
-          for (int d = 0; d < 4; ++d) { pw16[x][rt][0][d] = 0u; pw16[x][rt][1][d] = 0u; }
+          for (int c = 0; c < 2; ++c) { pwv16[x][rt][c] = wu32x4_t{0, 0, 0, 0}; pw_launder(pwv16[x][rt][c]); }
         }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { er0[i] = 0.0f; er1[i] = 0.0f; pw_launder(er0[i]); pw_launder(er1[i]); }
+      ones16 = wu32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 pairs
+      pw_launder(ones16);
 #pragma unroll
       for (int db = 0; db < 8; ++db) { vfr16[db][0] = wu32x4_t{0, 0, 0, 0}; vfr16[db][1] = wu32x4_t{0, 0, 0, 0}; }
     }
+    else {
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      ps0[x] = 0.0f; ps1[x] = 0.0f;
+      for (int x = 0; x < 2; ++x) {
+        ps0[x] = 0.0f; ps1[x] = 0.0f;
+        pw_launder(ps0[x]); pw_launder(ps1[x]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { S[x][0][r] = -INFINITY; S[x][1][r] = -INFINITY; pw[x][r] = 0u; e0[x][r] = 0.0f; e1[x][r] = 0.0f; }
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[x][kb][r] = -INFINITY;
+          pw_launder(S[x][kb]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pwv[x][i] = wu32x4_t{0, 0, 0, 0}; pw_launder(pwv[x][i]); }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { er0[i] = 0.0f; er1[i] = 0.0f; pw_launder(er0[i]); pw_launder(er1[i]); }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
     }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
   };
 
   Item cur;
@@ -710,21 +772,21 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     constexpr int KA = kAK + 32 * kb + 4 * ks, QA = kAQ + 32 * x + 4 * ks;
     if constexpr (ks == 0) {
       if (__builtin_expect(!need_mask, 1)) {
-        ops::template qk_zero<KA, QA>(S[x][kb]);
+        ops::template qk_zero_ho<KA, QA>(S[x][kb]);
       } else {
-        const int rel = cur.lim[x] - t * kPwTile - 32 * kb - 4 * half;     // visible: (r & 3) + 8 (r >> 2) <= rel
+        const int rel = row_lim(cur, x) - t * kPwTile - 32 * kb - 4 * half;     // visible: (r & 3) + 8 (r >> 2) <= rel
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[x][kb][r] = ((r & 3) + 8 * (r >> 2) <= rel) ? 0.0f : -INFINITY;
-        ops::template qk_acc_masked<KA, QA>(S[x][kb]);
+        ops::template qk_acc_masked<KA, QA>(S[x][kb]);      // (an ordinary read-write operand: S is defined again here)
       }
     } else {
-      ops::template qk_acc<KA, QA>(S[x][kb]);
+      ops::template qk_acc_ho<KA, QA>(S[x][kb]);
     }
   };
   // MFMA g of O_x += V^T.P_x^T: output block g >> 2, k-step g & 3
   auto pv = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, b = g >> 2, sk = g & 3;
-    ops::template pv<kAO + 64 * x + 16 * b>(vfr[b][sk], wu32x4_t{pw[x][4 * sk], pw[x][4 * sk + 1], pw[x][4 * sk + 2], pw[x][4 * sk + 3]});
+    ops::template pv<kAO + 64 * x + 16 * b>(vfr[b][sk], pwv[x][sk]);
   };
   // exponentials, row sums and packing of sub-block x: 32 two- or three-instruction statements (per P word: exp exp,
   // and a few blocks later add add cvt) dealt over a window of 28 MFMA gaps. One statement per block: hipcc pads
@@ -744,8 +806,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       constexpr bool is_x = n < 2 || (n < 30 && ((n - 2) & 1) == 0);
       constexpr int j = n < 2 ? n : n >= 30 ? 14 + (n - 30) : is_x ? 2 * (1 + (n - 2) / 4) + (((n - 2) >> 1) & 1) : 2 * ((n - 2) / 4) + (((n - 2) >> 1) & 1);
       constexpr int kb = j >> 3, r = 2 * (j & 7);
-      if constexpr (is_x) a_exp2x2(e0[x][j], e1[x][j], S[x][kb][r], S[x][kb][r + 1]);
-      else ops::sum_pack(ps0[x], ps1[x], pw[x][j], e0[x][j], e1[x][j]);
+      // (see er0 / er1)
+      if constexpr (is_x) a_exp2x2_ho(er0[j % 3], er1[j % 3], S[x][kb][r], S[x][kb][r + 1]);
+      else ops::sum_pack_ho(ps0[x], ps1[x], pwv[x][j >> 2][j & 3], er0[j % 3], er1[j % 3]);
     });
   };
   // LDS reads. V(t)[b][sk]: two transposed 8-byte reads into one 4-register fragment
@@ -771,8 +834,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto qk16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kt = g >> 3, ks = (g >> 1) & 3, rt = g & 1;
     constexpr int KA = kAK + 16 * kt + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
-    if constexpr (ks == 0) pw_ops16::template qk_zero<KA, QA>(S16[x][rt][kt]);
-    else pw_ops16::template qk_acc<KA, QA>(S16[x][rt][kt]);
+    if constexpr (ks == 0) pw_ops16::template qk_zero_ho<KA, QA>(S16[x][rt][kt]);
+    else pw_ops16::template qk_acc_ho<KA, QA>(S16[x][rt][kt]);
   };
   // The mask of sub-block x, applied to the finished scores (sixteen accumulator set-ups per sub-block: a run-time branch
   // around each, as in the 32x32 form, costs a general iteration a third of its time). Runs right behind the segment
@@ -785,7 +848,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<2>([&](auto RT) __attribute__((always_inline)) {
       sfor<4>([&](auto KT) __attribute__((always_inline)) {
         constexpr int rt = decltype(RT)::value, kt = decltype(KT)::value;
-        const int rel = cur.lim[2 * x + rt] - t * kPwTile - 16 * kt - 4 * g4;     // visible: r <= rel
+        const int rel = row_lim(cur, 2 * x + rt) - t * kPwTile - 16 * kt - 4 * g4;     // visible: r <= rel
 #pragma unroll
         for (int r = 0; r < 4; ++r) S16[x][rt][kt][r] = (r <= rel) ? S16[x][rt][kt][r] : -INFINITY;
       });
@@ -793,8 +856,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
   // MFMA g (0..31) of O_x += V^T.P_x^T: d tile g >> 2, 32-key block (g >> 1) & 1, row tile g & 1
   auto pv16 = [&](auto X, auto GC) __attribute__((always_inline)) {
-    constexpr int x = decltype(X)::value, g = decltype(GC)::value, db = g >> 2, c = (g >> 1) & 1, rt = g & 1;
-    pw_ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], wu32x4_t{pw16[x][rt][c][0], pw16[x][rt][c][1], pw16[x][rt][c][2], pw16[x][rt][c][3]});
+    constexpr int x = decltype(X)::value, g = decltype(GC)::value, db = (g >> 2) & 7, c = (g >> 1) & 1, rt = g & 1;
+    if constexpr (g < 32) pw_ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]);
+    else pw_ops16::lsum_ho(L16[x][rt], ones16, pwv16[x][rt][c]);        // g = 32 .. 35: the row sums of this tile
   };
   // the 32 exponential / sum-and-pack blocks of sub-block x over a window of 56 gaps. Word j (0..15): row tile j >> 3,
   // key tile (j >> 1) & 3, register pair j & 1
@@ -809,8 +873,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       constexpr bool is_x = n < 2 || (n < 30 && ((n - 2) & 1) == 0);
       constexpr int j = n < 2 ? n : n >= 30 ? 14 + (n - 30) : is_x ? 2 * (1 + (n - 2) / 4) + (((n - 2) >> 1) & 1) : 2 * ((n - 2) / 4) + (((n - 2) >> 1) & 1);
       constexpr int rt = j >> 3, kt = (j >> 1) & 3, pr = j & 1;
-      if constexpr (is_x) a_exp2x2(e0[x][j], e1[x][j], S16[x][rt][kt][2 * pr], S16[x][rt][kt][2 * pr + 1]);
-      else ops::sum_pack(qs0[x][rt], qs1[x][rt], pw16[x][rt][kt >> 1][2 * (kt & 1) + pr], e0[x][j], e1[x][j]);
+      if constexpr (is_x) a_exp2x2_ho(er0[j % 3], er1[j % 3], S16[x][rt][kt][2 * pr], S16[x][rt][kt][2 * pr + 1]);
+      else pw_ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[j % 3], er1[j % 3]);
     });
   };
   // V(t) fragment (db, c): the 4 x 16 blocks at rows 32 c + 4 g4 and + 16
@@ -900,11 +964,11 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       });
       PW_SEG_STAMP(1);
       if constexpr (!steady) { if (__builtin_expect(need_mask, 0)) mask16(ic<0>{}, t); }
-      sfor<32>([&](auto GC) __attribute__((always_inline)) {
+      sfor<36>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         pv16(ic<1>{}, GC);
-        if constexpr (g >= 8) estream16(ic<0>{}, ic<g - 8>{});
-        if constexpr (g >= 3 && (g & 1) == 1) vread16(ic<((g - 3) / 2)>{}, ic<VR>{});
+        if constexpr (g >= 8 && g < 32) estream16(ic<0>{}, ic<(g >= 8 && g < 32) ? g - 8 : 0>{});
+        if constexpr (g >= 3 && g < 32 && (g & 1) == 1) vread16(ic<(g >= 3 && g < 32) ? ((g - 3) / 2) : 0>{}, ic<VR>{});
       });
       PW_SEG_STAMP(2);
       sfor<32>([&](auto GC) __attribute__((always_inline)) {
@@ -919,11 +983,11 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(vfr16[0][0]), "+v"(vfr16[0][1]), "+v"(vfr16[1][0]), "+v"(vfr16[1][1]), "+v"(vfr16[2][0]), "+v"(vfr16[2][1]), "+v"(vfr16[3][0]), "+v"(vfr16[3][1]),
                      "+v"(vfr16[4][0]), "+v"(vfr16[4][1]), "+v"(vfr16[5][0]), "+v"(vfr16[5][1]), "+v"(vfr16[6][0]), "+v"(vfr16[6][1]), "+v"(vfr16[7][0]), "+v"(vfr16[7][1]));
-      sfor<32>([&](auto GC) __attribute__((always_inline)) {
+      sfor<36>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         pv16(ic<0>{}, GC);
         if constexpr (g == 1) kread16(ic<15>{}, ic<KR>{});
-        if constexpr (g >= 8) estream16(ic<1>{}, ic<g - 8>{});
+        if constexpr (g >= 8 && g < 32) estream16(ic<1>{}, ic<(g >= 8 && g < 32) ? g - 8 : 0>{});
       });
       PW_SEG_STAMP(4);
     } else {
@@ -1010,49 +1074,69 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       const int r16o = lane_o & 15, g4o = lane_o >> 4;
       sfor<2>([&](auto SB) __attribute__((always_inline)) {
         constexpr int x = decltype(SB)::value;
+        float amax2[2] = {0.0f, 0.0f}, l2[2];
+        bool ok2[2];
+        // one row tile's 32 output registers: scaled, packed, to `store(db, words)`
+        auto tile_out = [&](auto RT, float inv, auto store) __attribute__((always_inline)) {
+          constexpr int rt = decltype(RT)::value;
+          sfor<8>([&](auto DB) __attribute__((always_inline)) {
+            constexpr int db = decltype(DB)::value, base = kAO + 64 * x + 32 * rt + 4 * db;
+            const float o0 = acc_read<base>(), o1 = acc_read<base + 1>(), o2 = acc_read<base + 2>(), o3 = acc_read<base + 3>();
+            pw_amax3(amax2[rt], o0, o1);
+            pw_amax3(amax2[rt], o2, o3);
+            store(DB, wu32x2_t{pw_pack<T>(o0 * inv, o1 * inv), pw_pack<T>(o2 * inv, o3 * inv)});   // d = 16 db + 4 g4 + 0..3
+          });
+        };
         sfor<2>([&](auto RT) __attribute__((always_inline)) {
           constexpr int rt = decltype(RT)::value;
-          float l = qs0[x][rt] + qs1[x][rt];                 // this lane's 16 keys of every tile; the row's other keys: lanes r16 + 16 g
-          l += __shfl_xor(l, 16, 64);
-          l += lane_xor32(l);
+          const float l = L16[x][rt][0];                     // the row's whole sum (of P as P.V saw it: rounded to bf16)
           int tok_local, hq;
           const bool row_ok = row_of(I, 2 * x + rt, tok_local, hq);
           if (I.lse_base && row_ok && g4o == 0)
             I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? __builtin_amdgcn_logf(l) * 0.6931471805599453f : -INFINITY;
           const float inv = (row_ok && l > 0.0f) ? 1.0f / l : 0.0f;
-          float amax = 0.0f;
-          uint16_t* op = I.out_base + (int64_t)(I.q_start + tok_local) * (int64_t)sa.out_st + (int64_t)hq * (int64_t)sa.out_sh + 4 * g4o;
-          sfor<8>([&](auto DB) __attribute__((always_inline)) {
-            constexpr int db = decltype(DB)::value, base = kAO + 64 * x + 32 * rt + 4 * db;
-            const float o0 = acc_read<base>(), o1 = acc_read<base + 1>(), o2 = acc_read<base + 2>(), o3 = acc_read<base + 3>();
-            pw_amax3(amax, o0, o1);
-            pw_amax3(amax, o2, o3);
-            const wu32x2_t w2 = wu32x2_t{pw_pack<T>(o0 * inv, o1 * inv), pw_pack<T>(o2 * inv, o3 * inv)};   // d = 16 db + 4 g4 + 0..3
-            if (wide_store) *(wu32x2_t*)(ost + (16 * rt + r16o) * kPwORS + (16 * db + 4 * g4o) * 2) = w2;
-            else if (row_ok) *(wu32x2_t*)(op + 16 * db) = w2;
-          });
-          amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-          amax = fmaxf(amax, lane_xor32(amax));
-          const bool has_keys = row_ok && I.tile_hi > I.tile_lo && I.lim[2 * x + rt] >= key_lo;
-          bad16[x][rt] = has_keys && !(l >= kPwSumLo && l <= kPwSumHi && amax < INFINITY);
-#ifdef PW_FORCE_FALLBACK
-          bad16[x][rt] = has_keys;
-#endif
+          l2[rt] = l; ok2[rt] = row_ok;
+          if (__builtin_expect(wide_store, 1)) {
+            tile_out(RT, inv, [&](auto DB, wu32x2_t w2) __attribute__((always_inline)) {
+              *(wu32x2_t*)(ost + (16 * rt + r16o) * kPwORS + (16 * decltype(DB)::value + 4 * g4o) * 2) = w2;
+            });
+          } else {
+            uint16_t* op = I.out_base + (int64_t)(I.q_start + tok_local) * (int64_t)sa.out_st + (int64_t)hq * (int64_t)sa.out_sh + 4 * g4o;
+            tile_out(RT, inv, [&](auto DB, wu32x2_t w2) __attribute__((always_inline)) {
+              if (row_ok) *(wu32x2_t*)(op + 16 * decltype(DB)::value) = w2;
+            });
+          }
         });
-        if (wide_store) {
+        if (__builtin_expect(wide_store, 1)) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           wu32x4_t rows[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) rows[j] = *(const wu32x4_t*)(ost + (4 * j + orow) * kPwORS + och * 16);
           typedef __attribute__((address_space(1))) wu32x4_t* grow_t;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          auto row_off = [&](int j, uint32_t& tq) {
             const uint32_t m = (uint32_t)(wave * 64 + x * 32 + 4 * j + orow);
-            const uint32_t tq = sa.g_shift >= 0 ? (m >> sa.g_shift) : ((m * g_inv) >> 16);
-            const uint32_t off = tq * st_b + (m - tq * (uint32_t)G) * sh_b + (uint32_t)och * 16u;
-            if (whole_block || tq < tok_left) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off));
+            tq = sa.g_shift >= 0 ? (m >> sa.g_shift) : ((m * g_inv) >> 16);
+            return tq * st_b + (m - tq * (uint32_t)G) * sh_b + (uint32_t)och * 16u;
+          };
+          if (__builtin_expect(whole_block, 1)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); if (tq < tok_left) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
           }
         }
+        // the two row tiles' magnitude checks, after the stores are on their way (four cross-lane steps in one go)
+        float am0 = fmaxf(amax2[0], __shfl_xor(amax2[0], 16, 64)), am1 = fmaxf(amax2[1], __shfl_xor(amax2[1], 16, 64));
+        am0 = fmaxf(am0, lane_xor32(am0)); am1 = fmaxf(am1, lane_xor32(am1));
+        sfor<2>([&](auto RT) __attribute__((always_inline)) {
+          constexpr int rt = decltype(RT)::value;
+          const bool has_keys = ok2[rt] && I.tile_hi > I.tile_lo && row_lim(I, 2 * x + rt) >= key_lo;
+          bad16[x][rt] = has_keys && !(l2[rt] >= kPwSumLo && l2[rt] <= kPwSumHi && (rt ? am1 : am0) < INFINITY);
+#ifdef PW_FORCE_FALLBACK
+          bad16[x][rt] = has_keys;
+#endif
+        });
       });
     } else
     sfor<2>([&](auto SB) __attribute__((always_inline)) {
@@ -1108,7 +1192,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         });
       }
       amax = fmaxf(amax, lane_xor32(amax));
-      const bool has_keys = row_ok && I.tile_hi > I.tile_lo && I.lim[sb] >= key_lo;
+      const bool has_keys = row_ok && I.tile_hi > I.tile_lo && row_lim(I, sb) >= key_lo;
       bad[sb] = has_keys && !(l >= kPwSumLo && l <= kPwSumHi && amax < INFINITY);   // a NaN sum fails both comparisons
 #ifdef PW_FORCE_FALLBACK
       bad[sb] = has_keys;                          // diagnostic build: every row through the per-row routine
@@ -1195,7 +1279,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         if constexpr (M16) {
           sfor<32>([&](auto GC) __attribute__((always_inline)) { estream16(ic<1>{}, ic<24 + decltype(GC)::value>{}); });
           asm volatile("s_nop 1");
-          sfor<32>([&](auto GC) __attribute__((always_inline)) { pv16(ic<1>{}, GC); });
+          sfor<36>([&](auto GC) __attribute__((always_inline)) { pv16(ic<1>{}, GC); });
         } else {
           sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
           asm volatile("s_nop 1");
@@ -1323,7 +1407,12 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   const int per_cu = std::max(1, cus / p.num_kv_heads);
   a.slots = std::max(1, std::min(items_per_head, slots_env > 0 ? slots_env : ((a.tickets || p.num_seqs == 1) ? per_cu : items_per_head)));
   const size_t lds = kPwLds;
-  static const bool m16 = [] { const char* e = getenv("MI355_PW_M16"); return e && e[0] == '1'; }();   // A/B: the 16x16x32 instantiation
+  // Which matrix instruction: the 16x16x32 instantiation draws less power per flop (the chip holds ~2.33 GHz under it
+  // instead of ~2.1) but issues twice as many matrix instructions, and its work items cost ~0.5 us more outside the tile
+  // loop. It wins where the loops are long (1 x 4096: +1.9 %, 1 x 16384: +2.8 %, 16 x 4096: +0.8 %) and loses on
+  // short sequences (4 x 2048: -2.5 %). MI355_PW_M16=0 / 1 pins either one (measurements, tests).
+  static const int m16_env = [] { const char* e = getenv("MI355_PW_M16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool m16 = m16_env >= 0 ? m16_env == 1 : p.max_seqlen_k >= 4096;
   if (m16) {
     static std::atomic<uint64_t> lds_opt_in16{0};
     const int rc1 = ensure_dynamic_lds((const void*)prefill_pw_kernel<T, true>, (int)kPwLds, lds_opt_in16, "hipFuncSetAttribute(prefill_pw m16)");
