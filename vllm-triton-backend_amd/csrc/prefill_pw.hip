@@ -103,6 +103,21 @@ __device__ __forceinline__ void a_exp2x2(float& r0, float& r1, float x0, float x
 __device__ __forceinline__ void a_exp2x2_ho(float r0, float r1, float x0, float x1) {
   asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" :: "v"(r0), "v"(r1), "v"(x0), "v"(x1));
 }
+__device__ __forceinline__ void a_exp_ho(float r, float x) { asm volatile("v_exp_f32 %0, %1" :: "v"(r), "v"(x)); }
+// instruction q (0..47) of a sub-block's exponential / pack stream in the 16x16x32 form: kind 0 / 1 = exponential of the
+// word's first / second score, 2 = pack; j = the word
+struct PwEOp { int kind, j; };
+constexpr PwEOp pw_eop(int q) {
+  int acc = 0;
+  for (int n = 0; n < 32; ++n) {
+    const bool is_x = n < 2 || (n < 30 && ((n - 2) & 1) == 0);
+    const int j = n < 2 ? n : n >= 30 ? 14 + (n - 30) : is_x ? 2 * (1 + (n - 2) / 4) + (((n - 2) >> 1) & 1) : 2 * ((n - 2) / 4) + (((n - 2) >> 1) & 1);
+    const int cnt = is_x ? 2 : 1;
+    if (q < acc + cnt) return PwEOp{is_x ? q - acc : 2, j};
+    acc += cnt;
+  }
+  return PwEOp{-1, 0};
+}
 // a value the compiler knows nothing about from here on (it stays where it is: no instruction)
 template <typename V> __device__ __forceinline__ void pw_launder(V& v) { asm volatile("" : "+v"(v)); }
 
@@ -860,20 +875,21 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     if constexpr (g < 32) pw_ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]);
     else pw_ops16::lsum_ho(L16[x][rt], ones16, pwv16[x][rt][c]);        // g = 32 .. 35: the row sums of this tile
   };
-  // the 32 exponential / sum-and-pack blocks of sub-block x over a window of 56 gaps. Word j (0..15): row tile j >> 3,
-  // key tile (j >> 1) & 3, register pair j & 1
+  // The 48 exponential / pack instructions of sub-block x, one per matrix-instruction gap, over a window of 56 gaps (a
+  // 16-cycle matrix instruction leaves this wave ~7 cycles of issue in its shadow: one v_exp_f32 fills it, two stall the
+  // pipe - tools/probes/issue_model.hip). Word j (0..15): row tile j >> 3, key tile (j >> 1) & 3, register pair j & 1;
+  // order: the 32 blocks X X | X P X P ... | P P of the 32x32 form (X = a word's two exponentials, P = its pack).
   auto estream16 = [&](auto X, auto WC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, w = decltype(WC)::value;
-    constexpr int n0 = w * 32 / 56, n1 = (w + 1) * 32 / 56;
+    constexpr int q0 = w * 48 / 56, q1 = (w + 1) * 48 / 56;
 #ifdef PW_ABL_E
     return;
 #endif
-    sfor<n1 - n0>([&](auto NC) __attribute__((always_inline)) {
-      constexpr int n = n0 + decltype(NC)::value;
-      constexpr bool is_x = n < 2 || (n < 30 && ((n - 2) & 1) == 0);
-      constexpr int j = n < 2 ? n : n >= 30 ? 14 + (n - 30) : is_x ? 2 * (1 + (n - 2) / 4) + (((n - 2) >> 1) & 1) : 2 * ((n - 2) / 4) + (((n - 2) >> 1) & 1);
-      constexpr int rt = j >> 3, kt = (j >> 1) & 3, pr = j & 1;
-      if constexpr (is_x) a_exp2x2_ho(er0[j % 3], er1[j % 3], S16[x][rt][kt][2 * pr], S16[x][rt][kt][2 * pr + 1]);
+    sfor<q1 - q0>([&](auto QC) __attribute__((always_inline)) {
+      constexpr PwEOp op = pw_eop(q0 + decltype(QC)::value);
+      constexpr int j = op.j, rt = j >> 3, kt = (j >> 1) & 3, pr = j & 1;
+      if constexpr (op.kind == 0) a_exp_ho(er0[j % 3], S16[x][rt][kt][2 * pr]);
+      else if constexpr (op.kind == 1) a_exp_ho(er1[j % 3], S16[x][rt][kt][2 * pr + 1]);
       else pw_ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[j % 3], er1[j % 3]);
     });
   };
