@@ -118,6 +118,23 @@ constexpr PwEOp pw_eop(int q) {
   }
   return PwEOp{-1, 0};
 }
+// which of the 26 stream instructions left for a P.V segment goes into its gap g: the even gaps and 1, 7, 13, 19, 25, 31, 33, 35
+constexpr int pw_pv_slot(int g) {
+  int n = 0;
+  for (int h = 0; h < 36; ++h) {
+    const bool used = (h & 1) == 0 || h == 1 || h == 7 || h == 13 || h == 19 || h == 25 || h == 31 || h == 33 || h == 35;
+    if (h == g) return used ? n : -1;
+    n += used ? 1 : 0;
+  }
+  return -1;
+}
+// the K(t+1) fragment read that goes into gap g of segment 4 (fragments 4 .. 15; 0 .. 3 are read in segment 3): the odd
+// gaps the stream leaves free, then 7 and 13
+constexpr int pw_kread_slot(int g) {
+  const int gaps[12] = {3, 5, 7, 9, 11, 13, 15, 17, 21, 23, 27, 29};
+  for (int i = 0; i < 12; ++i) if (gaps[i] == g) return 4 + i;
+  return -1;
+}
 // a value the compiler knows nothing about from here on (it stays where it is: no instruction)
 template <typename V> __device__ __forceinline__ void pw_launder(V& v) { asm volatile("" : "+v"(v)); }
 
@@ -875,23 +892,34 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     if constexpr (g < 32) pw_ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]);
     else pw_ops16::lsum_ho(L16[x][rt], ones16, pwv16[x][rt][c]);        // g = 32 .. 35: the row sums of this tile
   };
-  // The 48 exponential / pack instructions of sub-block x, one per matrix-instruction gap, over a window of 56 gaps (a
-  // 16-cycle matrix instruction leaves this wave ~7 cycles of issue in its shadow: one v_exp_f32 fills it, two stall the
-  // pipe - tools/probes/issue_model.hip). Word j (0..15): row tile j >> 3, key tile (j >> 1) & 3, register pair j & 1;
-  // order: the 32 blocks X X | X P X P ... | P P of the 32x32 form (X = a word's two exponentials, P = its pack).
-  auto estream16 = [&](auto X, auto WC) __attribute__((always_inline)) {
-    constexpr int x = decltype(X)::value, w = decltype(WC)::value;
-    constexpr int q0 = w * 48 / 56, q1 = (w + 1) * 48 / 56;
+  // Instruction q (0..47) of sub-block x's exponential / pack stream. A 16-cycle matrix instruction leaves this wave ~7
+  // cycles of issue in its shadow: one v_exp_f32 fills it, two stall the pipe (tools/probes/issue_model.hip), so the stream
+  // is dealt one instruction per gap. Words in key-tile order (w: key tile w >> 2, row tile (w >> 1) & 1, register pair
+  // w & 1), blocks X X | X P X P ... | P P as in the 32x32 form: word w's exponentials are instructions 3 w - 2, 3 w - 1,
+  // after the score tile 8 (w >> 2) + 10 gaps into the S_x segment (two matrix instructions behind the tile's last one).
+  auto eop16 = [&](auto X, auto QC) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value;
+    constexpr PwEOp op = pw_eop(decltype(QC)::value);
+    constexpr int w = op.j, kt = w >> 2, rt = (w >> 1) & 1, pr = w & 1;
 #ifdef PW_ABL_E
     return;
 #endif
-    sfor<q1 - q0>([&](auto QC) __attribute__((always_inline)) {
-      constexpr PwEOp op = pw_eop(q0 + decltype(QC)::value);
-      constexpr int j = op.j, rt = j >> 3, kt = (j >> 1) & 3, pr = j & 1;
-      if constexpr (op.kind == 0) a_exp_ho(er0[j % 3], S16[x][rt][kt][2 * pr]);
-      else if constexpr (op.kind == 1) a_exp_ho(er1[j % 3], S16[x][rt][kt][2 * pr + 1]);
-      else pw_ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[j % 3], er1[j % 3]);
-    });
+    if constexpr (op.kind == 0) a_exp_ho(er0[w % 3], S16[x][rt][kt][2 * pr]);
+    else if constexpr (op.kind == 1) a_exp_ho(er1[w % 3], S16[x][rt][kt][2 * pr + 1]);
+    else if constexpr (op.kind == 2) pw_ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[w % 3], er1[w % 3]);
+  };
+  // the stream's instructions in a P.V segment's gap g (36 gaps). Steady iterations: 22 went out during the S_x segment,
+  // the other 26 take the even gaps and eight odd ones (the odd gaps carry the LDS reads); general iterations: all 48
+  // behind the mask, four per three gaps.
+  auto estream_pv = [&](auto X, auto GC, auto LATE) __attribute__((always_inline)) {
+    constexpr int g = decltype(GC)::value;
+    if constexpr (decltype(LATE)::value != 0) {
+      constexpr int q0 = g * 48 / 36, q1 = (g + 1) * 48 / 36;
+      sfor<q1 - q0>([&](auto I) __attribute__((always_inline)) { eop16(X, ic<q0 + decltype(I)::value>{}); });
+    } else {
+      constexpr int slot = pw_pv_slot(g);
+      if constexpr (slot >= 0) eop16(X, ic<(slot >= 0 ? 22 + slot : 0)>{});
+    }
   };
   // V(t) fragment (db, c): the 4 x 16 blocks at rows 32 c + 4 g4 and + 16
   auto vread16 = [&](auto FC, auto SLOT) __attribute__((always_inline)) {
@@ -958,8 +986,11 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #define PW_DMA_AT(seg, g) if constexpr ((seg) == 1 && (g) >= 2 && (g) < 10) dma_piece(ic<((seg) == 1 && (g) >= 2 && (g) < 10) ? (g) - 2 : 0>{})
 #endif
     if constexpr (M16) {
-      // 32 matrix instructions of 16 cycles per segment. Fragment f = g >> 1 is read by the instructions 2 f and 2 f + 1
-      // (row tiles 0, 1) and re-loaded three gaps later: V(t) in segment 2 (P.V of B over V(t-1)), K(t+1) in segment 3.
+      // 32 / 36 matrix instructions of 16 cycles per segment. S_A | O_B += P_B(t-1), l_B | S_B | O_A += P_A(t), l_A. Beside them,
+      // one instruction per gap where it can be had: A's exponentials from gap 10 of segment 1 on (its first score tile is
+      // done) through segment 2, B's from gap 10 of segment 3 through segment 4; the LDS-DMA in gaps 2 .. 9 of segment 1;
+      // V(t) fragment f (read by instructions 2 f, 2 f + 1 of segment 2) re-loaded in the odd gaps from 2 f + 3 on; K(t+1)
+      // fragments 0 .. 3 in segment 3, the others in the gaps segment 4's stream leaves free.
       sfor<32>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         qk16(ic<0>{}, GC);
@@ -968,31 +999,34 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           kb64 = group_base_fast(cur, t + 3, pg_k, ic<0>{});
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (steady && g == 2) {
+        if constexpr (steady && g == 1) {
           __builtin_amdgcn_sched_barrier(0);
           vb64 = group_base_fast(cur, t + 2, pg_v, ic<1>{});
           pg_v = pg_k;
           pw_sload(pg_k, cur.bt64, entry_off_fast(t + 4));
           __builtin_amdgcn_sched_barrier(0);
         }
-        estream16(ic<1>{}, ic<24 + g>{});
-        if constexpr (g >= 4 && g < 20 && (g & 1) == 0) dma_piece(ic<((g >= 4 && g < 20) ? ((g - 4) / 2) : 0)>{});
+        // (the four waves issue their pieces at the same time and the CU's address unit takes 64 cycles per round of four:
+        // eight pieces in eight consecutive gaps stall the issue - K(t+3) here, V(t+2) in segment 3, every other gap)
+        if constexpr (g >= 2 && g < 10 && (g & 1) == 0) dma_piece(ic<((g >= 2 && g < 10) ? (g - 2) / 2 : 0)>{});
+        if constexpr (steady && g >= 10) eop16(ic<0>{}, ic<(g >= 10 ? g - 10 : 0)>{});
       });
       PW_SEG_STAMP(1);
       if constexpr (!steady) { if (__builtin_expect(need_mask, 0)) mask16(ic<0>{}, t); }
       sfor<36>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         pv16(ic<1>{}, GC);
-        if constexpr (g >= 8 && g < 32) estream16(ic<0>{}, ic<(g >= 8 && g < 32) ? g - 8 : 0>{});
+        estream_pv(ic<0>{}, GC, ic<(steady ? 0 : 1)>{});
         if constexpr (g >= 3 && g < 32 && (g & 1) == 1) vread16(ic<(g >= 3 && g < 32) ? ((g - 3) / 2) : 0>{}, ic<VR>{});
       });
       PW_SEG_STAMP(2);
       sfor<32>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         qk16(ic<1>{}, GC);
-        estream16(ic<0>{}, ic<24 + g>{});
+        if constexpr (g < 8 && (g & 1) == 0) dma_piece(ic<(g < 8 ? 4 + g / 2 : 4)>{});
         if constexpr (g == 1) vread16(ic<15>{}, ic<VR>{});
-        if constexpr (g >= 3 && (g & 1) == 1) kread16(ic<((g - 3) / 2)>{}, ic<KR>{});
+        if constexpr (g >= 3 && g < 10 && (g & 1) == 1) kread16(ic<((g >= 3 && g < 10) ? (g - 3) / 2 : 0)>{}, ic<KR>{});
+        if constexpr (steady && g >= 10) eop16(ic<1>{}, ic<(g >= 10 ? g - 10 : 0)>{});
       });
       PW_SEG_STAMP(3);
       if constexpr (!steady) { if (__builtin_expect(need_mask, 0)) mask16(ic<1>{}, t); }
@@ -1002,8 +1036,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       sfor<36>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         pv16(ic<0>{}, GC);
-        if constexpr (g == 1) kread16(ic<15>{}, ic<KR>{});
-        if constexpr (g >= 8 && g < 32) estream16(ic<1>{}, ic<(g >= 8 && g < 32) ? g - 8 : 0>{});
+        estream_pv(ic<1>{}, GC, ic<(steady ? 0 : 1)>{});
+        constexpr int kf = pw_kread_slot(g);
+        if constexpr (kf >= 0) kread16(ic<(kf >= 0 ? kf : 0)>{}, ic<KR>{});
       });
       PW_SEG_STAMP(4);
     } else {
@@ -1293,8 +1328,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       // drain: sub-block B of the wave's last tile
       if (own_hi > tile_lo) {
         if constexpr (M16) {
-          sfor<32>([&](auto GC) __attribute__((always_inline)) { estream16(ic<1>{}, ic<24 + decltype(GC)::value>{}); });
-          asm volatile("s_nop 1");
+          asm volatile("s_nop 1");           // (B's exponentials and packs ended with its iteration)
           sfor<36>([&](auto GC) __attribute__((always_inline)) { pv16(ic<1>{}, GC); });
         } else {
           sfor<16>([&](auto GC) __attribute__((always_inline)) { estream(ic<1>{}, ic<12 + decltype(GC)::value>{}); });
