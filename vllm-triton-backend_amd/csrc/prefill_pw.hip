@@ -1457,12 +1457,11 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   const int per_cu = std::max(1, cus / p.num_kv_heads);
   a.slots = std::max(1, std::min(items_per_head, slots_env > 0 ? slots_env : ((a.tickets || p.num_seqs == 1) ? per_cu : items_per_head)));
   const size_t lds = kPwLds;
-  // Which matrix instruction: the 16x16x32 instantiation draws less power per flop (the chip holds ~2.33 GHz under it
-  // instead of ~2.1) but issues twice as many matrix instructions, and its work items cost ~0.5 us more outside the tile
-  // loop. It wins where the loops are long (1 x 4096: +1.9 %, 1 x 16384: +2.8 %, 16 x 4096: +0.8 %) and loses on
-  // short sequences (4 x 2048: -2.5 %). MI355_PW_M16=0 / 1 pins either one (measurements, tests).
-  static const int m16_env = [] { const char* e = getenv("MI355_PW_M16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-  const bool m16 = m16_env >= 0 ? m16_env == 1 : p.max_seqlen_k >= 4096;
+  // Which matrix instruction: the 16x16x32 instantiation (the product) draws less power per flop - the chip holds
+  // ~2.2-2.3 GHz under it instead of ~2.0-2.1 - at the price of twice as many matrix instructions to issue; with its
+  // exponentials dealt one per gap it is ahead on every shape this kernel is chosen for (same box: 1 x 4096 +6.9 %,
+  // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
+  static const bool m16 = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
   if (m16) {
     static std::atomic<uint64_t> lds_opt_in16{0};
     const int rc1 = ensure_dynamic_lds((const void*)prefill_pw_kernel<T, true>, (int)kPwLds, lds_opt_in16, "hipFuncSetAttribute(prefill_pw m16)");
