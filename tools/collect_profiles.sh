@@ -6,6 +6,7 @@ set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$REPO/gpurun_out/prof_r02}
 mkdir -p "$OUT"
+OUT=$(cd "$OUT" && pwd)                  # (a relative path would be lost with the cd below)
 cd /tmp && export TMPDIR=/tmp
 echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes)"
 python3 $REPO/tools/collect_traffic.py $OUT/traffic > $OUT/traffic.log 2>&1; tail -60 $OUT/traffic.log
