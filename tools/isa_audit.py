@@ -16,6 +16,7 @@ def main():
         print("==", names[0])
         inasm = False
         cnt, outside, waits = {}, [], []
+        regions, reg = [], [0, 0, 0]            # between s_barriers: [asm MFMAs, compiler s_nops, compiler v_movs]
         for i, l in enumerate(chunk.split("\n")):
             t = l.strip()
             if t.startswith(";;#ASMSTART"):
@@ -33,9 +34,16 @@ def main():
                 outside.append((i, t))
             if not inasm and op == "s_waitcnt":
                 waits.append((i, t))
+            if op == "s_barrier":
+                regions.append(tuple(reg))
+                reg = [0, 0, 0]
+            reg[0] += inasm and op.startswith("v_mfma")
+            reg[1] += (not inasm) and op == "s_nop"
+            reg[2] += (not inasm) and op.startswith("v_mov_b")
         for k in sorted(cnt, key=lambda x: -cnt[x])[:70]:
             print(f"  {k:34s}{cnt[k]}")
         print("compiler accvgpr/scratch outside asm:", len(outside), outside[:8])
+        print("regions between barriers (asm MFMAs, compiler s_nops, compiler v_movs):", regions)
         print("compiler s_waitcnt:", len(waits))
         for w in waits:
             print("   ", w)
