@@ -587,7 +587,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     asm volatile("" : "+v"(lo));
     const int r4 = lo >> 4, c16 = lo & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + ((c16 ^ (((R & 3) << 2) | ((R >> 2) & 3))) << 4)); }
+    // V's chunk swizzle follows the transposed read of the instantiation: half a wave of it covers rows 0..3 x four chunks
+    // (32x32x16 form: f = 4 (R & 3) | (R >> 2) & 3 keeps the rows apart) or rows 0..7 x two chunks (16x16x32 form: f = 2 (R & 7);
+    // the other form's f there puts rows r and r + 4 on the same banks: 34 % of LDS-active cycles were conflicts)
+    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; const int f = M16 ? 2 * (R & 7) : (((R & 3) << 2) | ((R >> 2) & 3)); voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + ((c16 ^ f) << 4)); }
   };
   set_k_offsets(15);
   set_v_offsets(15);
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   uint32_t v_rd16[8];
 #pragma unroll
   for (int db = 0; db < 8; ++db) {
-    const int row = 4 * g4 + q4, f = ((row & 3) << 2) | ((row >> 2) & 3);
+    const int row = 4 * g4 + q4, f = 2 * (row & 7);
     v_rd16[db] = (uint32_t)(kLdsV + row * ROWB + (((2 * db + (pp >> 1)) ^ f) << 4) + 8 * (pp & 1));
   }
 
