@@ -366,7 +366,7 @@ def main():
                            "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
                 "roofline": roofline("mfma", pf_ach, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", pf["w"], pf, {
                     "algorithmic_flops_per_launch": pf["w"]["flops"],
-                    "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.0-2.2 GHz (in-kernel clock, "
+                    "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.1-2.35 GHz (in-kernel clock, "
                             "tools/pw_clock.py, profiles/r02/pw_clock.log)"}),
             }
 
