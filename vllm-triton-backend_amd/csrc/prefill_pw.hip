@@ -37,8 +37,15 @@
 //     no register to spare for values hoisted out of the item loop (tools/isa_audit.py must report no compiler
 //     accumulator-register or scratch use).
 //
-// MFMA orientation, the in-register softmax layout and the LDS swizzles are those of prefill_dma_kernel
-// (prefill_mfma.hip).
+//   * TWO instantiations. The text above describes the 32x32x16 one (M16 = false: MFMA orientation, in-register softmax
+//     layout and LDS swizzles of prefill_dma_kernel, prefill_mfma.hip). The product is M16 = true: both contractions on
+//     v_mfma_f32_16x16x32_bf16 - the chip runs this kernel at its power limit and holds a higher clock under that shape -
+//     with what its doubled matrix-instruction count asks for: the row sums on the matrix pipe (l += 1.P^T), the
+//     exponentials dealt ONE per 16-cycle gap from the moment a sub-block's first score tile is done, LDS-DMA split over
+//     two segments, a V swizzle that matches its transposed reads. One wave per SIMD pays ~4 cycles of issue for every
+//     instruction, ~9 for a matrix instruction, with nothing overlapping inside the wave (tools/probes/issue_model.hip).
+//   * the tile loop's VGPR state (S, the ring of exponentials, row sums, P) is HAND-OWNED: its asm statements name those
+//     registers as inputs and write them; see the state block in the kernel.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
