@@ -86,7 +86,9 @@ def test_prefill_64_rows_per_wave_kernel_on_the_16x16x32_matrix_instruction():
           "tests/test_gpu_prefill_ksplit.py", "tests/test_gpu_fuzz.py"],
          keyword="(mixed and 128 and dtype0) or outside or ksplit or key_split or agree")
     _run({"MI355_PREFILL": "pw", "MI355_PW_M16": "0"},
-         ["tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties", "tests/test_gpu_prefill_ksplit.py"])
+         ["tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties", "tests/test_gpu_prefill_ksplit.py", "tests/test_gpu_lse.py"])
+    # the row sums of the 16x16x32 form come off the matrix pipe: its lse on every shape of the lse tests
+    _run({"MI355_PREFILL": "pw", "MI355_PW_M16": "1"}, ["tests/test_gpu_lse.py"])
 
 
 def test_prefill_8_wave_kernel_with_rows_outside_its_first_reference():
