@@ -60,6 +60,15 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out) {
   BODY_LOOP(EXP("8") ADD("9") ADD("10") ADD("11"))                           // 23: exp + 3 add alone
   BODY_LOOP("s_nop 0\n\t")                                                  // 24: s_nop 0
   BODY_LOOP(M16("0:3") "s_nop 0\n\t" M16("4:7") "s_nop 0\n\t")               // 25: (16x16x32 + s_nop 0) x2
+  // accumulators in VGPRs, A / B in accumulator registers (the S = K.Q^T chains of the kernel) and the other way round (P.V)
+#define M16V(acc) "v_mfma_f32_16x16x32_bf16 v[" acc "], a[128:131], a[132:135], v[" acc "]\n\t"
+#define M16P(acc) "v_mfma_f32_16x16x32_bf16 a[" acc "], v[24:27], v[28:31], a[" acc "]\n\t"
+  BODY_LOOP(M16V("16:19") M16V("20:23"))                                     // 26: S-style, 2 chains
+  BODY_LOOP(M16V("16:19") M16V("20:23") M16V("32:35") M16V("36:39"))          // 27: S-style, 4 chains (per 4)
+  BODY_LOOP(M16P("0:3") M16P("4:7"))                                          // 28: P.V-style, 2 chains
+  BODY_LOOP(M16V("16:19") EXP("8") M16V("20:23") EXP("9"))                     // 29: S-style 2 chains + exp each
+  BODY_LOOP(M16P("0:3") EXP("8") M16P("4:7") "v_cvt_pk_bf16_f32 v9, v0, v1\n\t")   // 30: P.V-style 2 chains + exp / cvt
+  BODY_LOOP(M16V("16:19") M16V("20:23") M16V("32:35") M16V("36:39") M16V("40:43") M16V("44:47") M16V("16:19") M16V("20:23"))   // 31: S-style, zero-free chain of 8 slots, 6 accumulators
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
@@ -76,7 +85,9 @@ int main() {
                          "2 chains 16x16x32 (per 2)", "16x16x32 back-to-back chain", "32x32x16 back-to-back chain", "(16x16x32 + exp) x2", "(16x16x32 + 2 exp) x2",
                          "(16x16x32 + 3 add) x2", "(16x16x32 + 2 add) x2", "(16x16x32 + exp + add) x2", "(16x16x32 + exp + 2 add) x2", "32x32x16 + 2 exp",
                          "32x32x16 + 2 exp + 2 add + cvt", "32x32x16 + 7 add", "(16x16x32 + ds_read_b128) x2", "(16x16x32 + 2 tr reads) x2",
-                         "(16x16x32 + pk_add + cvt) x2", "32x32x16 + 2 exp + pk_add + cvt + tr read", "exp + add", "exp + 3 add", "s_nop 0", "(16x16x32 + s_nop 0) x2"};
-  for (int i = 0; i < 26; ++i) printf("%2d %-46s %8.1f cycles per group\n", i, names[i], (double)h[i] / 256.0);
+                         "(16x16x32 + pk_add + cvt) x2", "32x32x16 + 2 exp + pk_add + cvt + tr read", "exp + add", "exp + 3 add", "s_nop 0", "(16x16x32 + s_nop 0) x2",
+                         "S-style 16x16x32 (acc in VGPRs), 2 chains (per 2)", "S-style, 4 chains (per 4)", "P.V-style (A / B in VGPRs), 2 chains (per 2)",
+                         "S-style 2 chains + exp each (per 2)", "P.V-style 2 chains + exp / cvt (per 2)", "S-style, 8 in a row over 6 accumulators (per 8)"};
+  for (int i = 0; i < 32; ++i) printf("%2d %-46s %8.1f cycles per group\n", i, names[i], (double)h[i] / 256.0);
   return 0;
 }
