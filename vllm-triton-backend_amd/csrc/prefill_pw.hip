@@ -142,6 +142,31 @@ constexpr int pw_kread_slot(int g) {
   for (int i = 0; i < 12; ++i) if (gaps[i] == g) return 4 + i;
   return -1;
 }
+// compile-time checks of the three tables above
+constexpr bool pw_tables_ok() {
+  int exp_lo[16] = {}, exp_hi[16] = {}, pack[16] = {};
+  for (int q = 0; q < 48; ++q) {
+    const PwEOp op = pw_eop(q);
+    if (op.j < 0 || op.j > 15 || op.kind < 0 || op.kind > 2) return false;
+    (op.kind == 0 ? exp_lo : op.kind == 1 ? exp_hi : pack)[op.j] = q + 1;
+    // a word's exponentials are dealt in the S segment from gap 10 on, one per gap: its score tile (8 (w >> 2) + 7 is the
+    // tile's last matrix instruction) must be two instructions behind by then
+    if (op.kind < 2 && q < 22 && q + 10 < 8 * (op.j >> 2) + 10) return false;
+  }
+  for (int w = 0; w < 16; ++w) {
+    if (!exp_lo[w] || !exp_hi[w] || !pack[w] || exp_hi[w] != exp_lo[w] + 1 || pack[w] < exp_hi[w] + 2) return false;
+    // ring of three: word w + 3's exponentials overwrite word w's registers, after word w's pack
+    if (w + 3 < 16 && exp_lo[w + 3] < pack[w]) return false;
+  }
+  int slots = 0, kfrags = 0;
+  for (int g = 0; g < 36; ++g) {
+    const int sl = pw_pv_slot(g), kf = pw_kread_slot(g);
+    if (sl >= 0) { if (sl != slots) return false; ++slots; }
+    if (kf >= 0) { if (kf != 4 + kfrags || g < 0) return false; ++kfrags; }
+  }
+  return slots == 26 && kfrags == 12;
+}
+static_assert(pw_tables_ok(), "prefill_pw_kernel: the 16x16x32 form's instruction tables are inconsistent");
 // a value the compiler knows nothing about from here on (it stays where it is: no instruction)
 template <typename V> __device__ __forceinline__ void pw_launder(V& v) { asm volatile("" : "+v"(v)); }
 
