@@ -26,7 +26,21 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 301 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 400 /* major*10000 + minor*100 + patch */
+/*
+ * Version notes (what a caller written against an older header must know)
+ *   0.4.0  mi355_attn_params grew at its END (slot_mapping, slot_mapping_i32, new_kv_all_rows, reserved2): zero the
+ *          struct before filling it and nothing changes. A fused decode write (write_new_kv) now honours
+ *          slot_mapping[i] < 0 (padding row: the cache is not written) when a slot mapping is handed in.
+ *   0.3.1  WORKSPACE CONTRACT: a prefill call for which mi355_attn_workspace_bytes() answers 256 KiB (the bf16 / f16
+ *          D = 128 fast path) treats the head of the workspace as TICKET COUNTERS that must be zero on entry and are
+ *          left zero on exit. Calls of that kind used to need no workspace and ignored the pointer; a caller that
+ *          hands such calls a non-zeroed scratch must now either zero-fill it once (as the header always asked for
+ *          the decode counters) or pass NULL / 0, which selects the static work-item deal. A launch that was aborted
+ *          mid-kernel leaves the counters non-zero: zero-fill the workspace again after a device error.
+ *   0.3.0  write_new_kv (fused cache write of a decode step), non_causal.
+ *   0.2.0  lse output.
+ */
 
 #if defined(__GNUC__)
 #define MI355_API __attribute__((visibility("default")))
@@ -159,6 +173,20 @@ typedef struct mi355_attn_params {
    * 1: every query row sees ALL seqused_k keys of its sequence (prefill_flash_attention(causal=False),
    * triton_flash_attention.py:1326-1484; no sliding window / ALiBi with it). Served by the shape-agnostic kernel. */
   int32_t non_causal;
+
+  /* library version >= 0.4.0 */
+  /* With write_new_kv: the step's slot mapping as vLLM hands it to reshape_and_cache_flash (triton_attn.py:396-405),
+   * int64 or int32, [num_tokens]; at most one non-NULL. Row i's K/V is stored only if its slot is >= 0: a negative slot
+   * marks a padding row of a captured graph (triton_attn.py:149-151) and leaves the cache untouched, whatever
+   * seqused_k / block_table hold for that row. The POSITION written is still seqused_k[i] - 1 through the block table -
+   * for a live row that is the slot vLLM computed, by construction of a decode step. Both NULL: every row is stored. */
+  const int64_t* slot_mapping;
+  const int32_t* slot_mapping_i32;
+  /* With k_new / v_new: 1 = rows of sequences with query_len == 1 read their key positions >= context_len from the
+   * linear tensors as well (self-attention over linear K/V with no cache behind it, prefill_flash_attention); 0 = the
+   * legacy ops' rule, such rows read the cache only (chunked_prefill_paged_decode) */
+  int32_t new_kv_all_rows;
+  int32_t reserved2;
 } mi355_attn_params;
 
 /*

@@ -95,3 +95,56 @@ def test_varlen_prefill_against_the_reference_kernels_outputs(name):
         assert _lib.last_kernel() == "generic", _lib.last_kernel()      # the correctness path: no MFMA kernel without the causal mask
     atol, rtol = golden_io.tolerance(t["q"].dtype)
     torch.testing.assert_close(out.float().cpu(), t["out"].float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [True, False])
+def test_self_attention_prefill_reads_the_linear_tensors_in_one_library_call(dtype, causal, monkeypatch):
+    """Q and K/V share `cu_seqlens` (the reference harness's use, scripts/callers/triton_3d.py:100-112): ONE C-ABI call
+    with the linear k / v as the library's new-token source, no scratch tensor or cache write on the Python side - a
+    sequence of length 1 included (its only key is in the linear tensors too)."""
+    from mi355_attn import _lib
+    from mi355_attn.kernels import flash, prefill_flash_attention
+
+    hq, hk, d = 8, 2, 128
+    g = torch.Generator().manual_seed(91)
+    lens = [129, 1, 64, 200, 17, 1]
+    cu = [0] + torch.tensor(lens).cumsum(0).tolist()
+    q = (torch.rand(cu[-1], hq, d, generator=g) * 2 - 1).to(dtype)
+    k = (torch.rand(cu[-1], hk, d, generator=g) * 2 - 1).to(dtype)
+    v = (torch.rand(cu[-1], hk, d, generator=g) * 2 - 1).to(dtype)
+    scale = 1.0 / math.sqrt(d)
+    if causal:
+        ref = _dense_reference(q, k, v, cu, cu, scale)
+    else:
+        ref = torch.zeros(q.shape, dtype=torch.float64)
+        for i in range(len(lens)):
+            a, b = cu[i], cu[i + 1]
+            for h in range(hq):
+                s = scale * (q[a:b, h].double() @ k[a:b, h // (hq // hk)].double().T)
+                ref[a:b, h] = torch.softmax(s, dim=-1) @ v[a:b, h // (hq // hk)].double()
+    dev = torch.device("cuda:0")
+    cud = torch.tensor(cu, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    calls = {"attn": 0, "cache": 0}
+
+    class Counting:
+        def __init__(self, fn, key):
+            self.fn, self.key = fn, key
+            self.restype, self.argtypes = fn.restype, fn.argtypes
+
+        def __call__(self, *a):
+            calls[self.key] += 1
+            return self.fn(*a)
+
+    monkeypatch.setattr(lib, "mi355_unified_attention", Counting(lib.mi355_unified_attention, "attn"), raising=False)
+    monkeypatch.setattr(lib, "mi355_reshape_and_cache_flash", Counting(lib.mi355_reshape_and_cache_flash, "cache"), raising=False)
+    n_scratch = len(flash._scratch)
+    out = prefill_flash_attention(q.to(dev), k.to(dev), v.to(dev), max(lens), max(lens), cud, cud, causal=causal, sm_scale=scale)
+    torch.cuda.synchronize()
+    assert calls == {"attn": 1, "cache": 0}, calls
+    assert len(flash._scratch) == n_scratch
+    if causal:
+        assert _lib.last_kernel().startswith("repack+prefill_"), _lib.last_kernel()
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(out.double().cpu(), ref, atol=tol, rtol=tol)

@@ -156,3 +156,68 @@ def test_impl_forward_issues_one_launch_for_a_decode_step(kv_cache_dtype, monkey
     got_v = kv_cache[1].view(cache_dtype) if fp8 else kv_cache[1]
     assert torch.equal(got_k.cpu().view(torch.uint8), kc_ref.view(torch.uint8))
     assert torch.equal(got_v.cpu().view(torch.uint8), vc_ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+def test_padded_decode_graph_leaves_the_cache_of_padding_rows_untouched(kv_cache_dtype):
+    """Full-graph mode (LIB/backend/triton_attn.py:107,:120-128,:149-151): a decode step is captured at batch 8 and
+    replayed with 5 live sequences; the 3 padding rows carry slot -1, and their seq_lens / block-table rows hold whatever
+    an earlier step left there. The reference's cache write skips slot -1; the fused write must as well - both for
+    padding rows with seq_len 0 (vLLM zeroes them) and for rows whose stale seq_len and block-table row point INTO a
+    live sequence's pages."""
+    import gpu_util
+    from mi355_attn.backend import attn
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page, B, live = 16, 4, 128, 16, 8, 5
+    fp8 = kv_cache_dtype == "fp8"
+    cache_dtype = torch.float8_e4m3fn if fp8 else torch.bfloat16
+    ks, vs = (0.03, 0.05) if fp8 else (1.0, 1.0)
+    kv_lens = [300, 17, 2048, 33, 129, 64, 500, 16]
+    inp = _case(57, kv_lens, Hq, Hk, D, page, torch.bfloat16, cache_dtype if fp8 else None, ks, vs)
+    kv_cache = torch.stack([inp["k_cache"], inp["v_cache"]]).to(dev)
+    if fp8:
+        kv_cache = kv_cache.view(torch.uint8)
+    impl = attn.MI355AttentionImpl(Hq, D, inp["scale"], Hk, None, None, kv_cache_dtype)
+    layer = types.SimpleNamespace(_k_scale=torch.tensor(ks, device=dev), _v_scale=torch.tensor(vs, device=dev), _q_scale=torch.tensor(1.0, device=dev))
+    seq_lens = inp["seqused_k"].to(dev).clone()
+    slot_mapping = inp["slots"].to(dev).clone()
+    block_table = inp["block_table"].to(dev).clone()
+    md = attn.MI355AttentionMetadata(
+        num_actual_tokens=B, max_query_len=1, avg_query_len=1, avg_seq_len=100, query_start_loc=inp["cu_seqlens_q"].to(dev),
+        max_seq_len=max(kv_lens), seq_lens=seq_lens, block_table=block_table, slot_mapping=slot_mapping,
+        use_cascade=False, common_prefix_len=0, cu_prefix_query_lens=None, prefix_kv_lens=None, suffix_kv_lens=None)
+    q, kn, vn = inp["q"].to(dev), inp["k_new"].to(dev), inp["v_new"].to(dev)
+    output = torch.zeros(B, Hq * D, dtype=torch.bfloat16, device=dev)
+    snapshot = kv_cache.clone()
+    impl.forward(layer, q, kn, vn, kv_cache, md, output=output)       # warm-up (sizes the workspace), then restore the cache
+    torch.cuda.synchronize()
+    kv_cache.copy_(snapshot)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):                                     # the plain torch idiom: torch's own capture stream
+        impl.forward(layer, q, kn, vn, kv_cache, md, output=output)
+    kv_cache.copy_(snapshot)
+    for stale in (False, True):
+        # rows 5..7 are padding: slot -1; seq_len 0 (what vLLM writes) or - the harder case - stale values whose last
+        # position lies inside live sequence 2's pages
+        slot_mapping[live:] = -1
+        if stale:
+            seq_lens[live:] = torch.tensor([700, 1024, 2048], dtype=torch.int32, device=dev)
+            block_table[live:] = block_table[2]
+        else:
+            seq_lens[live:] = 0
+        kv_cache.copy_(snapshot)
+        output.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        # expected cache: the separate write with the same slot mapping (slot -1 skipped)
+        kc_ref, vc_ref = inp["k_cache"].clone(), inp["v_cache"].clone()
+        orc.reshape_and_cache_flash_oracle(inp["k_new"], inp["v_new"], kc_ref, vc_ref, slot_mapping.cpu(), k_scale=ks, v_scale=vs)
+        got_k = kv_cache[0].view(cache_dtype) if fp8 else kv_cache[0]
+        got_v = kv_cache[1].view(cache_dtype) if fp8 else kv_cache[1]
+        assert torch.equal(got_k.cpu().view(torch.uint8), kc_ref.view(torch.uint8)), f"stale={stale}"
+        assert torch.equal(got_v.cpu().view(torch.uint8), vc_ref.view(torch.uint8)), f"stale={stale}"
+        ref = orc.unified_attention_oracle(inp["q"][:live], kc_ref, vc_ref, inp["cu_seqlens_q"][:live + 1], inp["seqused_k"][:live],
+                                           inp["block_table"][:live], inp["scale"], k_scale=ks, v_scale=vs, mode="3d")
+        atol, rtol = golden_io.tolerance(torch.bfloat16, cache_dtype if fp8 else None)
+        torch.testing.assert_close(output[:live].view(live, Hq, D).float().cpu(), ref.float(), atol=atol, rtol=rtol)

@@ -399,3 +399,105 @@ def test_fp8_cache_write_of_edge_values_is_bit_exact(cache_dtype, kv_cache_dtype
     assert torch.equal(kc[1, 3].cpu(), want(key)[0])
     assert torch.equal(vc[1, 3].cpu(), want(value)[0])
     assert int(kc[0].sum()) == 0 and int(kc[1, :3].sum()) == 0            # nothing else written
+
+
+def test_impl_forward_local_attention_branch_with_hand_built_virtual_batches():
+    """The iRoPE / chunked local attention branch of forward (LIB/backend/triton_attn.py:157-190 builds the virtual
+    batches, :423-444 swaps them in): with `use_irope` and `local_attn_metadata` the attention call runs over VIRTUAL
+    sequences - one per (sequence, attention chunk) - while the cache write still uses the step's real slot mapping.
+    The virtual metadata is built by hand here (vLLM's make_local_attention_virtual_batches is not needed for that) and
+    the result is checked against the oracle on the virtual batch AND against a dense float64 softmax with the chunk
+    mask written out, on the real sequences."""
+    import gpu_util
+    from mi355_attn.backend import attn
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page, chunk = 8, 2, 128, 16, 32
+    dtype = torch.bfloat16
+    query_lens, ctx_lens = [50, 1, 7, 33], [40, 70, 0, 31]
+    kv_lens = [a + b for a, b in zip(query_lens, ctx_lens)]
+    inp = orc.make_paged_inputs(61, query_lens, kv_lens, Hq, Hk, D, page, dtype)
+    T = sum(query_lens)
+    g = torch.Generator().manual_seed(62)
+    k_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype)
+    v_new = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(dtype)
+    slots = []
+    for i, (ql, cl) in enumerate(zip(query_lens, ctx_lens)):
+        for j in range(cl, cl + ql):
+            slots.append(int(inp["block_table"][i, j // page]) * page + j % page)
+    slot_mapping = torch.tensor(slots, dtype=torch.int64)
+    kc, vc = inp["k_cache"].clone(), inp["v_cache"].clone()
+    orc.reshape_and_cache_flash_oracle(k_new, v_new, kc, vc, slot_mapping)
+    # virtual batches: for every sequence, every attention chunk its query tokens fall into
+    v_qlens, v_klens, v_bt = [], [], []
+    ppc = chunk // page
+    for i, (ql, cl) in enumerate(zip(query_lens, ctx_lens)):
+        pos = cl
+        while pos < cl + ql:
+            c0 = (pos // chunk) * chunk
+            hi = min(c0 + chunk, cl + ql)
+            v_qlens.append(hi - pos)
+            v_klens.append(hi - c0)
+            row = inp["block_table"][i, c0 // page: c0 // page + ppc]
+            v_bt.append(torch.cat([row, torch.zeros(ppc - row.numel(), dtype=torch.int32)]))
+            pos = hi
+    v_cu = torch.tensor([0] + torch.tensor(v_qlens).cumsum(0).tolist(), dtype=torch.int32)
+    v_sk = torch.tensor(v_klens, dtype=torch.int32)
+    v_bt = torch.stack(v_bt).contiguous()
+    assert int(v_cu[-1]) == T and len(v_qlens) > len(query_lens)
+    ref = orc.unified_attention_oracle(inp["q"], kc, vc, v_cu, v_sk, v_bt, inp["scale"])
+    # independent: dense float64 softmax over the real sequences with the chunk mask
+    dense = torch.zeros(T, Hq, D, dtype=torch.float64)
+    t0 = 0
+    for i, (ql, cl) in enumerate(zip(query_lens, ctx_lens)):
+        L = cl + ql
+        pages = inp["block_table"][i, : (L + page - 1) // page].long()
+        ks = kc[pages].reshape(-1, Hk, D)[:L].double()
+        vs = vc[pages].reshape(-1, Hk, D)[:L].double()
+        qpos = torch.arange(cl, L)[:, None]
+        kpos = torch.arange(L)[None, :]
+        mask = (kpos <= qpos) & (kpos >= (qpos // chunk) * chunk)
+        for h in range(Hq):
+            s = inp["scale"] * (inp["q"][t0:t0 + ql, h].double() @ ks[:, h // (Hq // Hk)].T)
+            dense[t0:t0 + ql, h] = torch.softmax(s.masked_fill(~mask, float("-inf")), dim=-1) @ vs[:, h // (Hq // Hk)]
+        t0 += ql
+    torch.testing.assert_close(ref.double(), dense, atol=2e-2, rtol=2e-2)
+
+    impl = attn.MI355AttentionImpl(Hq, D, inp["scale"], Hk, None, None, "auto", use_irope=True)
+    layer = types.SimpleNamespace(_k_scale=torch.tensor(1.0, device=dev), _v_scale=torch.tensor(1.0, device=dev), _q_scale=torch.tensor(1.0, device=dev))
+    local = attn.MI355AttentionMetadata.LocalAttentionMetadata(
+        local_query_start_loc=v_cu.to(dev), local_seqused_k=v_sk.to(dev), local_block_table=v_bt.to(dev),
+        local_max_query_len=max(v_qlens), local_max_seq_len=max(v_klens), local_avg_query_len=T // len(v_qlens),
+        local_avg_seq_len=sum(v_klens) // len(v_klens), local_scheduler_metadata=None)
+    md = attn.MI355AttentionMetadata(
+        num_actual_tokens=T, max_query_len=max(query_lens), avg_query_len=T // 4, avg_seq_len=sum(kv_lens) // 4,
+        query_start_loc=inp["cu_seqlens_q"].to(dev), max_seq_len=max(kv_lens), seq_lens=inp["seqused_k"].to(dev),
+        block_table=inp["block_table"].to(dev), slot_mapping=slot_mapping.to(dev), use_cascade=False, common_prefix_len=0,
+        cu_prefix_query_lens=None, prefix_kv_lens=None, suffix_kv_lens=None, local_attn_metadata=local)
+    kv_cache = torch.stack([inp["k_cache"], inp["v_cache"]]).to(dev)
+    output = torch.full((T, Hq * D), float("nan"), dtype=dtype, device=dev)
+    impl.forward(layer, inp["q"].to(dev), k_new.to(dev), v_new.to(dev), kv_cache, md, output=output)
+    torch.cuda.synchronize()
+    assert torch.equal(kv_cache[0].cpu().view(torch.int16), kc.view(torch.int16))        # the write used the REAL slot mapping
+    torch.testing.assert_close(output.view(T, Hq, D).float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    # the same layer without local metadata attends over the whole context: a different result (the branch was really taken)
+    md.local_attn_metadata = None
+    out2 = torch.full((T, Hq * D), float("nan"), dtype=dtype, device=dev)
+    impl.forward(layer, inp["q"].to(dev), k_new.to(dev), v_new.to(dev), kv_cache, md, output=out2)
+    torch.cuda.synchronize()
+    assert (out2.float() - output.float()).abs().max().item() > 0.05
+
+    # a decode step with local metadata must not take the fused write (its kernel knows nothing of virtual batches)
+    dec = attn.MI355AttentionMetadata(
+        num_actual_tokens=1, max_query_len=1, avg_query_len=1, avg_seq_len=71, query_start_loc=torch.tensor([0, 1], dtype=torch.int32, device=dev),
+        max_seq_len=71, seq_lens=torch.tensor([71], dtype=torch.int32, device=dev), block_table=inp["block_table"][1:2].to(dev),
+        slot_mapping=slot_mapping[50:51].to(dev), use_cascade=False, common_prefix_len=0, cu_prefix_query_lens=None, prefix_kv_lens=None,
+        suffix_kv_lens=None,
+        local_attn_metadata=attn.MI355AttentionMetadata.LocalAttentionMetadata(
+            local_query_start_loc=torch.tensor([0, 1], dtype=torch.int32, device=dev), local_seqused_k=torch.tensor([7], dtype=torch.int32, device=dev),
+            local_block_table=inp["block_table"][1:2, 4:6].contiguous().to(dev), local_max_query_len=1, local_max_seq_len=7,
+            local_avg_query_len=1, local_avg_seq_len=7, local_scheduler_metadata=None))
+    o1 = torch.full((1, Hq * D), float("nan"), dtype=dtype, device=dev)
+    impl.forward(layer, inp["q"][50:51].to(dev), k_new[50:51].to(dev), v_new[50:51].to(dev), kv_cache, dec, output=o1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(o1.view(1, Hq, D).float().cpu(), ref[50:51].float(), atol=2e-2, rtol=2e-2)

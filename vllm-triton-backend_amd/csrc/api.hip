@@ -54,10 +54,12 @@ static int validate(const mi355_attn_params* p) {
   }
   if (p->lse && p->lse_stride_token < p->num_q_heads) { set_error("lse_stride_token %lld is smaller than num_q_heads %d", (long long)p->lse_stride_token, p->num_q_heads); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
-  if (p->non_causal && (p->sliding_window > 0 || p->alibi_slopes || p->write_new_kv || p->k_new)) {
-    set_error("non_causal attention takes neither a sliding window, ALiBi slopes nor linear new-token K/V");
+  if (p->non_causal && (p->sliding_window > 0 || p->alibi_slopes || p->write_new_kv)) {
+    set_error("non_causal attention takes neither a sliding window nor ALiBi slopes nor a fused cache write");
     return MI355_ERR_UNSUPPORTED;
   }
+  if (p->slot_mapping && p->slot_mapping_i32) { set_error("at most one of slot_mapping / slot_mapping_i32 may be non-NULL"); return MI355_ERR_BAD_ARG; }
+  if (p->new_kv_all_rows && (!p->k_new || p->write_new_kv)) { set_error("new_kv_all_rows needs k_new / v_new and excludes write_new_kv"); return MI355_ERR_BAD_ARG; }
   if (p->write_new_kv) {
     if (!p->k_new || !p->v_new) { set_error("write_new_kv needs k_new / v_new"); return MI355_ERR_BAD_ARG; }
     if (p->max_seqlen_q != 1 || p->num_tokens != p->num_seqs || p->skip_decodes || p->only_decodes) {
@@ -156,7 +158,7 @@ static RepackPlan plan_repack(const mi355_attn_params& p) {
   r.pd.k_new = r.pd.v_new = nullptr;         // decode rows never read the linear source (generic_attn.hip: use_new)
   r.pd.only_decodes = 1;
   const bool uniform_prefill = (int64_t)p.num_seqs * p.max_seqlen_q == p.num_tokens;
-  r.direct_decode = !p.skip_decodes && !uniform_prefill && p.num_seqs > 1 && decode_supported(r.pd);
+  r.direct_decode = !p.skip_decodes && !p.new_kv_all_rows && !uniform_prefill && p.num_seqs > 1 && decode_supported(r.pd);
   mi355_attn_params pr = repacked_params(p, nullptr, 0);
   if (r.direct_decode) pr.skip_decodes = 1;
   const size_t a = plain_workspace_bytes(pr), b = r.direct_decode ? decode_workspace_bytes(r.pd) : 0;

@@ -259,6 +259,25 @@ __device__ __forceinline__ void scalar_load_word_and_pair(const int32_t* w, cons
       : "memory");
 }
 
+// The same plus one more word at `w2` (all wave-uniform), still ONE scalar round trip.
+__device__ __forceinline__ void scalar_load_2words_and_pair(const int32_t* w, const int32_t* w2, const int32_t* base, int i0, int i1, int& rw, int& rw2, int& r0, int& r1) {
+  const int o0 = __builtin_amdgcn_readfirstlane(i0 * 4), o1 = __builtin_amdgcn_readfirstlane(i1 * 4);
+  const uint64_t b = (uint64_t)base, ww = (uint64_t)w, w2w = (uint64_t)w2;
+  const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint32_t wlo = __builtin_amdgcn_readfirstlane((uint32_t)ww), whi = __builtin_amdgcn_readfirstlane((uint32_t)(ww >> 32));
+  const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)w2w), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(w2w >> 32));
+  const uint64_t bu = ((uint64_t)bhi << 32) | blo, wu = ((uint64_t)whi << 32) | wlo, xu = ((uint64_t)xhi << 32) | xlo;
+  asm volatile(
+      "s_load_dword %0, %4, 0x0\n\t"
+      "s_load_dword %1, %5, 0x0\n\t"
+      "s_load_dword %2, %6, %7\n\t"
+      "s_load_dword %3, %6, %8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(rw), "=&s"(rw2), "=&s"(r0), "=&s"(r1)
+      : "s"(wu), "s"(xu), "s"(bu), "s"(o0), "s"(o1)
+      : "memory");
+}
+
 // One LDS-DMA piece: every lane fetches 16 bytes from its own global address and the wave's 1 KiB
 // lands contiguously at LDS byte address `lds_dst` (wave-uniform) + lane*16.
 // Issued through inline asm ON PURPOSE: for the builtin form hipcc (ROCm 7.2) orders every later

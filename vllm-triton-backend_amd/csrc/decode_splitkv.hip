@@ -246,6 +246,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   // cu_seqlens_q first.
   RowInfo ri;
   int pg_first[2] = {0, 0};
+  int slot_sign = 0;           // write_new_kv: < 0 marks a padding row whose K/V must not reach the cache (triton_attn.py:149-151)
   const bool fast_head = !FEAT && a.unit_is_seq;
   if (fast_head) {
     if (unit >= p.num_seqs || p.skip_decodes) return;
@@ -255,6 +256,13 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     // index inside the row is safe to read)
     const int last_blk = max(0, min(((p.max_seqlen_k + p.page_size - 1) >> a.page_shift) - 1, (int)p.block_table_stride - 1));
     int seq_len;
+    if (p.write_new_kv && (p.slot_mapping || p.slot_mapping_i32)) {
+      // the word of this row's slot that carries its sign (int64: the high half) rides the same round trip
+      const int32_t* sw = p.slot_mapping ? (const int32_t*)(p.slot_mapping + unit) + 1 : p.slot_mapping_i32 + unit;
+      scalar_load_2words_and_pair(p.seqused_k + unit, sw, p.block_table + (int64_t)unit * p.block_table_stride,
+                                  min((t0s * 2 * 16) >> a.page_shift, last_blk), min(((t0s * 2 + 1) * 16) >> a.page_shift, last_blk),
+                                  seq_len, slot_sign, pg_first[0], pg_first[1]);
+    } else
     scalar_load_word_and_pair(p.seqused_k + unit, p.block_table + (int64_t)unit * p.block_table_stride,
                               min((t0s * 2 * 16) >> a.page_shift, last_blk), min(((t0s * 2 + 1) * 16) >> a.page_shift, last_blk),
                               seq_len, pg_first[0], pg_first[1]);
@@ -267,6 +275,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     ri = row_info(p, a.by_seq, unit);
     if (!ri.valid) return;
     load_q(ri.token);
+    if (p.write_new_kv && (p.slot_mapping || p.slot_mapping_i32))
+      slot_sign = p.slot_mapping ? ((const int32_t*)(p.slot_mapping + ri.token))[1] : p.slot_mapping_i32[ri.token];
   }
   const int token = ri.token, n_keys = ri.n_keys, first_key = ri.first_key, ctx_len = ri.ctx_len;
 
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       // reshape_and_cache_flash would have stored it - is written to its page, and takes part in this tile like any
       // cached row. pg[] still holds this tile's pages: a wave's last lookup is for its last tile.
       if (p.write_new_kv && tile == tile_hi - 1 && t1 == tile_hi) {
-        const bool store_row = qg == 0;         // the waves of the other query-head groups only take the row
+        const bool store_row = qg == 0 && slot_sign >= 0;   // the waves of the other query-head groups only take the row; a padding row (slot < 0) is attended over but never stored
         const int r_last = n_keys - 1 - tile * kTileKeys;
 #pragma unroll
         for (int h = 0; h < 2; ++h)

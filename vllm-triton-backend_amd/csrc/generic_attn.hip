@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void generic_attn_kernel(const GenericArgs a) {
   int n_keys = p.non_causal ? seq_len : ctx_len + q_pos + 1;   // causal: keys j <= ctx + q_pos
   if (n_keys > seq_len) n_keys = seq_len;
   const int kv_head = head / (p.num_q_heads / p.num_kv_heads);
-  const bool use_new = (p.k_new != nullptr) && (q_len > 1);
+  const bool use_new = (p.k_new != nullptr) && (q_len > 1 || p.new_kv_all_rows);
 
   const float k_scale = (kKvIsFp8 && p.k_scale) ? p.k_scale[0] : 1.0f;
   const float v_scale = (kKvIsFp8 && p.v_scale) ? p.v_scale[0] : 1.0f;

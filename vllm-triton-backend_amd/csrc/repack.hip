@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   const int j0 = pg * kRepackPage;
   if (j0 >= seq_len) return;
   const int ctx = seq_len - q_len;
-  const bool use_new = p.k_new != nullptr && q_len > 1;   // generic_attn.hip: same rule
+  const bool use_new = p.k_new != nullptr && (q_len > 1 || p.new_kv_all_rows);   // generic_attn.hip: same rule
   const int D = p.head_size, Hk = p.num_kv_heads, chunks = D >> 3;
   const int pieces = kRepackPage * chunks;
   const int64_t dst_page = ((int64_t)seq * a.pages_per_seq + pg) * kRepackPage * Hk * D;
@@ -219,6 +219,7 @@ mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, siz
   r.block_table = (const int32_t*)(base ? base + l.bt_off : (char*)(uintptr_t)256);
   r.block_table_stride = pages_per_seq(p);
   r.k_new = r.v_new = nullptr;
+  r.new_kv_all_rows = 0;
   r.kv_dtype = p.q_dtype;                 // an fp8 cache is dequantised on the way in
   r.k_scale = r.v_scale = nullptr;
   r.page_size = kRepackPage;
@@ -241,7 +242,7 @@ bool repack_supported(const mi355_attn_params& p) {
   const mi355_attn_params r = repacked_params(p, nullptr, 0);
   // a decode-only call is repacked only when the split-KV kernel cannot read the cache itself (fp8 or 4-D v0 caches:
   // 1 + 2 + 2 bytes per element moved instead of 1, still several times faster than the shape-agnostic kernel)
-  if (p.max_seqlen_q <= 1) return !decode_supported(p) && decode_supported(r);
+  if (p.max_seqlen_q <= 1) return (p.new_kv_all_rows || !decode_supported(p)) && decode_supported(r);
   return prefill_supported(r);
 }
 

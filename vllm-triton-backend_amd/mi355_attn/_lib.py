@@ -97,6 +97,10 @@ class AttnParams(C.Structure):
         ("lse_stride_token", C.c_int64),
         ("write_new_kv", C.c_int32),
         ("non_causal", C.c_int32),
+        ("slot_mapping", C.c_void_p),
+        ("slot_mapping_i32", C.c_void_p),
+        ("new_kv_all_rows", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -218,8 +222,21 @@ def current_stream_handle(device: torch.device) -> int:
 # A buffer that has been handed out is NEVER freed: a HIP graph captured earlier holds its raw address (arrival
 # counters, split partials) and replays into it long after a later, larger call made the binding move on to a bigger
 # buffer. Growth is geometric, so the retired buffers together stay below the size of the live one.
+# While a stream is CAPTURING nothing is allocated. `torch.cuda.graph(g)` without `stream=` captures on a private
+# stream no eager call ever ran on (torch's default capture stream; `triton.testing.do_bench_cudagraph` and vLLM's
+# full-graph capture do exactly that), so the capture borrows the device's largest workspace: capture serialises with
+# the warm-up that allocated it, and a replay runs on whatever stream the caller replays on - stream-ordered with the
+# eager calls of that stream, which is the only stream the borrowed buffer can meet it on.
 _workspaces: dict = {}
 _retired: list = []
+
+
+def _largest_on_device(device: torch.device):
+    best = None
+    for (dtype_, index_, _stream), ws in _workspaces.items():
+        if dtype_ == device.type and index_ == device.index and (best is None or ws.numel() > best.numel()):
+            best = ws
+    return best
 
 
 def workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
@@ -229,9 +246,12 @@ def workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
+            best = _largest_on_device(device)
+            if best is not None and best.numel() >= nbytes:
+                return best
             raise RuntimeError(
-                "mi355_attn workspace must be allocated before graph capture: run one eager call of "
-                "the largest shape first"
+                f"mi355_attn workspace ({nbytes} bytes) must be allocated before graph capture: run one eager call of "
+                "the largest shape on this device first (any stream)"
             )
         if ws is not None:
             _retired.append(ws)

@@ -246,6 +246,7 @@ class MI355AttentionImpl(AttentionImpl):
         self.kv_sharing_target_layer_name = kv_sharing_target_layer_name
         self.use_irope = use_irope
         self.num_queries_per_kv = self.num_heads // self.num_kv_heads
+        self._q_scale_checked = False
 
         MI355AttentionBackend.validate_head_size(head_size)
 
@@ -256,6 +257,22 @@ class MI355AttentionImpl(AttentionImpl):
         # gfx950 speaks OCP fp8 (e4m3fn), unlike MI300's fnuz
         self.fp8_dtype = torch.float8_e5m2 if kv_cache_dtype == "fp8_e5m2" else torch.float8_e4m3fn
         logger.warning_once("Using mi355-attn attention PLUGIN V1 (hand-written gfx950 HIP kernels).")
+
+    def _check_q_scale(self, layer) -> None:
+        """The reference asserts `layer._q_scale == 1.0` on every forward (triton_attn.py:412): with a device tensor that
+        is a host sync per layer and step, and an error under graph capture. Checked ONCE per layer here (the scale is a
+        checkpoint constant), from the host-side float when the layer carries one, never while a stream is capturing."""
+        if self._q_scale_checked:
+            return
+        qs = getattr(layer, "_q_scale_float", None)
+        if qs is None:
+            qs = getattr(layer, "_q_scale", 1.0)
+            if isinstance(qs, torch.Tensor):
+                if qs.is_cuda and torch.cuda.is_current_stream_capturing():
+                    return                      # not now; the warm-up run before the capture has normally checked already
+                qs = float(qs)
+        assert qs == 1.0, "A non 1.0 q_scale is not currently supported."
+        self._q_scale_checked = True
 
     def forward(
         self,
@@ -294,7 +311,7 @@ class MI355AttentionImpl(AttentionImpl):
             if q.dim() == 2:
                 q = q.view(-1, self.num_heads, self.head_size)
             if self.kv_cache_dtype.startswith("fp8"):
-                assert layer._q_scale == 1.0, "A non 1.0 q_scale is not currently supported."
+                self._check_q_scale(layer)
             torch.ops.mi355_attn.decode_attention_and_cache_write(
                 q, key, value, key_cache, value_cache, out, attn_metadata.query_start_loc, attn_metadata.seq_lens, int(attn_metadata.max_seq_len),
                 float(self.scale), attn_metadata.block_table, attn_metadata.slot_mapping, layer._k_scale, layer._v_scale, self.kv_cache_dtype)
@@ -305,7 +322,7 @@ class MI355AttentionImpl(AttentionImpl):
                                                          layer._k_scale, layer._v_scale)
 
         if self.kv_cache_dtype.startswith("fp8"):
-            assert layer._q_scale == 1.0, "A non 1.0 q_scale is not currently supported."
+            self._check_q_scale(layer)
             # Q stays in its own dtype: K/V are dequantised in the kernel (the reference skips Q
             # quantisation on ROCm as well, triton_attn.py:414-420); the op views the uint8 cache as gfx950's OCP fp8
 

@@ -34,7 +34,7 @@ def fill_attn_params(
     q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_size,
     block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection,
     k_new=None, v_new=None, skip_decodes=False, only_decodes=False, num_segments=0,
-    legacy_v0_layout=False, lse=None, write_new_kv=False, non_causal=False,
+    legacy_v0_layout=False, lse=None, write_new_kv=False, non_causal=False, slot_mapping=None, new_kv_all_rows=False,
 ):
     """Build the C struct. Returns (params, keepalive) — keepalive holds temporaries whose device
     memory the struct points to."""
@@ -112,6 +112,14 @@ def fill_attn_params(
     p.num_segments = int(num_segments)
     p.write_new_kv = int(bool(write_new_kv))
     p.non_causal = int(bool(non_causal))
+    p.new_kv_all_rows = int(bool(new_kv_all_rows))
+    if slot_mapping is not None:
+        if slot_mapping.dtype not in (torch.int64, torch.int32) or not slot_mapping.is_contiguous() or slot_mapping.shape[0] < q.shape[0]:
+            raise ValueError("slot_mapping must be a contiguous int64 or int32 tensor with one entry per query token")
+        if slot_mapping.dtype == torch.int64:
+            p.slot_mapping = slot_mapping.data_ptr()
+        else:
+            p.slot_mapping_i32 = slot_mapping.data_ptr()
     if lse is not None:
         if lse.dtype != torch.float32 or lse.dim() != 2 or lse.shape[0] != q.shape[0] or lse.shape[1] != q.shape[1] or lse.stride(1) != 1:
             raise ValueError("softmax_lse must be a float32 [num_tokens, num_heads] tensor with contiguous heads")
@@ -173,11 +181,13 @@ def unified_attention(
 
 
 def decode_attention_and_cache_write(q, key, value, k_cache, v_cache, out, seqused_k, max_seqlen_k, softmax_scale, block_table,
-                                     k_descale=None, v_descale=None, cu_seqlens_q=None):
+                                     k_descale=None, v_descale=None, cu_seqlens_q=None, slot_mapping=None):
     """One launch for a decode step (every sequence has ONE query token): the new token's key / value (row i of `key` /
     `value` belongs to position seqused_k[i] - 1 of sequence i) is stored into its cache page - quantised for an fp8
     cache exactly as reshape_and_cache_flash stores it - and attended over, by the wave that owns the sequence's last
     tile. Replaces the pair of calls at LIB/backend/triton_attn.py:393-405 + :437 for such steps.
+    `slot_mapping` (the step's, as reshape_and_cache_flash would get it): a row whose slot is negative - a padding row of
+    a captured graph, triton_attn.py:149-151 - is never stored, whatever its seqused_k / block_table row hold.
     Returns False (and does nothing) when this configuration is not served fused: the caller then issues the two calls."""
     if not q.is_cuda:
         raise RuntimeError("mi355_attn.decode_attention_and_cache_write needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
@@ -185,7 +195,7 @@ def decode_attention_and_cache_write(q, key, value, k_cache, v_cache, out, sequs
     if cu_seqlens_q is None:
         cu_seqlens_q = _arange_cu(n, q.device)
     p, keep = fill_attn_params(q, k_cache, v_cache, out, cu_seqlens_q, 1, seqused_k, max_seqlen_k, softmax_scale, (-1, -1), block_table, 0.0,
-                               k_descale, v_descale, None, None, k_new=key, v_new=value, write_new_kv=True)
+                               k_descale, v_descale, None, None, k_new=key, v_new=value, write_new_kv=True, slot_mapping=slot_mapping)
     if not _lib.load().mi355_decode_write_fusable(C.byref(p)):
         return False
     launch(p, q.device)

@@ -65,7 +65,7 @@ def _decode_attention_and_cache_write_impl(q, key, value, key_cache, value_cache
         kc, vc = kc.view(_FP8[kv_cache_dtype]), vc.view(_FP8[kv_cache_dtype])
     n = q.shape[0]
     if _decode_attention_and_cache_write(q, key[:n], value[:n], kc, vc, out, seqused_k, max_seqlen_k, softmax_scale, block_table,
-                                         k_scale, v_scale, cu_seqlens_q):
+                                         k_scale, v_scale, cu_seqlens_q, slot_mapping if slot_mapping.shape[0] >= n else None):
         return
     _reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype, k_scale, v_scale)
     _unified_attention(q=q, k=kc, v=vc, out=out, cu_seqlens_q=cu_seqlens_q, max_seqlen_q=1, seqused_k=seqused_k, max_seqlen_k=max_seqlen_k,

@@ -5,7 +5,7 @@ from setuptools import find_packages, setup
 
 setup(
     name="mi355-attn",
-    version="0.1.0",
+    version="0.4.0",
     description="MI355X (gfx950) native paged-attention backend for vLLM",
     packages=find_packages(include=["mi355_attn", "mi355_attn.*"]),
     package_data={"mi355_attn": ["libmi355_attn.so"]},
