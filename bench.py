@@ -15,9 +15,11 @@ Three more workloads are timed the same way right after it and reported in the s
   "mixed"       C4 (configs[3]): the reference harness's mixed batch (32 decodes, 16 partial and 16 full prefills,
                 98 336 query tokens), ONE global batch dealt to the N ranks by mi355_attn.parallel.shard_batch
                 (cost-balanced, each rank holds only its sequences' pages)          -> TFLOP/s, strong scaling
+  "prefill_b8"  the C2 family's batch of 8: 8 sequences x 4096 tokens, ONE global batch dealt to the ranks
+                the same way                                                         -> TFLOP/s, strong scaling
 Multi-GPU: the path shards over sequences with no data-path collective: C2/C3/C5 are weak scaling
-(every rank owns its own sequences, KV pages and block table), C4 is the batch-sharded split of one batch; the only
-collectives are the timing barrier and the MAX over ranks of the measured time.
+(every rank owns its own sequences, KV pages and block table), C4 and prefill_b8 are batch-sharded splits of one batch;
+the only collectives are the timing barrier and the MAX over ranks of the measured time.
 `python bench.py --gpus N` with N > 1 and no torch.distributed environment starts the N ranks itself
 (torch.distributed.run as a child process, before this process touches a GPU) and fails loudly when the box has
 fewer than N GPUs.
@@ -43,7 +45,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 # Untimed launches of the same call before the W warm-up steps (reported as "prewarm_s" in the line): a 120 us kernel timed
 # 20 times right after its inputs were generated measures the device's clock/power ramp out of idle, not the kernel.
 PREWARM_S = float(os.environ.get("MI355_BENCH_PREWARM_S", "0.25"))
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+ALL_LEGS = ("prefill", "decode", "decode_fp8", "mixed", "prefill_b8")
 
 
 def spawn_ranks(args) -> int:
@@ -61,6 +64,7 @@ def spawn_ranks(args) -> int:
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    cmd += ["--legs", args.legs]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     env = dict(os.environ)
@@ -86,9 +90,12 @@ def make_workload(kind, device, seed, rank, world):
     dt = torch.bfloat16
     gen = torch.Generator(device=device).manual_seed(seed)
     g = torch.Generator(device="cpu").manual_seed(seed)
-    if kind == "mixed":                                   # C4: one GLOBAL batch (same seed on every rank), sharded below
+    if kind in ("mixed", "prefill_b8"):                   # one GLOBAL batch (same seed on every rank), sharded below
         Hq, Hk, D = 32, 8, 128
-        qlens, kvlens = c4_lens()
+        if kind == "mixed":                               # C4
+            qlens, kvlens = c4_lens()
+        else:                                             # the C2 family's batch of 8 (B in {2,4,8} for the multi-GPU curve)
+            qlens, kvlens = [4096] * 8, [4096] * 8
         S, T = len(qlens), sum(qlens)
         pps = [(n + page - 1) // page for n in kvlens]
         nb = sum(pps) + 8
@@ -237,7 +244,7 @@ def cpu_baseline(w, out_gpu):
 
 # device symbol behind each name mi355_last_kernel() reports for the benchmarked calls (profiles are keyed by symbol)
 # (symbol prefix, substring the instantiation must carry, substring it must not carry)
-KERNEL_SYMBOL = {"prefill_mfma": ("prefill_pw_kernel", "", "\0"), "decode_splitkv": ("decode_splitkv_kernel", "", "e4m3"),
+KERNEL_SYMBOL = {"prefill_mfma_pw": ("prefill_pw_kernel", "", "\0"), "decode_splitkv": ("decode_splitkv_kernel", "", "e4m3"),
                  "decode_splitkv_fp8": ("decode_splitkv_kernel", "e4m3", "\0")}
 
 
@@ -276,9 +283,19 @@ def measured_traffic(leg, kernel_name):
     return None
 
 
-def roofline(bound, achieved, peak, unit, w, res, extra):
+def roofline(bound, work, peak, unit, scale, w, res, steps, extra):
+    """`achieved` / `frac`: algorithmic work of one launch over the kernel's average launch duration taken from the SAME
+    clock as the leg's `value` (wall clock of the K timed steps between the barriers / K, max over ranks) - so the line's
+    `frac` is `value` per GPU over the peak, and never better than what the driver's own clock sees. `*_events`: the same
+    with the HIP-event bracket around the K launches on their stream (it leaves out the launch latency in front of the
+    first kernel and the wake-up behind the last synchronize: ~60 us per timed region, 3 % of 20 steps of 112 us).
+    The rocprofv3 per-kernel average under profiles/ leaves out the gaps between launches as well."""
+    t_wall, t_ev = res["wall"] / steps, res["per_launch"]
+    achieved, achieved_ev = work / t_wall / scale, work / t_ev / scale
     r = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-         "traffic": measured_traffic(w["kind"], res["kernel"]), "kernel": res["kernel"], "kernel_us": round(res["per_launch"] * 1e6, 2)}
+         "traffic": measured_traffic(w["kind"], res["kernel"]), "kernel": res["kernel"], "clock": "wall clock of the timed steps / K (the clock of `value`)",
+         "kernel_us": round(t_wall * 1e6, 2), "achieved_events": round(achieved_ev, 2), "frac_events": round(achieved_ev / peak, 4),
+         "kernel_us_events": round(t_ev * 1e6, 2)}
     r.update(extra)
     return r
 
@@ -289,9 +306,9 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--legs", default="prefill,decode,decode_fp8,mixed",
-                    help="comma list of the workloads to run (profiles of ONE kernel: --legs prefill | decode | decode_fp8 | mixed); "
-                         "the driver's default runs all four, the headline value is the prefill leg's")
+    ap.add_argument("--legs", default=",".join(ALL_LEGS),
+                    help="comma list of the workloads to run (profiles of ONE kernel: --legs prefill | decode | decode_fp8 | mixed | prefill_b8); "
+                         "the driver's default runs all of them, the headline value is the prefill leg's")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # inside torch.distributed.run
@@ -327,14 +344,14 @@ def main():
             dist.barrier()
 
     legs = [x for x in args.legs.split(",") if x]
-    unknown = set(legs) - {"prefill", "decode", "decode_fp8", "mixed"}
+    unknown = set(legs) - set(ALL_LEGS)
     if unknown or not legs:
-        raise SystemExit(f"bench.py: --legs takes prefill, decode, decode_fp8, mixed; got {args.legs!r}")
+        raise SystemExit(f"bench.py: --legs takes {', '.join(ALL_LEGS)}; got {args.legs!r}")
     results = {}
-    for kind in ("prefill", "decode", "decode_fp8", "mixed"):
+    for kind in ALL_LEGS:
         if kind not in legs:
             continue
-        w = make_workload(kind, device, seed=0 if kind == "mixed" else rank, rank=rank, world=world)
+        w = make_workload(kind, device, seed=0 if kind in ("mixed", "prefill_b8") else rank, rank=rank, world=world)
         call = build_call(w, device)
         call()
         torch.cuda.synchronize(device)
@@ -353,10 +370,10 @@ def main():
     if rank == 0:
         K = args.steps
         pf, dc, d8, mx = results.get("prefill"), results.get("decode"), results.get("decode_fp8"), results.get("mixed")
+        b8 = results.get("prefill_b8")
         line = {"legs": legs}
         if pf:
             pf_val = pf["w"]["flops"] * n_gpus * K / pf["wall"] / 1e12
-            pf_ach = pf["w"]["flops"] / pf["per_launch"] / 1e12
             line = {
                 "metric": "attn fwd TFLOPS (prefill) + KV GB/s (decode), Llama-3-8B GQA seq4k",
                 "value": round(pf_val, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup, "prewarm_s": PREWARM_S,
@@ -364,7 +381,7 @@ def main():
                 "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": "C2 prefill: Llama-3-8B shape Hq32/Hk8/D128, 1 seq x 4096 tokens per GPU, causal, paged KV (16-token pages)",
                            "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
-                "roofline": roofline("mfma", pf_ach, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", pf["w"], pf, {
+                "roofline": roofline("mfma", pf["w"]["flops"], MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12, pf["w"], pf, K, {
                     "algorithmic_flops_per_launch": pf["w"]["flops"],
                     "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.1-2.35 GHz (in-kernel clock, "
                             "tools/pw_clock.py, profiles/r02/pw_clock.log)"}),
@@ -372,10 +389,9 @@ def main():
 
         def decode_leg(res, label, cfg):
             val = res["w"]["bytes"] * n_gpus * K / res["wall"] / 1e9
-            ach = res["w"]["bytes"] / res["per_launch"] / 1e9
             return {"metric": label, "value": round(val, 1), "unit": "GB/s", "ms_per_step": round(res["wall"] / K * 1e3, 4),
                     "config": {"workload": cfg, "global_batch": res["w"]["B"] * n_gpus, "kernel": res["kernel"]},
-                    "roofline": roofline("hbm", ach, HBM_PEAK_GBS, "GB/s", res["w"], res, {
+                    "roofline": roofline("hbm", res["w"]["bytes"], HBM_PEAK_GBS, "GB/s", 1e9, res["w"], res, K, {
                         "algorithmic_bytes_per_launch": res["w"]["bytes"],
                         "note": "peak = nominal HBM3E rate; a plain streaming read of 2 GiB reaches 7.15 TB/s on this chip with nt loads, "
                                 "6.2 TB/s with ordinary ones (profiles/r01/hbm_read_reference_point.log)"})}
@@ -394,6 +410,13 @@ def main():
                                                     "16 full prefills 4096), 98336 query tokens, ONE batch dealt to the ranks by parallel.shard_batch",
                                         "global_batch": 64, "parallelism": f"batch-sharded x{n_gpus} (LPT by attention cost), no collective",
                                         "rank0_share": mx["w"]["local"], "kernel": mx["kernel"]}}
+        if b8:
+            b8_val = b8["w"]["flops"] * K / b8["wall"] / 1e12          # ONE global batch: strong scaling
+            line["prefill_b8"] = {"metric": "attn fwd TFLOPS (prefill, batch of 8 dealt to the ranks)", "value": round(b8_val, 2), "unit": "TFLOP/s",
+                                  "ms_per_step": round(b8["wall"] / K * 1e3, 4), "scaling": "strong",
+                                  "config": {"workload": "C2 family: Hq32/Hk8/D128, 8 sequences x 4096 tokens, ONE batch dealt to the ranks by parallel.shard_batch",
+                                             "global_batch": 8, "parallelism": f"batch-sharded x{n_gpus}, no collective",
+                                             "rank0_share": b8["w"]["local"], "kernel": b8["kernel"]}}
         if n_gpus == 1 and not args.no_cpu_baseline:
             if pf:
                 line["cpu_baseline"] = cpu_baseline(pf["w"], pf["w"]["out"])

@@ -149,7 +149,9 @@ typedef struct mi355_attn_params {
   int32_t only_decodes;        /* 1: process only sequences with query_len == 1                  */
                                /*   (filter_by_query_len, triton_paged_decode_attention_2d.py:143-148) */
   int32_t kernel_select;       /* mi355_kernel_select                                            */
-  int32_t num_segments;        /* split-KV segment count for MI355_SELECT_3D; 0 = library picks  */
+  int32_t num_segments;        /* split-KV segment count of the decode path / key-split count of */
+                               /*   a prefill (1 = every Q block walks its whole key range in    */
+                               /*   one pass, the reference's 2D kernel); 0 = library picks       */
   int32_t reserved1;
 
   /* optional second output (library version >= 0.2.0; not in the reference): the natural-log sum of exponentials of every
@@ -171,7 +173,9 @@ typedef struct mi355_attn_params {
   int32_t write_new_kv;
   /* 0 (every op of the reference's backend path): causal - query t of a sequence sees keys j <= t + seqused_k - query_len.
    * 1: every query row sees ALL seqused_k keys of its sequence (prefill_flash_attention(causal=False),
-   * triton_flash_attention.py:1326-1484; no sliding window / ALiBi with it). Served by the shape-agnostic kernel. */
+   * triton_flash_attention.py:1326-1484; no sliding window / ALiBi with it). Served by the 64-rows-per-wave matrix-core
+   * kernel where it applies (bf16 / f16, head size 128, 16-bit cache or linear k_new / v_new), else by the shape-agnostic
+   * kernel. */
   int32_t non_causal;
 
   /* library version >= 0.4.0 */
@@ -294,6 +298,19 @@ MI355_API int mi355_paged_attention_v0(const mi355_attn_params* p, void* workspa
 /* 1 if mi355_unified_attention serves these parameters with write_new_kv = 1 (host arithmetic only), else 0: the caller
  * then issues mi355_reshape_and_cache_flash followed by the plain call. */
 MI355_API int mi355_decode_write_fusable(const mi355_attn_params* p);
+
+/*
+ * Merge of partial attention results over DISJOINT key ranges (library version >= 0.4.0): the exchange step of a
+ * cross-GPU split-KV / context-parallel call after the ranks' (out, lse) have been gathered, and the
+ * arithmetic of reduce_segments (LIB/kernels/triton_unified_attention.py:804-828) on normalised partials:
+ *     lse = log sum_r exp(lse_r),   out = sum_r out_r * exp(lse_r - lse).
+ * part_out [parts, num_tokens, Hq, D] contiguous, in the query type `dtype` (bf16 / f16: what the kernels wrote, no f32
+ * copy); part_lse [parts, num_tokens, Hq] f32 (a range that saw no key: -inf). out [num_tokens, Hq, D] with the given
+ * element strides, lse [num_tokens, Hq] or NULL. 1 <= parts <= 8. One launch, no workspace.
+ */
+MI355_API int mi355_merge_attention_partials(const void* part_out, const float* part_lse, int parts, void* out, float* lse, int dtype,
+                                             int num_tokens, int num_q_heads, int head_size, int64_t out_stride_token, int64_t out_stride_head,
+                                             int64_t lse_stride_token, mi355_stream_t stream);
 
 /* Paged-cache write, see mi355_cache_params. */
 MI355_API int mi355_reshape_and_cache_flash(const mi355_cache_params* p, mi355_stream_t stream);

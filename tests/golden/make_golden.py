@@ -132,9 +132,12 @@ def run_unified(ua, inp, *, window=0, softcap=0.0, alibi=None, k_scale=None, v_s
 
 
 def unified_case(ua, name, *, seed, query_lens, kv_lens, hq, hk, d, page, dtype, kv_dtype=None, kv_scale=1.0,
-                 window=0, softcap=0.0, use_alibi=False, force=None, tile=(16, 16), num_pages=None, v_scale=None):
+                 window=0, softcap=0.0, use_alibi=False, force=None, tile=(16, 16), num_pages=None, v_scale=None, representable_in=None):
     inp = make_paged_inputs(seed, query_lens, kv_lens, hq, hk, d, page, dtype, kv_dtype=kv_dtype, kv_scale=kv_scale,
                             num_pages=num_pages)
+    if representable_in is not None:      # fp32 run on values a 16-bit type holds exactly: the same inputs feed the 16-bit kernels
+        for key in ("q", "k_cache", "v_cache"):
+            inp[key] = inp[key].to(representable_in).to(dtype)
     alibi = None
     if use_alibi:
         alibi = torch.tensor([2.0 ** (-(i + 1) * 8.0 / hq) for i in range(hq)], dtype=torch.float32)
@@ -152,6 +155,10 @@ def unified_case(ua, name, *, seed, query_lens, kv_lens, hq, hk, d, page, dtype,
              seqused_k=inp["seqused_k"], block_table=inp["block_table"], out=out)
     if alibi is not None:
         t["alibi_slopes"] = alibi
+    if representable_in is not None:      # stored in the narrow type (exact), half the bytes
+        meta["stored_as"] = str(representable_in).replace("torch.", "")
+        for key in ("q", "k_cache", "v_cache"):
+            t[key] = t[key].to(representable_in)
     save(name, meta, **t)
 
 
@@ -346,6 +353,14 @@ def main():
     unified_case(ua, "decode_fp8e4m3_kv_fp16q_scales", seed=17, dtype=hf, kv_dtype=e4, kv_scale=0.0237, v_scale=0.041, hq=8, hk=2, **dec)
     unified_case(ua, "mixed_fp8e4m3_kv_fp16q_scales", seed=18, dtype=hf, kv_dtype=e4, kv_scale=0.0237, v_scale=0.041, **mixed)
     unified_case(ua, "mixed_fp8e5m2_kv_fp16q_scales", seed=19, dtype=hf, kv_dtype=e5, kv_scale=0.0237, v_scale=0.041, **mixed)
+
+    # --- round 3: the bf16 fast path (prefill_pw_kernel: bf16 only, chosen from 2048 keys on) against the reference's
+    # 2D kernel itself. bf16 does not run under the Triton interpreter, so the reference computes in fp32
+    # on bf16-REPRESENTABLE inputs, BLOCK_M = BLOCK_N = 64: a 256-token chunk over a 2048-token context (2304 keys)
+    unified_case(ua, "long_chunk_gqa4_d128_bf16rep_fp32", seed=20, dtype=f32, query_lens=[256], kv_lens=[2304], hq=4, hk=1, d=128, page=16,
+                 tile=(64, 64), representable_in=bf)
+    unified_case(ua, "long_chunk_gqa4_d128_f16rep_fp32", seed=21, dtype=f32, query_lens=[256], kv_lens=[2304], hq=4, hk=1, d=128, page=16,
+                 tile=(64, 64), representable_in=hf)
 
     legacy_cases()
     cache_cases()

@@ -35,6 +35,15 @@ def load(name):
     return meta, out
 
 
+def widen(meta, t):
+    """Fixtures whose reference run was fp32 on values a 16-bit type holds exactly store q / k / v in that type
+    (`stored_as`): the tensors as the reference saw them (fp32), for comparisons at fp32 tightness."""
+    if "stored_as" not in meta:
+        return t
+    out_dt = t["out"].dtype
+    return {k: (v.to(out_dt) if k in ("q", "k_cache", "v_cache") else v) for k, v in t.items()}
+
+
 def tolerance(q_dtype, kv_dtype=None):
     """Stated tolerances: fp32 1e-5, fp16 1e-3, bf16 2e-2; +1e-2 for an fp8 KV cache
     (reference: scripts/test.py:310-312)."""

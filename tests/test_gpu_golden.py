@@ -38,3 +38,28 @@ def test_reshape_and_cache_flash_golden(name):
     torch.cuda.synchronize()
     assert torch.equal(kc.cpu().view(torch.uint8), t["k_cache_out"].view(torch.uint8))
     assert torch.equal(vc.cpu().view(torch.uint8), t["v_cache_out"].view(torch.uint8))
+
+
+@pytest.mark.parametrize("name", golden_io.names("long_chunk"))
+def test_64_rows_per_wave_prefill_kernel_vs_the_reference_2d_kernel(name):
+    """`prefill_pw_kernel` (16-bit only, chosen from 2048 keys on) against the reference's own 2D kernel: the fixture is
+    the reference's fp32 run (BLOCK_M = BLOCK_N = 64) on inputs a 16-bit type holds exactly - bf16 does not run under the
+    Triton interpreter - a 256-token chunk over a 2048-token context. `num_segments = 1` asks for the
+    single pass over the key range (the reference's 2D kernel); the auto plan would deal this small grid's keys to
+    several workgroups (covered by the parametrised test above)."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+
+    meta, t = golden_io.load(name)
+    assert t["q"].dtype in (torch.bfloat16, torch.float16) and t["out"].dtype == torch.float32
+    d = gpu_util.to_dev(t)
+    out = torch.full_like(d["q"], float("nan"))
+    ql = meta["query_lens"]
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(ql), d["seqused_k"], max(meta["kv_lens"]), meta["scale"],
+                               (-1, -1), d["block_table"], 0.0, None, None, None, None, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    assert _lib.last_kernel() == "prefill_mfma_pw", _lib.last_kernel()
+    atol, rtol = golden_io.tolerance(t["q"].dtype)
+    torch.testing.assert_close(out.float().cpu(), t["out"], atol=atol, rtol=rtol)

@@ -164,7 +164,7 @@ def test_prefill_c2_full_size_properties():
     scale = 1.0 / math.sqrt(D)
     d = gpu_util.to_dev(t)
     out, kernel = gpu_util.run_unified(d, scale)
-    assert kernel == "prefill_mfma"
+    assert kernel in ("prefill_mfma_pw", "prefill_mfma"), kernel       # the 64-rows-per-wave kernel unless a variant is pinned (test_gpu_variants.py)
     assert not torch.isnan(out).any()
     # sampled query tokens vs the oracle: token at position pos == decode with kv_len pos+1
     for pos in (0, 1, 63, 64, 1000, 2047, 4095):
@@ -258,7 +258,7 @@ def test_prefill_key_split_with_rows_outside_the_fixed_reference_range():
                                        inp["scale"], mode="2d", block_n=64)
     d = gpu_util.to_dev(inp)
     out, kernel = gpu_util.run_unified(d, inp["scale"])
-    assert kernel == "prefill_mfma_ksplit", kernel
+    assert kernel in ("prefill_mfma_pw_ksplit", "prefill_mfma_ksplit"), kernel
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
 
@@ -303,7 +303,7 @@ def test_mixed_c4_full_size_sampled_rows():
     scale = 1.0 / math.sqrt(D)
     d = dict(q=q.to(dev), k_cache=k.to(dev), v_cache=v.to(dev), block_table=bt.to(dev), cu_seqlens_q=cu.to(dev), seqused_k=sl.to(dev))
     out, kernel = gpu_util.run_unified(d, scale)
-    assert kernel == "prefill_mfma+decode_splitkv", kernel
+    assert kernel in ("prefill_mfma_pw+decode_splitkv", "prefill_mfma+decode_splitkv"), kernel
     assert torch.isfinite(out.float()).all()
     cul = cu.tolist()
 
@@ -346,3 +346,58 @@ def test_prefill_with_padding_tokens_behind_the_last_sequence(query_lens, kv_len
     assert torch.isnan(out[T:]).all(), "rows of padding tokens were written"
     assert not torch.isnan(out[:T]).any()
     torch.testing.assert_close(out[:T].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("window", [8, 100, 1024, 3000])
+def test_prefill_sliding_window_on_the_64_rows_per_wave_kernel(dtype, window):
+    """Sliding window (reference: :474-479) from 2048 keys on: a Q block's tile range starts at the window of its first
+    token, the tiles at the window's lower edge carry the lower bound in their mask, steady tiles lie between the two
+    masked ends. Windows shorter than a tile, of a few tiles, and longer than some of the sequences; chunked prefill
+    (context in the cache), a decode row in the batch, rows through the f32 routine."""
+    import gpu_util
+
+    query_lens, kv_lens = [700, 270, 1, 2100], [2300, 2100, 2500, 2100]
+    inp = orc.make_paged_inputs(35 + window, query_lens, kv_lens, 8, 2, 128, 16, dtype)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], sliding_window=window, mode="2d", block_n=64)
+    _, ref_lse = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                          inp["scale"], sliding_window=window, return_lse=True)
+    d = gpu_util.to_dev(inp)
+    lse = torch.full((inp["q"].shape[0], 8), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    # (num_segments = 1: every Q block walks its key range in one pass - the auto plan deals this small grid's keys to
+    # several workgroups of the register-staged kernel)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (window - 1, 0), d["block_table"], 0.0, None, None, None, None, lse=lse, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
+    assert kernel.startswith("prefill_mfma_pw_sw"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    torch.testing.assert_close(lse.cpu(), ref_lse.float(), atol=2e-2, rtol=1e-3)
+    out9, _ = gpu_util.run_unified(d, inp["scale"], window=window, force=9)
+    torch.testing.assert_close(out.float(), out9.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("gains", [(0.0, 4.0, -4.0), (0.0, 30.0, 0.0, -30.0), (0.0, 0.0, 100.0, -100.0)])
+def test_prefill_f16_rows_whose_scores_sit_far_from_zero(gains):
+    """The f16 instantiation of the 64-rows-per-wave kernel: P <= 65504, so every row computes P = 2^(score - m_ref)
+    against ITS OWN reference (the largest score among the first keys of its first tile, with 6 powers of two of
+    margin). Rows whose scores all sit at +-20 .. +-540 log2 units must come out at f16 tolerance like any other."""
+    import gpu_util
+
+    query_lens, kv_lens = [700, 270, 1], [2300, 2100, 2500]
+    inp = _spiked_inputs(37, query_lens, kv_lens, 8, 2, gains)
+    inp = {k: (v.to(torch.float16) if isinstance(v, torch.Tensor) and v.dtype == torch.bfloat16 else v) for k, v in inp.items()}
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(d, inp["scale"])
+    assert kernel.startswith("prefill_mfma_pw"), kernel
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-3, rtol=2e-3)

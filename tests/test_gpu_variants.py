@@ -53,6 +53,16 @@ def test_prefill_64_rows_per_wave_kernel_on_small_shapes():
          keyword="(mixed and 128 and dtype0) or page_sizes or strided or leave or agree")
 
 
+def test_prefill_64_rows_per_wave_kernel_in_f16():
+    """The f16 instantiation (P <= 65504: every row's reference leaves 22 powers of two above its estimate) pinned on
+    the small parity shapes, the C2 size, the lse shapes and rows whose scores sit far from zero."""
+    _run({"MI355_PREFILL": "pw", "MI355_PREFILL_KEY_SPLITS": "1"},
+         ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_page_sizes", "tests/test_gpu_fuzz.py"],
+         keyword="(mixed and 128 and dtype1) or page_sizes or agree")
+    _run({"MI355_PREFILL": "pw", "MI355_PW_SLOTS": "2"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill_ksplit.py"],
+         keyword="(mixed and 128 and dtype1) or fp16")
+
+
 def test_prefill_64_rows_per_wave_kernel_walking_many_items_per_workgroup():
     """Two workgroups per KV head (MI355_PW_SLOTS): every workgroup walks many work items - several sequences, empty Q
     blocks, key splits - with the next item's loads in flight over the current item's output; batches of several

@@ -21,6 +21,7 @@ def _run_oracle(meta, t, fn=orc.unified_attention_oracle, **kw):
 @pytest.mark.parametrize("name", UNIFIED)
 def test_oracle_matches_reference_kernels(name):
     meta, t = golden_io.load(name)
+    t = golden_io.widen(meta, t)          # (16-bit-representable fp32 fixtures: the reference computed in fp32)
     out = _run_oracle(meta, t, mode=meta["path"], block_n=meta["tile"][1])
     atol, rtol = golden_io.tolerance(t["q"].dtype, t["k_cache"].dtype)
     # same algorithm, same tiling -> much tighter than the stated cross-implementation tolerance
@@ -31,6 +32,7 @@ def test_oracle_matches_reference_kernels(name):
 @pytest.mark.parametrize("name", UNIFIED)
 def test_oracle_matches_dense_fp64(name):
     meta, t = golden_io.load(name)
+    t = golden_io.widen(meta, t)
     dense = _run_oracle(meta, t, fn=orc.dense_attention_fp64)
     for mode in ("2d", "3d"):
         out = _run_oracle(meta, t, mode=mode, block_n=t["k_cache"].shape[1])

@@ -25,12 +25,16 @@ def main():
     ap.add_argument("--page", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kvdtype", default="same", choices=["same", "fp8", "fp8_e5m2"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--window", type=int, default=0, help="sliding window (keys per query row), 0 = off; FLOPs count the visible keys only")
+    ap.add_argument("--softcap", type=float, default=0.0)
+    ap.add_argument("--segments", type=int, default=0, help="num_segments of the call (1 = no key split)")
     ap.add_argument("--legacy", action="store_true", help="context_attention_fwd: v0 cache layout for the first --ctx keys, the rest from linear k/v")
     ap.add_argument("--ctx", type=int, default=0, help="context keys per sequence already in the cache (query length = seq - ctx)")
     ap.add_argument("--generic", action="store_true", help="with --legacy: force the shape-agnostic kernel (the path before the repack)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    dt = torch.bfloat16
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     torch.manual_seed(0)
     B, L, page = args.batch, args.seq, args.page
     pps = (L + page - 1) // page
@@ -45,7 +49,13 @@ def main():
     sl = torch.full((B,), L, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
     flops = 4 * L * L * args.d * args.hq / 2 * B
-    p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), (-1, -1), bt, 0.0, ksc, ksc, None, None)
+    win = (args.window - 1, 0) if args.window else (-1, -1)
+    if args.window:          # row at position i sees min(i + 1, window) keys
+        W = args.window
+        vis = sum(min(i + 1, W) for i in range(L))
+        flops = 4 * args.d * args.hq * vis * B
+    p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), win, bt, args.softcap, ksc, ksc, None, None,
+                                      num_segments=args.segments)
     if args.ctx and not args.legacy:     # chunked prefill through unified_attention: the last seq - ctx tokens are the queries
         QL = L - args.ctx
         q = q[: B * QL].contiguous()

@@ -79,7 +79,11 @@ enum class Path { Generic, Decode, Prefill, PrefillPlusDecode, Repacked };
 static Path choose(const mi355_attn_params& p) {
   const int sel = p.kernel_select;
   if (p.write_new_kv) return Path::Decode;     // validated: the fused decode kernel takes it
-  if (p.non_causal) return Path::Generic;      // every MFMA kernel is built around the causal mask
+  // non-causal: prefill_pw_kernel takes it (a context that covers the whole sequence); everything it does not serve
+  // (f32, other head sizes, soft-cap ...) runs on the shape-agnostic kernel, which reads linear k_new / v_new itself
+  const bool nc_fast = p.non_causal && sel != MI355_SELECT_GENERIC && sel != MI355_SELECT_3D && (p.k_new ? repack_supported(p) && prefill_pw_applicable(repacked_params(p, nullptr, 0))
+                                                                               : prefill_supported(p) && prefill_pw_applicable(p));
+  if (p.non_causal && !nc_fast) return Path::Generic;
   if (sel == MI355_SELECT_GENERIC) return Path::Generic;
   // legacy ops: cache in the v0 layout and/or new keys in linear tensors - gathered into a flash-layout scratch
   // cache first, then the kernels below run on that (repack.hip)
@@ -241,6 +245,17 @@ int mi355_paged_attention_v0(const mi355_attn_params* p, void* workspace, size_t
     return MI355_ERR_BAD_ARG;
   }
   return mi355_unified_attention(p, workspace, workspace_bytes, stream);
+}
+
+int mi355_merge_attention_partials(const void* part_out, const float* part_lse, int parts, void* out, float* lse, int dtype, int num_tokens,
+                                   int num_q_heads, int head_size, int64_t out_stride_token, int64_t out_stride_head, int64_t lse_stride_token,
+                                   mi355_stream_t stream) {
+  if (num_tokens < 0 || num_q_heads <= 0 || head_size <= 0) { set_error("merge: bad sizes"); return MI355_ERR_BAD_ARG; }
+  if (num_tokens == 0) return MI355_OK;
+  if (!part_out || !part_lse || !out) { set_error("merge: part_out / part_lse / out must be non-NULL"); return MI355_ERR_BAD_ARG; }
+  if (lse && lse_stride_token < num_q_heads) { set_error("merge: lse_stride_token is smaller than num_q_heads"); return MI355_ERR_BAD_ARG; }
+  return launch_merge_partials(part_out, part_lse, parts, out, lse, dtype, num_tokens, num_q_heads, head_size, out_stride_token, out_stride_head,
+                               lse_stride_token, (hipStream_t)stream);
 }
 
 int mi355_reshape_and_cache_flash(const mi355_cache_params* p, mi355_stream_t stream) {

@@ -330,6 +330,8 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
 size_t prefill_workspace_bytes(const mi355_attn_params& p);                                   // key-split partials, 0 if none
 int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream);
 const char* mi355_last_kernel_name();
+int launch_merge_partials(const void* part_out, const float* part_lse, int parts, void* out, float* lse, int dtype, int num_tokens,
+                          int num_q_heads, int head_size, int64_t out_stride_token, int64_t out_stride_head, int64_t lse_stride_token, hipStream_t stream);
 // legacy layouts / linear new-token source -> flash-layout scratch cache (repack.hip)
 bool repack_supported(const mi355_attn_params& p);
 size_t repack_scratch_bytes(const mi355_attn_params& p, size_t head);

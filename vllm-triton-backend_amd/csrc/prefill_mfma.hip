@@ -25,6 +25,7 @@
 // Launch grid mirrors the reference's static upper bound (T / BLOCK_Q + S Q-blocks, :886-889,
 // :935-943), heaviest (latest) Q blocks first.
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -1128,7 +1129,11 @@ static size_t prefill_bt_lds_bytes(const mi355_attn_params& p) {
 struct KeySplitPlan { int splits, tiles_per_split; bool wide; };   // wide: on the 8-wave / 256-row LDS-DMA kernel
 
 static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
-  static const char* env = getenv("MI355_PREFILL_KEY_SPLITS");   // measurements: force a split count (1 = never split)
+  static const char* env_s = getenv("MI355_PREFILL_KEY_SPLITS");   // measurements: force a split count (1 = never split)
+  // ... or the caller's num_segments (include/mi355_attn.h): 1 = one pass over the whole key range per Q block
+  char forced_buf[16];
+  const char* env = env_s;
+  if (!env && p.num_segments > 0) { snprintf(forced_buf, sizeof(forced_buf), "%d", p.num_segments); env = forced_buf; }
   const int G = p.num_q_heads / p.num_kv_heads, block_q = kBlockM / G;
   const long wgs = ((long)p.num_tokens / block_q + p.num_seqs) * p.num_kv_heads;
   const int tiles = (std::max(p.max_seqlen_k, 1) + kTileN - 1) / kTileN;
@@ -1156,7 +1161,8 @@ static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
   // two workgroups per CU, >= 8 tiles each (one sequence, Hq 32 / Hk 8: 512-token chunk at 8k keys 167 -> 79 us with 4
   // splits, at 32k keys 655 -> 275; two such chunks 112 -> 79 with 2; a 1024-token chunk at 32k keys 652 -> 534 with 2)
   // (392 / 408 workgroups: +10 % / +8 % with 2 splits; 520: nothing; 1040: -14 %)
-  if (!env && wgs < 512 && tiles >= 32) splits = (int)std::min<long>((512 + wgs - 1) / wgs, tiles / 8);
+  if (!env && wgs < 512 && tiles >= 32 && !p.non_causal) splits = (int)std::min<long>((512 + wgs - 1) / wgs, tiles / 8);
+  if (p.non_causal) splits = 1;                       // (only the wide plan above splits a non-causal call: its kernel is the one that serves it)
   splits = std::max(1, std::min(std::min(splits, kMaxKeySplits), tiles));
   const int tps = (tiles + splits - 1) / splits;
   return {(tiles + tps - 1) / tps, tps, false};
@@ -1199,8 +1205,8 @@ __global__ __launch_bounds__(256) void merge_key_splits_kernel(const MergeArgs a
   const int c = (int)(idx % chunks);
   const int64_t tok = row / p.num_q_heads;
   const int hq = (int)(row % p.num_q_heads);
-  if (tok >= p.cu_seqlens_q[p.num_seqs]) return;   // padding tokens past the last sequence belong to nobody
-  if (p.skip_decodes) {      // rows of query_len == 1 sequences were not computed and must stay untouched
+  if (p.cu_seqlens_q && tok >= p.cu_seqlens_q[p.num_seqs]) return;   // padding tokens past the last sequence belong to nobody
+  if (p.skip_decodes && p.cu_seqlens_q) {      // rows of query_len == 1 sequences were not computed and must stay untouched
     const int seq = find_seq_by_token(p.cu_seqlens_q, p.num_seqs, (int)tok);
     if (p.cu_seqlens_q[seq + 1] - p.cu_seqlens_q[seq] == 1) return;
   }
@@ -1241,6 +1247,32 @@ __global__ __launch_bounds__(256) void merge_key_splits_kernel(const MergeArgs a
   if (p.lse && c == 0) p.lse[tok * p.lse_stride_token + hq] = den > 0.0f ? m + __logf(den) : -INFINITY;
 }
 
+
+// The same merge as an entry point of its own (mi355_merge_attention_partials): the exchange step of a cross-GPU split-KV
+// (context-parallel) call hands every rank R normalised partial outputs + lse's of disjoint key ranges.
+int launch_merge_partials(const void* part_out, const float* part_lse, int parts, void* out, float* lse, int dtype, int num_tokens,
+                          int num_q_heads, int head_size, int64_t out_stride_token, int64_t out_stride_head, int64_t lse_stride_token, hipStream_t stream) {
+  if (parts < 1 || parts > kMaxKeySplits) { set_error("merge: %d partial results (1 .. %d are served)", parts, kMaxKeySplits); return MI355_ERR_UNSUPPORTED; }
+  if (!(dtype == MI355_BF16 || dtype == MI355_F16) || head_size % 8 != 0 || ((uintptr_t)part_out & 15) != 0 || ((uintptr_t)out & 7) != 0 ||
+      out_stride_token % 4 != 0 || out_stride_head % 4 != 0) {
+    set_error("merge: bf16 / f16 partials, head size a multiple of 8, 16-byte aligned partials, 8-byte aligned rows of out");
+    return MI355_ERR_UNSUPPORTED;
+  }
+  MergeArgs m;
+  memset(&m.p, 0, sizeof(m.p));
+  m.p.out = out; m.p.lse = lse;
+  m.p.num_tokens = num_tokens; m.p.num_q_heads = num_q_heads; m.p.head_size = head_size;
+  m.p.out_stride_token = out_stride_token; m.p.out_stride_head = out_stride_head; m.p.lse_stride_token = lse_stride_token;
+  m.part_out = (const uint16_t*)part_out;
+  m.part_lse = part_lse;
+  m.splits = parts;
+  const int64_t work = (int64_t)num_tokens * num_q_heads * (head_size / 8);
+  if (work == 0) return MI355_OK;
+  const dim3 grid((unsigned)((work + 255) / 256));
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(merge_key_splits_kernel<bf16_t>, grid, dim3(256), 0, stream, m);
+  else hipLaunchKernelGGL(merge_key_splits_kernel<f16_t>, grid, dim3(256), 0, stream, m);
+  return check_hip(hipGetLastError(), "merge_key_splits_kernel launch");
+}
 
 // cache element type as a function of the query type
 template <typename T> using kv_same = T;
@@ -1308,6 +1340,7 @@ bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
   const bool v1 = variant && variant[0] == 'v' && variant[1] == '1';
   if (!prefill_supported(p) || !prefill_pw_applicable(p) || v1 || (variant && variant[0] != 'p')) return false;
   const bool pinned = variant && variant[0] == 'p';
+  if (p.non_causal) return !ks || ks->wide;           // the one matrix-core kernel without the causal diagonal built in
   const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= 2048;
   return pinned ? (!ks || ks->wide) : use_pw;
 }

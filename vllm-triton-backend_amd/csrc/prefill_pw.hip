@@ -65,6 +65,8 @@ constexpr int kPwRows = 256;         // Q-block rows per workgroup
 constexpr float kPwLog2e = 1.4426950408889634f;
 constexpr float kPwSumLo = 5.421010862427522e-20f;   // 2^-64: below it a row's largest P may be close to the subnormals
 constexpr float kPwSumHi = 1.2676506002282294e30f;   // 2^100: above it a P or a partial sum may have overflowed
+constexpr float kPwRefMax = 1024.0f;                  // |reference| (log2 units) beyond which a row goes to the f32 routine (rounding of Q')
+constexpr float kPwSumLoF16 = 2.44140625e-4f;        // f16: 2^-12 (P's grid ends at 2^-24: below this sum too few bits are left)
 
 // accumulator-register map (owned by the asm statements below)
 constexpr int kAO = 0;     // O^T[sb][b]  : kAO + 64 sb + 16 b   (16 registers)
@@ -224,36 +226,41 @@ template <typename T> struct pw_ops;
 MI355_DEF_PW_OPS(bf16_t, "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
 #undef MI355_DEF_PW_OPS
 
-// The same contractions on v_mfma_f32_16x16x32_bf16 (M16 instantiation of the kernel): 4-register accumulators.
+// The same contractions on v_mfma_f32_16x16x32_{bf16,f16} (M16 instantiation of the kernel): 4-register accumulators.
 typedef __attribute__((ext_vector_type(4))) float wf32x4_t;
-struct pw_ops16 {
-  template <int KA, int QA> static __device__ __forceinline__ void qk_zero(wf32x4_t& s) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
-  }
-  template <int KA, int QA> static __device__ __forceinline__ void qk_acc(wf32x4_t& s) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
-  }
-  // hand-owned forms (see the state block of prefill_pw_kernel): the written registers are named as inputs
-  template <int KA, int QA> static __device__ __forceinline__ void qk_zero_ho(const wf32x4_t& s) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
-  }
-  template <int KA, int QA> static __device__ __forceinline__ void qk_acc_ho(const wf32x4_t& s) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
-  }
-  // row sums on the matrix pipe: l += 1 . P^T (A = sixteen rows of ones: every register of l holds the row's whole sum)
-  static __device__ __forceinline__ void lsum_ho(const wf32x4_t& l, const wu32x4_t& ones, const wu32x4_t& pf) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" :: "v"(l), "v"(ones), "v"(pf));
-  }
-  static __device__ __forceinline__ void pack_ho(uint32_t pk, float lo, float hi) {
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" :: "v"(pk), "v"(lo), "v"(hi));
-  }
-  template <int KA, int QA> static __device__ __forceinline__ void qk_acc_masked(wf32x4_t& s) {      // (see pw_ops)
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
-  }
-  template <int OA> static __device__ __forceinline__ void pv(const wu32x4_t& v, const wu32x4_t& pf) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pf), "n"(OA), "n"(OA + 3));
-  }
-};
+template <typename T> struct pw_ops16;
+#define MI355_DEF_PW_OPS16(TAG, MFMA, CVT, ONES)                                                                    \
+  template <> struct pw_ops16<TAG> {                                                                              \
+    static constexpr uint32_t kOnes = ONES;          /* a pair of 1.0 */                                            \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_zero(wf32x4_t& s) {                       \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));  \
+    }                                                                                                             \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_acc(wf32x4_t& s) {                        \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3)); \
+    }                                                                                                             \
+    /* hand-owned forms (see the state block of prefill_pw_kernel): the written registers are named as inputs */  \
+    /* a chain starts from the row's reference: C = -m_ref in all four registers (see the reference block) */     \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_ref_ho(const wf32x4_t& s, const wf32x4_t& r) { \
+      asm volatile(MFMA " %0, a[%c2:%c3], a[%c4:%c5], %1" :: "v"(s), "v"(r), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3)); \
+    }                                                                                                             \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_acc_ho(const wf32x4_t& s) {               \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], %0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));  \
+    }                                                                                                             \
+    /* row sums on the matrix pipe: l += 1 . P^T (A = sixteen rows of ones: every register of l holds the row's */ \
+    /* whole sum) */                                                                                               \
+    static __device__ __forceinline__ void lsum_ho(const wf32x4_t& l, const wu32x4_t& ones, const wu32x4_t& pf) { \
+      asm volatile(MFMA " %0, %1, %2, %0" :: "v"(l), "v"(ones), "v"(pf));                                          \
+    }                                                                                                             \
+    static __device__ __forceinline__ void pack_ho(uint32_t pk, float lo, float hi) {                             \
+      asm volatile(CVT " %0, %1, %2" :: "v"(pk), "v"(lo), "v"(hi));                                                \
+    }                                                                                                             \
+    template <int OA> static __device__ __forceinline__ void pv(const wu32x4_t& v, const wu32x4_t& pf) {          \
+      asm volatile(MFMA " a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pf), "n"(OA), "n"(OA + 3));               \
+    }                                                                                                             \
+  };
+MI355_DEF_PW_OPS16(bf16_t, "v_mfma_f32_16x16x32_bf16", "v_cvt_pk_bf16_f32", 0x3f803f80u)
+MI355_DEF_PW_OPS16(f16_t, "v_mfma_f32_16x16x32_f16", "v_cvt_pk_f16_f32", 0x3c003c00u)
+#undef MI355_DEF_PW_OPS16
 
 template <typename T> __device__ __forceinline__ float pw_lo(uint32_t w);
 template <typename T> __device__ __forceinline__ float pw_hi(uint32_t w);
@@ -269,6 +276,13 @@ template <int IDX> __device__ __forceinline__ void acc_write(uint32_t v) { asm v
 template <int IDX> __device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "n"(IDX)); }
 // running maximum of magnitudes: m = max(m, |a|, |b|) in one instruction (a NaN operand is dropped, like fmaxf)
 __device__ __forceinline__ void pw_amax3(float& m, float a, float b) { asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b)); }
+template <int IDX> __device__ __forceinline__ uint32_t acc_read_u32() { uint32_t r; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "n"(IDX)); return r; }
+// 16 bytes from sbase + voff (+ an immediate) straight into four accumulator registers: the destination is a literal in
+// the statement, the compiler never sees it (nothing to copy early, no VGPR held while the load is in flight). The
+// caller retires it with an s_waitcnt of its own.
+template <int AG, int IMM> __device__ __forceinline__ void pw_gload16_acc(uint32_t voff, uint64_t sbase) {
+  asm volatile("global_load_dwordx4 a[%c0:%c1], %2, %3 offset:%c4" :: "n"(AG), "n"(AG + 3), "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
 template <int IDX> __device__ __forceinline__ float acc_read() { float r; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "n"(IDX)); return r; }
 
 // LDS -> accumulator registers (K fragments), LDS -> VGPR transposed (V fragments). "memory": LDS accesses the
@@ -362,11 +376,16 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
 // MI355X_MICROARCH.md DVFS give-back item 7). Lane (r16 = lane & 15, g4 = lane >> 4) then owns query rows
 // 32 x + 16 rt + r16 (sub-block x, row tile rt) and, of a 16-key tile kt, the keys 16 kt + 4 g4 + r; register maps:
 // K[kt][ks] kAK + 16 kt + 4 ks, Q'[x][rt][ks] kAQ + 32 x + 16 rt + 4 ks, O[x][rt][db] kAO + 64 x + 32 rt + 4 db.
-template <typename T, bool M16>
+// SW (M16 only): sliding window. A Q block's tile range starts at the window of its first token (the reference's 2D kernel
+// only masks, :474-479; prefill_mfma_kernel tightens the same way), the tiles at the window's lower edge are general
+// iterations with the lower bound in their mask, and the steady stretch lies between the two masked ends.
+template <typename T, bool M16, bool SW>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
-  using ops = pw_ops<T>;
+  static_assert(M16 || !SW, "the sliding window is built into the 16x16x32 instantiation only");
+  using ops = pw_ops<bf16_t>;                  // the 32x32x16 form exists for bf16 only (its fixed reference 0 needs bf16's exponent range)
+  using ops16 = pw_ops16<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
-  static_assert(__is_same(T, bf16_t), "P = 2^s with the reference 0 needs the exponent range of bf16");
+  static_assert(M16 || __is_same(T, bf16_t), "P = 2^s with the reference 0 needs the exponent range of bf16");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   asm volatile("" ::: "a255");                 // the kernel owns all 256 accumulator registers
   const mi355_attn_params& p = a.p;
@@ -389,6 +408,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     int q_st, q_sh, out_st, out_sh;    // elements; the host admits [0, 2^22)
     int64_t lse_st, bt_stride, out_split_stride, lse_split_stride;
     int num_seqs, key_splits, num_qblocks, slots, G, BQ, g_shift, bq_shift, page_shift, skip_decodes, only_decodes, num_kv_heads;
+    int window, non_causal;
   };
   int lane_o = lane;
   KernArgs kp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -406,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sa.num_seqs = kp->p.num_seqs; sa.key_splits = kp->key_splits; sa.num_qblocks = kp->num_qblocks; sa.slots = kp->slots;
     sa.G = kp->group; sa.BQ = kp->block_q; sa.g_shift = kp->g_shift; sa.bq_shift = kp->bq_shift; sa.page_shift = kp->page_shift;
     sa.skip_decodes = kp->p.skip_decodes; sa.only_decodes = kp->p.only_decodes; sa.num_kv_heads = kp->p.num_kv_heads;
+    sa.window = SW ? kp->p.sliding_window : 0; sa.non_causal = kp->p.non_causal;
   };
   refresh_lane();
   // x / G, x % G, x / BQ for x >= 0: shifts when the divisor is a power of two (every GQA ratio in use), else the division
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // ONE workgroup is what lets the next item's query rows and first K/V tiles load while this item's output is
   // normalised and stored - a fresh workgroup pays that chain of round trips (~5 us) with its CU idle.
   struct Item {
-    int seq, q_start, q_len, seq_len, ctx_len, tok0, ksplit, tile_lo, tile_hi, last_group, w_tok_lo, rank;
+    int seq, q_start, q_len, seq_len, ctx_len, tok0, ksplit, tile_lo, tile_hi, last_group, w_tok_lo, w_tok_hi, rank;
     uint64_t bt64;                     // this sequence's block-table row
     uint16_t* out_base;
     float* lse_base;
@@ -478,17 +499,21 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       const int qb_local = qblock - (div_bq(q_start) + seq);
       if (qb_local * BQ >= q_len || (sa.skip_decodes && q_len == 1) || (sa.only_decodes && q_len != 1)) return false;
       I.seq = seq; I.q_start = q_start; I.q_len = q_len; I.seq_len = seq_len;
-      I.ctx_len = seq_len - q_len;
+      // non-causal (prefill_flash_attention(causal=False)): every row sees all seq_len keys - which is what every
+      // visibility formula below gives for a context that already covers the whole sequence
+      I.ctx_len = sa.non_causal ? seq_len : seq_len - q_len;
       I.tok0 = qb_local * BQ;
       I.w_tok_lo = I.tok0 + div_g(wave * 64);
+      I.w_tok_hi = min(I.tok0 + div_g(wave * 64 + 63), q_len - 1);
       const int wg_tok_hi = min(I.tok0 + BQ - 1, q_len - 1);
       const int n_keys_wg = max(0, min(I.ctx_len + wg_tok_hi + 1, seq_len));
       I.last_group = (max(n_keys_wg, 1) - 1) >> 4;                 // last 16-key group this Q block can see
       I.tile_lo = 0;
       I.tile_hi = (n_keys_wg + kPwTile - 1) / kPwTile;
+      if (SW && sa.window > 0) I.tile_lo = min(max(I.ctx_len + I.tok0 - sa.window + 1, 0) >> 6, I.tile_hi);   // first key the block's first token sees
       if (sa.key_splits > 1) {                    // key-split launch: an even share of this Q block's tiles
-        const int tps = (I.tile_hi + sa.key_splits - 1) / sa.key_splits;
-        I.tile_lo = min(I.ksplit * tps, I.tile_hi);
+        const int tps = (I.tile_hi - I.tile_lo + sa.key_splits - 1) / sa.key_splits;
+        I.tile_lo = min(I.tile_lo + I.ksplit * tps, I.tile_hi);
         I.tile_hi = min(I.tile_hi, I.tile_lo + tps);
       }
       I.out_base = sa.out + (int64_t)I.ksplit * sa.out_split_stride;
@@ -558,6 +583,11 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     const int tok = I.tok0 + div_g(m_row);
     return ((m_row < sa.BQ * sa.G) && (tok < I.q_len)) ? min(I.ctx_len + tok, I.seq_len - 1) : -1;
   };
+  // first visible key of the same row under a sliding window (keys j with position - j < window)
+  auto row_lo = [&](const Item& I, int sb) __attribute__((always_inline)) {
+    const int m_row = wave * 64 + sb * 16 + (lane_o & 15);
+    return I.ctx_len + I.tok0 + div_g(m_row) - sa.window + 1;
+  };
   auto row_of = [&](const Item& I, int sb, int& tok_local, int& hq) __attribute__((always_inline)) {
     const int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + (lane_o & 31);   // M16: sb = 2 x + rt
     tok_local = I.tok0 + div_g(m_row);
@@ -570,23 +600,22 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     return ((uint64_t)hi << 32) | lo;
   };
 
-  // ---- Q rows -> registers (padding rows read the sequence's last query row and are zeroed on conversion): scalar base,
-  // 32-bit lane offset (the host admits strides below 2^22 elements). Ordinary loads, so that the compiler never touches
-  // their registers before they have landed (it copies the outputs of an asm load at will); its wait before their first
-  // use counts only what IT issued after them - the epilogue's stores - and the LDS-DMA pieces between are older than
-  // those, so the wait covers them too (vmcnt retires in order).
-  wu32x4_t qraw[2][8];
+  // ---- Q rows -> the Q accumulator registers, raw (padding rows read the sequence's last query row and are zeroed on
+  // conversion): scalar base, 32-bit lane offset (the host admits strides below 2^22 elements), the destination a
+  // literal a[..] range of the asm statement. The previous item's Q' is dead by now (the seam sits behind its last matrix
+  // instruction), so the rows land where their scaled form will live - no VGPR carries them across the epilogue (64 of
+  // them did until round 3, the peak of the kernel's VGPR demand). Retired by the s_waitcnt vmcnt(0) of
+  // zero_o_and_convert_q; vmcnt is in order, so the compiler's own waits only ever over-wait for these.
   auto issue_q = [&](const Item& I) __attribute__((always_inline)) {
     // scalar address of the block's first token and this KV head's first query head; a lane's row is within 2^31 bytes of it
     const uint64_t qb = uniform64((uint64_t)(sa.q + (int64_t)(I.q_start + I.tok0) * (int64_t)sa.q_st + (int64_t)(head * sa.G) * (int64_t)sa.q_sh));
-    if constexpr (M16) {        // qraw[rt4 >> 1][4 (rt4 & 1) + ks] = Q[row 16 rt4 + r16][32 ks + 8 g4 .. + 7]
+    if constexpr (M16) {        // a[kAQ + 16 rt4 + 4 ks ..] = Q[row 16 rt4 + r16][32 ks + 8 g4 .. + 7]
       sfor<4>([&](auto RT) {
         constexpr int rt4 = decltype(RT)::value;
         int tok_local, hq;
         row_of(I, rt4, tok_local, hq);
         const uint32_t off = (uint32_t)(((min(tok_local, I.q_len - 1) - I.tok0) * sa.q_st + (hq - head * sa.G) * sa.q_sh + 8 * (lane_o >> 4)) * 2);
-        typedef const __attribute__((address_space(1))) char* gq_t;
-        sfor<4>([&](auto KS) { constexpr int ks = decltype(KS)::value; qraw[rt4 >> 1][4 * (rt4 & 1) + ks] = *(const __attribute__((address_space(1))) wu32x4_t*)((gq_t)qb + off + 64 * ks); });
+        sfor<4>([&](auto KS) { constexpr int ks = decltype(KS)::value; pw_gload16_acc<kAQ + 16 * rt4 + 4 * ks, 64 * ks>(off, qb); });
       });
     } else
     sfor<2>([&](auto SB) {
@@ -594,8 +623,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       int tok_local, hq;
       row_of(I, sb, tok_local, hq);
       const uint32_t off = (uint32_t)(((min(tok_local, I.q_len - 1) - I.tok0) * sa.q_st + (hq - head * sa.G) * sa.q_sh + 8 * (lane_o >> 5)) * 2);
-      typedef const __attribute__((address_space(1))) char* gq_t;
-      sfor<8>([&](auto KS) { constexpr int ks = decltype(KS)::value; qraw[sb][ks] = *(const __attribute__((address_space(1))) wu32x4_t*)((gq_t)qb + off + 32 * ks); });
+      sfor<8>([&](auto KS) { constexpr int ks = decltype(KS)::value; pw_gload16_acc<kAQ + 32 * sb + 4 * ks, 32 * ks>(off, qb); });
     });
   };
 
@@ -719,23 +747,21 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     group(I.tile_lo + 1, pv1, ic<1>{}, kLdsV + kSlotBytes);
   };
 
-  // ---- O = 0 and Q' = Q * scale * log2(e), packed, into accumulator registers ---------------------------
+  // ---- O = 0 and Q' = Q * scale * log2(e), packed, in place in the accumulator registers the raw rows landed in ---
   const float scale2 = p.scale * kPwLog2e;
   auto zero_o_and_convert_q = [&](const Item& I) __attribute__((always_inline)) {
     sfor<128>([&](auto IC) { acc_zero<kAO + decltype(IC)::value>(); });
     // the item's query rows have landed (and everything older: its first tiles, the previous item's output)
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[0][4]), "+v"(qraw[0][5]), "+v"(qraw[0][6]), "+v"(qraw[0][7]),
-                   "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]), "+v"(qraw[1][4]), "+v"(qraw[1][5]), "+v"(qraw[1][6]), "+v"(qraw[1][7])
-                 :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     sfor<2>([&](auto SB) {
       sfor<8>([&](auto KS) {
-        // (M16: qraw[x][4 rt + ks] is Q'[x][rt][ks], whose registers are kAQ + 32 x + 16 rt + 4 ks: the same index arithmetic)
+        // (M16: registers kAQ + 32 x + 16 rt + 4 ks are Q'[x][rt][ks]: with ks8 = 4 rt + ks the same index arithmetic)
         constexpr int sb = decltype(SB)::value, ks = decltype(KS)::value;
-        const wu32x4_t v = row_lim(I, M16 ? 2 * sb + (ks >> 2) : sb) >= 0 ? qraw[sb][ks] : wu32x4_t{0, 0, 0, 0};
+        const bool valid = row_lim(I, M16 ? 2 * sb + (ks >> 2) : sb) >= 0;
         sfor<4>([&](auto E) {
-          constexpr int e = decltype(E)::value;
-          acc_write<kAQ + 32 * sb + 4 * ks + e>(pw_pack<T>(pw_lo<T>(v[e]) * scale2, pw_hi<T>(v[e]) * scale2));
+          constexpr int e = decltype(E)::value, idx = kAQ + 32 * sb + 4 * ks + e;
+          const uint32_t v = valid ? acc_read_u32<idx>() : 0u;
+          acc_write<idx>(pw_pack<T>(pw_lo<T>(v) * scale2, pw_hi<T>(v) * scale2));
         });
       });
     });
@@ -762,11 +788,24 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // M16: S16[x][rt][kt] (keys 16 kt + 4 g4 + r of row 32 x + 16 rt + r16), pw16[x][rt][c] (the B operand of the P.V step
   // over keys 32 c ..: dwords (kt = 2c: r 0,1 | r 2,3 | kt = 2c + 1: r 0,1 | r 2,3)), vfr16[db][c], row sums per (x, rt)
   // (hand-owned as well; the row sums come off the matrix pipe: L16[x][rt] += 1 . P^T, two instructions per tile each)
-  wf32x4_t S16[2][2][4];
+  // (ONE set of score registers serves both sub-blocks: S_A is written in segment 1 and its last exponential issues
+  // before segment 2 ends; S_B is written from segment 3 on and consumed by the end of segment 4 - in steady and general
+  // iterations alike. Key tiles are consumed in the order they are produced, so the first chains of a segment write
+  // registers whose exponentials issued a segment earlier.)
+  wf32x4_t S16[1][2][4];
   wu32x4_t pwv16[2][2][2];
   wu32x4_t vfr16[8][2];
   wf32x4_t L16[2][2];
   wu32x4_t ones16;
+  // The rows' REFERENCES (M16): R16[x][rt] = -m_ref of this lane's row in all four registers, the C operand every score
+  // chain starts from, so that P = 2^(s - m_ref) comes straight off the exponential. m_ref is an ESTIMATE of the row's
+  // largest score - the maximum over the first 16 keys of the item's first tile (set_references, 16 matrix instructions
+  // per item) - not a running maximum: softmax is shift invariant, so any reference gives the same result as long as
+  // P and its sums stay inside the format, and that is checked per row when the block is done (bf16: scores within
+  // ~+-90 of the reference in log2 units; f16: P <= 65504 leaves 16 + kRefMargin above it, and what falls 24 - kRefMargin
+  // below it rounds to zero - 2^-18 of the reference term). A fixed reference 0 (rounds 1-2) failed for any row whose
+  // scores all sit far from zero; the first keys of a row are where attention sinks live.
+  wf32x4_t R16[2][2];
   auto reset_state = [&]() __attribute__((always_inline)) {
     if constexpr (M16) {
 #pragma unroll
@@ -775,14 +814,17 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         for (int rt = 0; rt < 2; ++rt) {
           L16[x][rt] = wf32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
           pw_launder(L16[x][rt]);
+          R16[x][rt] = wf32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+          pw_launder(R16[x][rt]);
+          if (x == 0)
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) { S16[x][rt][kt] = wf32x4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; pw_launder(S16[x][rt][kt]); }
+            for (int kt = 0; kt < 4; ++kt) { S16[0][rt][kt] = wf32x4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; pw_launder(S16[0][rt][kt]); }
 #pragma unroll
           for (int c = 0; c < 2; ++c) { pwv16[x][rt][c] = wu32x4_t{0, 0, 0, 0}; pw_launder(pwv16[x][rt][c]); }
         }
 #pragma unroll
       for (int i = 0; i < 3; ++i) { er0[i] = 0.0f; er1[i] = 0.0f; pw_launder(er0[i]); pw_launder(er1[i]); }
-      ones16 = wu32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 pairs
+      ones16 = wu32x4_t{ops16::kOnes, ops16::kOnes, ops16::kOnes, ops16::kOnes};      // pairs of 1.0
       pw_launder(ones16);
 #pragma unroll
       for (int db = 0; db < 8; ++db) { vfr16[db][0] = wu32x4_t{0, 0, 0, 0}; vfr16[db][1] = wu32x4_t{0, 0, 0, 0}; }
@@ -808,6 +850,40 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) vfr[b][sk] = wu32x4_t{0, 0, 0, 0};
     }
+  };
+
+  // ---- the rows' references (see R16): scores of the item's first tile against its first 16 keys (K fragments kt = 0
+  // are in their registers), maximum per row, over the four lane groups that hold a row's keys. Keys the row may not
+  // see (causal mask, sliding window) are left in: the reference only has to be in the neighbourhood of the row's
+  // scores. f16 leaves kRefMargin powers of two of head room above the estimate.
+  constexpr float kRefMargin = __is_same(T, f16_t) ? 6.0f : 0.0f;
+  auto set_references = [&]() __attribute__((always_inline)) {
+    // (temporaries: score registers [rt][x] - nothing of a tile is in them yet; ordinary operands here, so the compiler
+    // sees them defined again)
+    sfor<2>([&](auto X) __attribute__((always_inline)) {
+      sfor<2>([&](auto RT) __attribute__((always_inline)) {
+        constexpr int x = decltype(X)::value, rt = decltype(RT)::value;
+        sfor<4>([&](auto KS) __attribute__((always_inline)) {
+          constexpr int ks = decltype(KS)::value, KA = kAK + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
+          if constexpr (ks == 0) ops16::template qk_zero<KA, QA>(S16[0][rt][x]); else ops16::template qk_acc<KA, QA>(S16[0][rt][x]);
+        });
+      });
+    });
+    // the matrix pipe's results are readable (the compiler does not know these statements are matrix instructions)
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(S16[0][0][0]), "+v"(S16[0][0][1]), "+v"(S16[0][1][0]), "+v"(S16[0][1][1]));
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const wf32x4_t tv = S16[0][rt][x];
+        float m = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
+        m = fmaxf(m, lane_xor16(m));
+        m = fmaxf(m, lane_xor32(m));
+        const float r = -(m + kRefMargin);
+        R16[x][rt] = wf32x4_t{r, r, r, r};
+        pw_launder(R16[x][rt]);
+      }
+    asm volatile("s_nop 1" ::: "memory");        // VALU write -> matrix instruction reading it as C
   };
 
   Item cur;
@@ -901,8 +977,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto qk16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kt = g >> 3, ks = (g >> 1) & 3, rt = g & 1;
     constexpr int KA = kAK + 16 * kt + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
-    if constexpr (ks == 0) pw_ops16::template qk_zero_ho<KA, QA>(S16[x][rt][kt]);
-    else pw_ops16::template qk_acc_ho<KA, QA>(S16[x][rt][kt]);
+    if constexpr (ks == 0) ops16::template qk_ref_ho<KA, QA>(S16[0][rt][kt], R16[x][rt]);
+    else ops16::template qk_acc_ho<KA, QA>(S16[0][rt][kt]);
   };
   // The mask of sub-block x, applied to the finished scores (sixteen accumulator set-ups per sub-block: a run-time branch
   // around each, as in the 32x32 form, costs a general iteration a third of its time). Runs right behind the segment
@@ -910,22 +986,27 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto mask16 = [&](auto X, int t) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value;
     asm volatile("s_nop 7\n\ts_nop 3"
-                 : "+v"(S16[x][0][0]), "+v"(S16[x][0][1]), "+v"(S16[x][0][2]), "+v"(S16[x][0][3]),
-                   "+v"(S16[x][1][0]), "+v"(S16[x][1][1]), "+v"(S16[x][1][2]), "+v"(S16[x][1][3]));
+                 : "+v"(S16[0][0][0]), "+v"(S16[0][0][1]), "+v"(S16[0][0][2]), "+v"(S16[0][0][3]),
+                   "+v"(S16[0][1][0]), "+v"(S16[0][1][1]), "+v"(S16[0][1][2]), "+v"(S16[0][1][3]));
     sfor<2>([&](auto RT) __attribute__((always_inline)) {
       sfor<4>([&](auto KT) __attribute__((always_inline)) {
         constexpr int rt = decltype(RT)::value, kt = decltype(KT)::value;
         const int rel = row_lim(cur, 2 * x + rt) - t * kPwTile - 16 * kt - 4 * g4;     // visible: r <= rel
+        if constexpr (SW) {
+          const int rlo = sa.window > 0 ? row_lo(cur, 2 * x + rt) - t * kPwTile - 16 * kt - 4 * g4 : -1;     // ... and r >= rlo
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S16[x][rt][kt][r] = (r <= rel) ? S16[x][rt][kt][r] : -INFINITY;
+          for (int r = 0; r < 4; ++r) S16[0][rt][kt][r] = (r <= rel && r >= rlo) ? S16[0][rt][kt][r] : -INFINITY;
+        } else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S16[0][rt][kt][r] = (r <= rel) ? S16[0][rt][kt][r] : -INFINITY;
       });
     });
   };
   // MFMA g (0..31) of O_x += V^T.P_x^T: d tile g >> 2, 32-key block (g >> 1) & 1, row tile g & 1
   auto pv16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, db = (g >> 2) & 7, c = (g >> 1) & 1, rt = g & 1;
-    if constexpr (g < 32) pw_ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]);
-    else pw_ops16::lsum_ho(L16[x][rt], ones16, pwv16[x][rt][c]);        // g = 32 .. 35: the row sums of this tile
+    if constexpr (g < 32) ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]);
+    else ops16::lsum_ho(L16[x][rt], ones16, pwv16[x][rt][c]);        // g = 32 .. 35: the row sums of this tile
   };
   // Instruction q (0..47) of sub-block x's exponential / pack stream. A 16-cycle matrix instruction leaves this wave ~7
   // cycles of issue in its shadow: one v_exp_f32 fills it, two stall the pipe (tools/probes/issue_model.hip), so the stream
@@ -939,9 +1020,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #ifdef PW_ABL_E
     return;
 #endif
-    if constexpr (op.kind == 0) a_exp_ho(er0[w % 3], S16[x][rt][kt][2 * pr]);
-    else if constexpr (op.kind == 1) a_exp_ho(er1[w % 3], S16[x][rt][kt][2 * pr + 1]);
-    else if constexpr (op.kind == 2) pw_ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[w % 3], er1[w % 3]);
+    if constexpr (op.kind == 0) a_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr]);
+    else if constexpr (op.kind == 1) a_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1]);
+    else if constexpr (op.kind == 2) ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[w % 3], er1[w % 3]);
   };
   // the stream's instructions in a P.V segment's gap g (36 gaps). Steady iterations: 22 went out during the S_x segment,
   // the other 26 take the even gaps and eight odd ones (the odd gaps carry the LDS reads); general iterations: all 48
@@ -1000,6 +1081,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     // next iteration's entries (they land before the wait that ends this one)
     if constexpr (!steady) {
       need_mask = (t * kPwTile + kPwTile - 1 > cur.ctx_len + cur.w_tok_lo) || (t * kPwTile + kPwTile > cur.seq_len);
+      if constexpr (SW) need_mask = need_mask || (sa.window > 0 && t * kPwTile < cur.ctx_len + cur.w_tok_hi - sa.window + 1);   // below the window of the wave's last row
       tail_check(cur, t + 3, ic<0>{});
       tail_check(cur, t + 2, ic<1>{});
       kb64 = group_base(cur, t + 3, pg_k, ic<0>{});
@@ -1179,7 +1261,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           int tok_local, hq;
           const bool row_ok = row_of(I, 2 * x + rt, tok_local, hq);
           if (I.lse_base && row_ok && g4o == 0)
-            I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? __builtin_amdgcn_logf(l) * 0.6931471805599453f : -INFINITY;
+            I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? (__builtin_amdgcn_logf(l) - R16[x][rt][0]) * 0.6931471805599453f : -INFINITY;   // P = 2^(score + R)
           const float inv = (row_ok && l > 0.0f) ? 1.0f / l : 0.0f;
           l2[rt] = l; ok2[rt] = row_ok;
           if (__builtin_expect(wide_store, 1)) {
@@ -1218,7 +1300,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         sfor<2>([&](auto RT) __attribute__((always_inline)) {
           constexpr int rt = decltype(RT)::value;
           const bool has_keys = ok2[rt] && I.tile_hi > I.tile_lo && row_lim(I, 2 * x + rt) >= key_lo;
-          bad16[x][rt] = has_keys && !(l2[rt] >= kPwSumLo && l2[rt] <= kPwSumHi && (rt ? am1 : am0) < INFINITY);
+          bad16[x][rt] = has_keys && !(l2[rt] >= (__is_same(T, f16_t) ? kPwSumLoF16 : kPwSumLo) && l2[rt] <= kPwSumHi && (rt ? am1 : am0) < INFINITY);   // (an f16 P that overflowed is an inf in the sum)
+          // scores of a magnitude at which the 2^-9 relative rounding of Q' = Q * scale * log2(e) to 16 bits moves the
+          // DIFFERENCES between keys by tenths (thousands of log2 units: nothing a model produces): the f32 routine as well
+          bad16[x][rt] = bad16[x][rt] || (has_keys && !(fabsf(R16[x][rt][0]) <= kPwRefMax));
 #ifdef PW_FORCE_FALLBACK
           bad16[x][rt] = has_keys;
 #endif
@@ -1296,7 +1381,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         const int m = wave * 64 + rr;
         const int tok = I.tok0 + div_g(m);
         const int key_hi = min(min(I.ctx_len + tok, I.seq_len - 1) + 1, I.tile_hi * kPwTile);
-        pw_row_fallback<T>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo, key_hi, I.out_base, I.lse_base, lane);
+        const int key_lo_row = (SW && sa.window > 0) ? max(key_lo, I.ctx_len + tok - sa.window + 1) : key_lo;
+        pw_row_fallback<T>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo_row, key_hi, I.out_base, I.lse_base, lane);
       }
     }
   };
@@ -1311,6 +1397,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       if constexpr (M16) sfor<16>([&](auto NC) __attribute__((always_inline)) { kread16(NC, ic<0>{}); });
       else sfor<16>([&](auto NC) __attribute__((always_inline)) { kread(NC, ic<0>{}); });
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 0 is re-filled (K(tile_lo + 3)) in the first iteration
+      if constexpr (M16) set_references();
       int t = tile_lo;
 #ifdef MI355_PW_STAMP
       // diagnostic build only (tools/pw_clock.py): shader cycles and 100 MHz ticks around the tile loop
@@ -1325,25 +1412,40 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       // what the Q block can see (then the groups of t + 2, t + 3 are whole). Shifts, not divisions: the terms can be negative.
       const int steady_hi = 1 + min(min(tile_hi - 5, ((cur.last_group - wave) >> 2) - 4),
                                     min((cur.ctx_len + cur.w_tok_lo - (kPwTile - 1)) >> 6, (cur.seq_len >> 6) - 1));
-      while (t + 3 <= steady_hi) {                 // three at a time: leaves the ring phase at 0
-        iteration(ic<0>{}, ic<1>{}, t);
-        iteration(ic<1>{}, ic<1>{}, t + 1);
-        iteration(ic<2>{}, ic<1>{}, t + 2);
-        t += 3;
-      }
-      if (dynamic) { draw(); drawn = true; }      // the next item's ticket: a few tiles before this item ends
       // The workgroup walks tile_hi tiles, but a wave's 64 rows see no key past their last row's limit: the tiles from
       // own_hi on are wholly masked for it (G < 4: up to three of a Q block's last four). It computes nothing for
       // them - it only keeps staging its share of the K/V tiles the other waves still need.
-      const int w_tok_hi = min(cur.tok0 + (wave * 64 + 63) / G, cur.q_len - 1);
-      const int own_hi = cur.w_tok_lo >= cur.q_len ? tile_lo : max(tile_lo, min(tile_hi, (min(cur.ctx_len + w_tok_hi, cur.seq_len - 1) >> 6) + 1));
-      while (t < own_hi) {
-        iteration(ic<0>{}, ic<0>{}, t);
-        if (++t >= own_hi) break;
-        iteration(ic<1>{}, ic<0>{}, t);
-        if (++t >= own_hi) break;
-        iteration(ic<2>{}, ic<0>{}, t);
-        ++t;
+      const int own_hi = cur.w_tok_lo >= cur.q_len ? tile_lo : max(tile_lo, min(tile_hi, (min(cur.ctx_len + cur.w_tok_hi, cur.seq_len - 1) >> 6) + 1));
+      // Sliding window: the tiles below the window of the wave's LAST row are general iterations too (lower bound in the
+      // mask); they come first, in whole rounds of three so that the steady stretch starts at ring phase 0. One copy of
+      // the general loop serves both ends: pass 0 = the window's lower edge, pass 1 = steady stretch + the upper end.
+      int pre_hi = tile_lo;
+      if constexpr (SW) {
+        if (sa.window > 0) {
+          const int s_lo = (cur.ctx_len + cur.w_tok_hi - sa.window + 1 + (kPwTile - 1)) >> 6;   // first tile wholly inside every row's window
+          pre_hi = tile_lo + 3 * ((max(s_lo - tile_lo, 0) + 2) / 3);
+        }
+      }
+#pragma nounroll
+      for (int pass = SW ? 0 : 1; pass < 2; ++pass) {
+        if (pass == 1) {
+          while (t + 3 <= steady_hi) {                 // three at a time: leaves the ring phase at 0
+            iteration(ic<0>{}, ic<1>{}, t);
+            iteration(ic<1>{}, ic<1>{}, t + 1);
+            iteration(ic<2>{}, ic<1>{}, t + 2);
+            t += 3;
+          }
+          if (dynamic) { draw(); drawn = true; }      // the next item's ticket: a few tiles before this item ends
+        }
+        const int lim = pass == 0 ? min(pre_hi, own_hi) : own_hi;
+        while (t < lim) {
+          iteration(ic<0>{}, ic<0>{}, t);
+          if (++t >= lim) break;
+          iteration(ic<1>{}, ic<0>{}, t);
+          if (++t >= lim) break;
+          iteration(ic<2>{}, ic<0>{}, t);
+          ++t;
+        }
       }
 #ifdef MI355_PW_STAMP
       {
@@ -1412,12 +1514,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       issue_q(nxt);
       issue_first_tiles(nxt);
       PW_SEAM_STAMP(6);
-    } else {
-      // (defined on both paths: the registers of the previous item's rows are then not kept alive through the tile loop)
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qraw[sb][ks] = wu32x4_t{0, 0, 0, 0};
     }
     epilogue(cur);
 #ifdef MI355_PW_STAMP
@@ -1441,15 +1537,16 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 // host side
 // ---------------------------------------------------------------------------------------------
 
-// Preconditions beyond prefill_supported(): bf16, head size 128, no soft-cap / ALiBi / sliding window, bf16 cache, G <= 256.
+// Preconditions beyond prefill_supported(): bf16 or f16, head size 128, a cache of the query type, G <= 256; a sliding
+// window is served, soft-cap and ALiBi are not (they touch every score: prefill_mfma_kernel's FEAT instantiation).
 bool prefill_pw_applicable(const mi355_attn_params& p) {
-  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr;
   const int G = p.num_q_heads / p.num_kv_heads;
   // (rows of a Q block are addressed as 32-bit byte offsets from the block's first row: strides below 2^22 elements)
   const int64_t lim = (int64_t)1 << 22;
   const bool strides_ok = p.q_stride_token >= 0 && p.q_stride_token < lim && p.q_stride_head >= 0 && p.q_stride_head < lim &&
                           p.out_stride_token >= 0 && p.out_stride_token < lim && p.out_stride_head >= 0 && p.out_stride_head < lim;
-  return !feat && strides_ok && p.head_size == 128 && G <= kPwRows && p.q_dtype == MI355_BF16 && p.kv_dtype == p.q_dtype;
+  return !feat && strides_ok && p.head_size == 128 && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && p.kv_dtype == p.q_dtype;
 }
 
 template <typename T>
@@ -1496,24 +1593,34 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // ~2.2-2.3 GHz under it instead of ~2.0-2.1 - at the price of twice as many matrix instructions to issue; with its
   // exponentials dealt one per gap it is ahead on every shape this kernel is chosen for (same box: 1 x 4096 +6.9 %,
   // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
-  static const bool m16 = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
-  if (m16) {
-    static std::atomic<uint64_t> lds_opt_in16{0};
-    const int rc1 = ensure_dynamic_lds((const void*)prefill_pw_kernel<T, true>, (int)kPwLds, lds_opt_in16, "hipFuncSetAttribute(prefill_pw m16)");
+  static const bool m16_env = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
+  const bool sw = p.sliding_window > 0;
+  const bool m16 = m16_env || sw || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, no window
+  auto go = [&](auto kernel, std::atomic<uint64_t>& opted) -> int {
+    const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
     if (rc1 != MI355_OK) return rc1;
-    hipLaunchKernelGGL((prefill_pw_kernel<T, true>), dim3(a.slots * p.num_kv_heads), dim3(256), lds, stream, a);
-  } else {
-  static std::atomic<uint64_t> lds_opt_in{0};
-  const int rc0 = ensure_dynamic_lds((const void*)prefill_pw_kernel<T, false>, (int)kPwLds, lds_opt_in, "hipFuncSetAttribute(prefill_pw)");
-  if (rc0 != MI355_OK) return rc0;
-  hipLaunchKernelGGL((prefill_pw_kernel<T, false>), dim3(a.slots * p.num_kv_heads), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(a.slots * p.num_kv_heads), dim3(256), lds, stream, a);
+    return MI355_OK;
+  };
+  int rc_l = MI355_OK;
+  if (m16 && sw) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, true>, o);
+  } else if (m16) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, false>, o);
+  } else if constexpr (__is_same(T, bf16_t)) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, false, false>, o);
   }
+  if (rc_l != MI355_OK) return rc_l;
   const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");
-  if (rc == MI355_OK) set_kernel_name("prefill_mfma");
+  if (rc == MI355_OK) set_kernel_name(sw ? "prefill_mfma_pw_sw" : "prefill_mfma_pw");
   return rc;
 }
 
 int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream) {
+  if (p.q_dtype == MI355_F16) return launch_pw_t<f16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream);
   return launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream);
 }
 

@@ -38,6 +38,7 @@ EXPORTS = (
     "mi355_paged_attention_v0",
     "mi355_decode_write_fusable",
     "mi355_reshape_and_cache_flash",
+    "mi355_merge_attention_partials",
 )
 
 
@@ -165,6 +166,9 @@ def load() -> C.CDLL:
         legacy.argtypes = [C.POINTER(AttnParams), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.mi355_decode_write_fusable.restype = C.c_int
     lib.mi355_decode_write_fusable.argtypes = [C.POINTER(AttnParams)]
+    lib.mi355_merge_attention_partials.restype = C.c_int
+    lib.mi355_merge_attention_partials.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
     lib.mi355_reshape_and_cache_flash.restype = C.c_int
     lib.mi355_reshape_and_cache_flash.argtypes = [C.POINTER(CacheParams), C.c_void_p]
     _lib = lib
