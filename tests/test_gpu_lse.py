@@ -99,3 +99,11 @@ def test_key_ranges_of_one_long_sequence_merge_to_the_full_result():
     torch.testing.assert_close(merged_lse, full_lse, atol=1e-3, rtol=0)
     ref = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"])
     torch.testing.assert_close(merged.double().cpu(), ref, atol=2e-2, rtol=2e-2)
+    # the same merge as ONE launch of the library's kernel on the partials in their own 16-bit type (what the exchange
+    # step of parallel.all_gather_and_merge runs on a GPU; mi355_merge_attention_partials): output in the query type
+    dev_out, dev_lse = parallel.merge_partial_attention_device(torch.stack(outs), torch.stack(lses))
+    torch.cuda.synchronize()
+    assert dev_out.dtype == dtype
+    torch.testing.assert_close(dev_out.float(), merged, atol=8e-3, rtol=8e-3)
+    torch.testing.assert_close(dev_lse, merged_lse, atol=1e-4, rtol=1e-5)
+    assert torch.isinf(dev_lse).sum() == torch.isinf(merged_lse).sum()

@@ -397,7 +397,38 @@ def test_prefill_f16_rows_whose_scores_sit_far_from_zero(gains):
     ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
                                        inp["scale"], mode="2d", block_n=64)
     d = gpu_util.to_dev(inp)
-    out, kernel = gpu_util.run_unified(d, inp["scale"])
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], 0.0, None, None, None, None, num_segments=1)      # (one pass per Q block: see the window test)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
     assert kernel.startswith("prefill_mfma_pw"), kernel
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dtype,kv_dtype", [(torch.bfloat16, torch.float8_e4m3fn), (torch.float16, torch.float8_e5m2)])
+@pytest.mark.parametrize("window", [0, 700])
+def test_long_prefill_over_an_fp8_cache_runs_on_the_64_rows_per_wave_kernel(dtype, kv_dtype, window):
+    """A long prefill over an fp8 flash-layout cache (many query rows per sequence): the sequences' keys are dequantised
+    ONCE into the 16-bit scratch - the reference's (fp8 -> f32) * scale -> query type (:434-455), k and v scales that are
+    no powers of two and differ - and the 64-rows-per-wave kernel runs on that; the decode row of the batch reads the fp8
+    cache directly on the split-KV kernel."""
+    import gpu_util
+
+    query_lens, kv_lens = [2100, 1500, 1], [2100, 2600, 2500]
+    ks, vs = 0.0237, 0.041
+    inp = orc.make_paged_inputs(71, query_lens, kv_lens, 8, 2, 128, 16, dtype, kv_dtype=kv_dtype, kv_scale=ks)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], sliding_window=window, k_scale=ks, v_scale=vs, mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], window=window, kv_scale=ks, v_scale=vs)
+    assert kernel == ("repack+prefill_mfma_pw_sw+decode_splitkv_fp8" if window else "repack+prefill_mfma_pw+decode_splitkv_fp8"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype, kv_dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    out9, _ = gpu_util.run_unified(d, inp["scale"], window=window, kv_scale=ks, v_scale=vs, force=9)
+    torch.testing.assert_close(out.float(), out9.float(), atol=atol, rtol=rtol)

@@ -40,12 +40,18 @@ def _run(dev_inp, scale, lse=None):
 def _worker(rank, world, port, q_out):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "vllm-triton-backend_amd"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # one GPU per rank and RCCL when the box has them (the driver's scaling run), else both ranks on the one card and the
+    # exchange over gloo on host copies
+    own_gpu = torch.cuda.device_count() >= world
+    backend = "nccl" if own_gpu else "gloo"
+    dev = torch.device("cuda", rank if own_gpu else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if own_gpu else {}))
+    xdev = dev if own_gpu else torch.device("cpu")          # where the tensors of a collective live
     try:
         from mi355_attn import _lib, parallel
         from oracle import paged_attention_oracle as orc
 
-        dev = torch.device("cuda", 0)
         # a mixed batch: decode rows, chunked prefills over long contexts, full prefills (one long enough for the
         # 64-rows-per-wave kernel), same seed on both ranks
         query_lens = [1, 1, 300, 1, 2304, 64, 1, 500, 1, 128]
@@ -56,7 +62,7 @@ def _worker(rank, world, port, q_out):
                      seqused_k=lb.seqused_k.to(dev), block_table=lb.block_table.to(dev))
         out_local = _run(local, inp["scale"])
         kernel_local = _lib.last_kernel()
-        got = parallel.gather_outputs(out_local.cpu(), lb, inp["q"].shape[0])          # gloo: host tensors
+        got = parallel.gather_outputs(out_local.to(xdev), lb, inp["q"].shape[0]).cpu()
         whole = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
         full = _run(whole, inp["scale"]).cpu()
         # the split plans of a share and of the whole batch may differ (rounding of the merges), nothing else may
@@ -81,8 +87,8 @@ def _worker(rank, world, port, q_out):
                 o_i = _run(sub, dinp["scale"], lse=lse_i)
             outs.append(o_i.cpu())
             lses.append(lse_i.cpu())
-        merged, _ = parallel.all_gather_and_merge(torch.cat(outs).float(), torch.cat(lses))
-        cp_err = float((merged - ref.float()).abs().max())
+        merged, _ = parallel.all_gather_and_merge(torch.cat(outs).to(xdev), torch.cat(lses).to(xdev))    # nccl: 16-bit partials, merged by the library's kernel
+        cp_err = float((merged.float().cpu() - ref.float()).abs().max())
         q_out.put((rank, batch_err, nan_free, cp_err, kernel_local, lb.seq_ids))
     finally:
         dist.destroy_process_group()

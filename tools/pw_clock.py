@@ -35,7 +35,8 @@ def main():
     out = torch.empty_like(q)
     max_wgs = (batch * L * (Hq // Hk) // 256 + batch) * Hk + 64
     dbg = torch.zeros(12 * max_wgs, dtype=torch.int64, device=dev)
-    p, keep = ua.fill_attn_params(q, k, v, out, cu, L, sl, L, 1 / math.sqrt(D), (-1, -1), bt, 0.0, None, None, None, 2)
+    win = int(os.environ.get("MI355_WIN", "0"))             # sliding window (the SW instantiation)
+    p, keep = ua.fill_attn_params(q, k, v, out, cu, L, sl, L, 1 / math.sqrt(D), (win - 1, 0) if win else (-1, -1), bt, 0.0, None, None, None, 2)
     addr = dbg.data_ptr()
     p.reserved0 = C.c_int32(addr & 0xFFFFFFFF).value
     p.reserved1 = C.c_int32((addr >> 32) & 0xFFFFFFFF).value
@@ -72,8 +73,13 @@ def main():
     if os.environ.get("MI355_PW_SEAM"):     # library built with -DMI355_PW_SEAM too: realtime stamps inside the seam instead of the segment sums
         r2 = rec[rec[:, 6] > 0]
         d = lambda a_, b_: ((r2[:, b_] - r2[:, a_]).double() * 0.01).median().item()
-        print(f"  seam (us, medians; items followed by another): loop end -> drained {d(10, 3):.2f}, next item set up {d(3, 4):.2f}, loads landed + barrier {d(4, 5):.2f}, "
-              f"next rows and tiles requested {d(5, 6):.2f}, output stored {d(6, 11):.2f}")
+        print(f"  seam (us, medians; items followed by another): loop end -> drained {d(10, 3):.2f}, drained -> barrier {d(3, 4):.2f}, next item acquired {d(4, 5):.2f}, "
+              f"its loads requested / begun {d(5, 6):.2f}, output stored (+ loads dealt over it) {d(6, 11):.2f}")
+        nxt = {int(r[8]): r for r in rec}                # an item's entry stamp (8) is the previous item's exit stamp (11)
+        conv = [float(nxt[int(r[11])][9] - r[11]) * 0.01 for r in r2 if int(r[11]) in nxt]
+        if conv:
+            conv.sort()
+            print(f"  output stored -> next item's tile loop (Q conversion, waits, first K read): median {conv[len(conv) // 2]:.2f} us over {len(conv)} seams")
     print(f"  time per tile: {(rt[big]/tiles[big]).median()*10:.0f} ns; tile loop = {(rt.sum()*0.01)/ (us*256)*100:.1f} % of CU time (256 CUs x launch time)")
 
 

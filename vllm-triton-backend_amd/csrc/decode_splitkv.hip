@@ -371,6 +371,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     }
   };
   // one loaded 16-byte piece -> LDS row of the 16-bit type
+  // (fp8: a piece widens to two 16-byte stores, and ds_write_b128 is serviced eight lanes at a time on 32 banks
+  // (MI355X_MICROARCH.md, LDS): the eight pieces of a row, 32 bytes apart, put pieces p and p + 4 on the same banks in
+  // both stores - the 2-way conflicts of profiles/r02/pmc_decode_fp8.txt. Taking the two halves of pieces 4 .. 7 in
+  // swapped order - two 8-byte loads per piece, the first store then covers eight distinct 16-byte slots - removes them
+  // and made the kernel 20 % SLOWER (C5: 183 -> 220 us, profiles/r03/decode_fp8_swap_ab.log): this kernel lives on its
+  // VMEM issue slots, not on the LDS array.)
   auto park = [&](char* base, int row, int piece, u32x4_t v) {
     if constexpr (FP8) {
       u32x4_t lo, hi;
@@ -823,7 +829,16 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
   if (p.num_segments > 0) {
     want = p.num_segments;
   } else {
-    const long base = std::max(1L, decode_units(p) * p.num_kv_heads * query_head_groups(p));  // waves with one split each
+    // (the decode rows of a mixed batch: the grid runs over all sequences and the prefill ones leave at once, so the split
+    // count is sized for the rows that can be decode rows at most - every prefill sequence carries at most max_seqlen_q
+    // of the num_tokens - num_seqs tokens beyond one per sequence. C4: 64 sequences, 32 of them decode rows; sized for
+    // all 64 the launch ran 2 waves per CU at 3.7 TB/s, profiles/r02/bench_kernel_stats_mixed.csv)
+    long units = decode_units(p);
+    if (p.only_decodes && p.max_seqlen_q > 1 && p.num_tokens > p.num_seqs) {
+      const long prefills = ((long)p.num_tokens - p.num_seqs + p.max_seqlen_q - 2) / (p.max_seqlen_q - 1);
+      units = std::max(1L, std::min(units - 1, units - prefills));
+    }
+    const long base = std::max(1L, units * p.num_kv_heads * query_head_groups(p));  // waves with one split each
     // Work items in flight. With streaming loads a 16-bit cache runs best with 4 per CU: more only add partials and
     // a tail (8192 keys: batch 64 -> 2 splits 322 us, 4 splits 332, 8 splits 344; batch 16 -> 8 splits 90, 16: 95;
     // batch 4 at 32768 keys: 92 vs 94). The fp8 kernel spends its time widening, not waiting: it wants 8 per CU

@@ -457,6 +457,26 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // ballot. With a single sequence the first block-table entries ride the same trip, speculatively (checked when the
   // first tiles are requested).
   int spec_pg[4] = {0, 0, 0, 0}, spec_off[4] = {0, 0, 0, 0};
+  // ... and that trip is taken ONCE per workgroup: the two words stay in a register each across the tile loops (opaque
+  // to the compiler, so it neither reloads nor rematerialises them), and an item's set-up is scalar arithmetic on a
+  // ballot - 1.1 us of exposed latency per item until round 3.
+  // (not in the sliding-window instantiation: its general iterations leave no two registers to carry them)
+  constexpr bool kResidentTabs = false;
+  int cu_tab = 0, sk_tab = 0;
+  if (kResidentTabs && p.num_seqs <= 63) {
+    cu_tab = p.cu_seqlens_q[min(lane, p.num_seqs)];
+    sk_tab = p.seqused_k[min(lane, p.num_seqs - 1)];
+  }
+  pw_launder(cu_tab);
+  pw_launder(sk_tab);
+  // one sequence (every instantiation): its three words as scalars
+  int one_q_start = 0, one_q_end = 0, one_seq_len = 0;
+  if (!SW && p.num_seqs == 1) {
+    one_q_start = __builtin_amdgcn_readfirstlane(p.cu_seqlens_q[0]);
+    one_q_end = __builtin_amdgcn_readfirstlane(p.cu_seqlens_q[1]);
+    one_seq_len = __builtin_amdgcn_readfirstlane(p.seqused_k[0]);
+  }
+  asm volatile("" : "+s"(one_q_start), "+s"(one_q_end), "+s"(one_seq_len));
   auto setup_idx = [&](Item& I, int idx) -> bool {       // item idx of this KV head's list; false: it is empty
     {
       const int BQ = sa.BQ;
@@ -479,9 +499,13 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       }
       int seq, q_start, q_len, seq_len;
       const int qr_o = lane_o & 31;
-      if (sa.num_seqs <= 63) {
-        const int cu_v = sa.cu[min(lane_o, sa.num_seqs)];
-        const int sk_v = sa.sk[min(lane_o, sa.num_seqs - 1)];
+      // (not in the sliding-window instantiation: three more scalars held across its tile loops cost it 4 %)
+      if (!SW && sa.num_seqs == 1) {
+        seq = qblock >= 0 ? 0 : -1;
+        q_start = one_q_start; q_len = one_q_end - one_q_start; seq_len = one_seq_len;
+      } else if (sa.num_seqs <= 63) {
+        const int cu_v = kResidentTabs ? cu_tab : sa.cu[min(lane_o, sa.num_seqs)];
+        const int sk_v = kResidentTabs ? sk_tab : sa.sk[min(lane_o, sa.num_seqs - 1)];
         const unsigned long long le = __ballot(lane_o < sa.num_seqs && div_bq(cu_v) + lane_o <= qblock);
         seq = __builtin_popcountll(le) - 1;
         const int sq = max(seq, 0);
@@ -606,18 +630,22 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // instruction), so the rows land where their scaled form will live - no VGPR carries them across the epilogue (64 of
   // them did until round 3, the peak of the kernel's VGPR demand). Retired by the s_waitcnt vmcnt(0) of
   // zero_o_and_convert_q; vmcnt is in order, so the compiler's own waits only ever over-wait for these.
-  auto issue_q = [&](const Item& I) __attribute__((always_inline)) {
+  // `part` (M16): -1 = all four row tiles, else only row tile `part` - at the seam the loads of the next item are dealt
+  // over the four row tiles of the current item's output (see epilogue): 36 load instructions per wave take the CU's
+  // address unit 2.4 us when the four waves issue them back to back, time the output's VALU / LDS work can run beside.
+  auto issue_q = [&](const Item& I, int part) __attribute__((always_inline)) {
     // scalar address of the block's first token and this KV head's first query head; a lane's row is within 2^31 bytes of it
     const uint64_t qb = uniform64((uint64_t)(sa.q + (int64_t)(I.q_start + I.tok0) * (int64_t)sa.q_st + (int64_t)(head * sa.G) * (int64_t)sa.q_sh));
     if constexpr (M16) {        // a[kAQ + 16 rt4 + 4 ks ..] = Q[row 16 rt4 + r16][32 ks + 8 g4 .. + 7]
       sfor<4>([&](auto RT) {
         constexpr int rt4 = decltype(RT)::value;
+        if (part >= 0 && part != rt4) return;
         int tok_local, hq;
         row_of(I, rt4, tok_local, hq);
         const uint32_t off = (uint32_t)(((min(tok_local, I.q_len - 1) - I.tok0) * sa.q_st + (hq - head * sa.G) * sa.q_sh + 8 * (lane_o >> 4)) * 2);
         sfor<4>([&](auto KS) { constexpr int ks = decltype(KS)::value; pw_gload16_acc<kAQ + 16 * rt4 + 4 * ks, 64 * ks>(off, qb); });
       });
-    } else
+    } else if (part <= 0)
     sfor<2>([&](auto SB) {
       constexpr int sb = decltype(SB)::value;
       int tok_local, hq;
@@ -721,18 +749,26 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   // ---- an item's first tiles on their way: K0 K1 V0 | K2 V1 (twenty pieces) ------------------------------
   int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration (V's = K's of one iteration earlier)
-  auto issue_first_tiles = [&](const Item& I) __attribute__((always_inline)) {
+  int ft_pg[3] = {0, 0, 0};                      // block-table entries of the item's first three tiles
+  bool ft_any = false;
+  // the scalar side: ring offsets back to whole groups, the first four block-table entries
+  auto first_tiles_begin = [&](const Item& I) __attribute__((always_inline)) {
     if (k_tail) { set_k_offsets(15); k_tail = false; }     // the previous item may have ended inside a group
     if (v_tail) { set_v_offsets(15); v_tail = false; }
-    if (I.tile_hi <= I.tile_lo) return;
-    int pk0, pk1, pk2, pv0, pv1;
+    ft_any = I.tile_hi > I.tile_lo;
+    if (!ft_any) return;
     const int eo0 = entry_off(I, I.tile_lo), eo1 = entry_off(I, I.tile_lo + 1), eo2 = entry_off(I, I.tile_lo + 2), eo3 = entry_off(I, I.tile_lo + 3);
     if (sa.num_seqs == 1 && sa.key_splits == 1 && eo0 == spec_off[0] && eo1 == spec_off[1] && eo2 == spec_off[2] && eo3 == spec_off[3]) {
-      pk0 = spec_pg[0]; pk1 = spec_pg[1]; pk2 = spec_pg[2]; pg_k = spec_pg[3];     // the speculative entries are the right ones
+      ft_pg[0] = spec_pg[0]; ft_pg[1] = spec_pg[1]; ft_pg[2] = spec_pg[2]; pg_k = spec_pg[3];     // the speculative entries are the right ones
     } else {
-      scalar_load4((const int32_t*)I.bt64, eo0 >> 2, eo1 >> 2, eo2 >> 2, eo3 >> 2, pk0, pk1, pk2, pg_k);
+      scalar_load4((const int32_t*)I.bt64, eo0 >> 2, eo1 >> 2, eo2 >> 2, eo3 >> 2, ft_pg[0], ft_pg[1], ft_pg[2], pg_k);
     }
-    pv0 = pk0; pv1 = pk1; pg_v = pk2;            // K and V share the block table
+    pg_v = ft_pg[2];                             // K and V share the block table
+  };
+  // group g of K0 K1 V0 K2 V1 (four LDS-DMA pieces each)
+  auto first_tiles_group = [&](const Item& I, auto GC) __attribute__((always_inline)) {
+    constexpr int g = decltype(GC)::value;
+    if (!ft_any) return;
     auto group = [&](int tile, int page, auto ISV, uint32_t lds_dst) {
       constexpr bool isv = decltype(ISV)::value != 0;
       tail_check(I, tile, ISV);
@@ -740,17 +776,33 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) pw_glds16(isv ? voff[i] : koff[i], base, lds_dst + lds_wave + i * 1024);
     };
-    group(I.tile_lo, pk0, ic<0>{}, kLdsK);
-    group(I.tile_lo + 1, pk1, ic<0>{}, kLdsK + kSlotBytes);
-    group(I.tile_lo, pv0, ic<1>{}, kLdsV);
-    group(I.tile_lo + 2, pk2, ic<0>{}, kLdsK + 2 * kSlotBytes);
-    group(I.tile_lo + 1, pv1, ic<1>{}, kLdsV + kSlotBytes);
+    if constexpr (g == 0) group(I.tile_lo, ft_pg[0], ic<0>{}, kLdsK);
+    if constexpr (g == 1) group(I.tile_lo + 1, ft_pg[1], ic<0>{}, kLdsK + kSlotBytes);
+    if constexpr (g == 2) group(I.tile_lo, ft_pg[0], ic<1>{}, kLdsV);
+    if constexpr (g == 3) group(I.tile_lo + 2, ft_pg[2], ic<0>{}, kLdsK + 2 * kSlotBytes);
+    if constexpr (g == 4) group(I.tile_lo + 1, ft_pg[1], ic<1>{}, kLdsV + kSlotBytes);
+  };
+  auto issue_first_tiles = [&](const Item& I) __attribute__((always_inline)) {
+    first_tiles_begin(I);
+    sfor<5>([&](auto GC) __attribute__((always_inline)) { first_tiles_group(I, GC); });
+  };
+  // The next item's loads, hung in front of the output's first row tile (hook 0 of epilogue). Dealt over the output's four
+  // row tiles they left the address unit to the output's own work - the seam's stamps shrank by 2.4 us - and the launch
+  // did not get faster (1 x 4096) or got slower (sliding window, 77 -> 82 us): whatever is issued after the output has
+  // begun is still in flight when the next item's tile loop starts, and the wait moves into its first iterations, where
+  // all four waves share it at the barrier. (profiles/r03/pw_seam.log)
+  auto next_item_loads = [&](const Item& I, auto PART) __attribute__((always_inline)) {
+    constexpr int part = decltype(PART)::value;
+    if constexpr (part == 0) {
+      issue_q(I, -1);
+      sfor<5>([&](auto GC) __attribute__((always_inline)) { first_tiles_group(I, GC); });
+    }
   };
 
   // ---- O = 0 and Q' = Q * scale * log2(e), packed, in place in the accumulator registers the raw rows landed in ---
   const float scale2 = p.scale * kPwLog2e;
-  auto zero_o_and_convert_q = [&](const Item& I) __attribute__((always_inline)) {
-    sfor<128>([&](auto IC) { acc_zero<kAO + decltype(IC)::value>(); });
+  auto zero_o_and_convert_q = [&](const Item& I, bool zero_o) __attribute__((always_inline)) {
+    if (zero_o) sfor<128>([&](auto IC) { acc_zero<kAO + decltype(IC)::value>(); });
     // the item's query rows have landed (and everything older: its first tiles, the previous item's output)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     sfor<2>([&](auto SB) {
@@ -902,9 +954,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     }
   };
   if (!acquire(cur, dynamic ? slot : 0, dynamic)) { finish(); return; }
-  issue_q(cur);
+  issue_q(cur, -1);
   issue_first_tiles(cur);
-  zero_o_and_convert_q(cur);
+  zero_o_and_convert_q(cur, true);
 
   // ---- the pieces of an iteration ------------------------------------------------------------------------
   // MFMA g of S_x = K.Q_x^T: 32-key block g >> 3, k-step g & 7. A chain starts from the constant 0; on a tile that
@@ -1070,7 +1122,13 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // iteration spends ~55 scalar instructions and five branches between the barrier and its first MFMA).
   auto iteration = [&](auto ITC, auto STC, int t) __attribute__((always_inline)) {
     constexpr int it = decltype(ITC)::value;
+    // STC: 1 = steady (see above); 0 = general; 2 (M16) = UNMASKED TAIL: the compute side of a steady iteration (no mask,
+    // exponentials dealt from the moment a sub-block's first score tile is done) with the fetch side of a general one
+    // (groups clamped to the share and the sequence, rows past the sequence's end redirected), its scalar arithmetic
+    // behind the first matrix instructions. A Q block's last four or five tiles lie past what the steady form may
+    // fetch blindly, but only the one or two on the causal diagonal need a mask.
     constexpr bool steady = decltype(STC)::value != 0;
+    constexpr bool fast_fetch = decltype(STC)::value == 1;
     constexpr int KR = ((it + 1) % 3) * kSlotBytes;            // K(t+1) is read from here
     constexpr int VR = (it % 3) * kSlotBytes;                  // V(t)
     constexpr int KD = kLdsK + (it % 3) * kSlotBytes;          // K(t+3) goes where K(t) was
@@ -1113,14 +1171,17 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         qk16(ic<0>{}, GC);
         if constexpr (steady && g == 0) {
           __builtin_amdgcn_sched_barrier(0);
-          kb64 = group_base_fast(cur, t + 3, pg_k, ic<0>{});
+          if constexpr (fast_fetch) kb64 = group_base_fast(cur, t + 3, pg_k, ic<0>{});
+          else { tail_check(cur, t + 3, ic<0>{}); kb64 = group_base(cur, t + 3, pg_k, ic<0>{}); }
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (steady && g == 1) {
           __builtin_amdgcn_sched_barrier(0);
-          vb64 = group_base_fast(cur, t + 2, pg_v, ic<1>{});
+          if constexpr (fast_fetch) vb64 = group_base_fast(cur, t + 2, pg_v, ic<1>{});
+          else { tail_check(cur, t + 2, ic<1>{}); vb64 = group_base(cur, t + 2, pg_v, ic<1>{}); }
           pg_v = pg_k;
-          pw_sload(pg_k, cur.bt64, entry_off_fast(t + 4));
+          if constexpr (fast_fetch) pw_sload(pg_k, cur.bt64, entry_off_fast(t + 4));
+          else pw_sload(pg_k, cur.bt64, entry_off(cur, t + 4));
           __builtin_amdgcn_sched_barrier(0);
         }
         // (the four waves issue their pieces at the same time and the CU's address unit takes 64 cycles per round of four:
@@ -1222,7 +1283,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
 
   // ---- an item's output: O / l through this wave's parking rows, whole 256-byte rows out ------------------
-  auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
+  // `hook(ic<part>)`, part 0 .. 3: called in front of each of the four row tiles' output (M16; the other form calls all
+  // four first): the seam hangs the next item's loads there.
+  auto epilogue = [&](const Item& I, auto hook) __attribute__((always_inline)) {
     const int G = sa.G;
     const uint32_t g_inv = (65536u + (uint32_t)G - 1u) / (uint32_t)G;   // m / G == (m * g_inv) >> 16 for m < 256, G <= 256
     const int lane = lane_o, qr = lane_o & 31, half = lane_o >> 5;
@@ -1257,6 +1320,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         };
         sfor<2>([&](auto RT) __attribute__((always_inline)) {
           constexpr int rt = decltype(RT)::value;
+          hook(ic<2 * x + rt>{});
           const float l = L16[x][rt][0];                     // the row's whole sum (of P as P.V saw it: rounded to bf16)
           int tok_local, hq;
           const bool row_ok = row_of(I, 2 * x + rt, tok_local, hq);
@@ -1309,7 +1373,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #endif
         });
       });
-    } else
+    } else {
+    sfor<4>([&](auto PART) __attribute__((always_inline)) { hook(PART); });
     sfor<2>([&](auto SB) __attribute__((always_inline)) {
       constexpr int sb = decltype(SB)::value;
       float l = ps0[sb] + ps1[sb];
@@ -1369,6 +1434,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       bad[sb] = has_keys;                          // diagnostic build: every row through the per-row routine
 #endif
     });
+    }
     // ---- rows that left the range: computed again, the plain way (never on attention scores as models produce them)
     // (M16: row 32 x + 16 rt + r16's flag sits in lane r16 of every lane group; packed into the same two 32-bit masks)
     const unsigned long long bad_a = M16 ? ((__ballot(bad16[0][0]) & 0xffffull) | ((__ballot(bad16[0][1]) & 0xffffull) << 16)) : __ballot(bad[0]);
@@ -1436,6 +1502,18 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
             t += 3;
           }
           if (dynamic) { draw(); drawn = true; }      // the next item's ticket: a few tiles before this item ends
+#ifndef PW_NO_TAIL2
+          if constexpr (M16) {
+            // unmasked for this wave, but too close to the end of the share or the sequence for the steady form's fetches
+            const int unmasked_hi = min(own_hi, 1 + min((cur.ctx_len + cur.w_tok_lo - (kPwTile - 1)) >> 6, (cur.seq_len >> 6) - 1));
+            while (t + 3 <= unmasked_hi) {
+              iteration(ic<0>{}, ic<2>{}, t);
+              iteration(ic<1>{}, ic<2>{}, t + 1);
+              iteration(ic<2>{}, ic<2>{}, t + 2);
+              t += 3;
+            }
+          }
+#endif
         }
         const int lim = pass == 0 ? min(pre_hi, own_hi) : own_hi;
         while (t < lim) {
@@ -1510,12 +1588,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     PW_SEAM_STAMP(4);
     const bool more = dynamic ? acquire(nxt, read_published(), true) : acquire(nxt, 0, false);
     PW_SEAM_STAMP(5);
-    if (more) {
-      issue_q(nxt);
-      issue_first_tiles(nxt);
-      PW_SEAM_STAMP(6);
-    }
-    epilogue(cur);
+    if (more) first_tiles_begin(nxt);
+    PW_SEAM_STAMP(6);
+    epilogue(cur, [&](auto PART) __attribute__((always_inline)) { if (more) next_item_loads(nxt, PART); });
 #ifdef MI355_PW_STAMP
     {
       unsigned long long st_exit;
@@ -1526,7 +1601,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     }
 #endif
     if (!more) break;
-    zero_o_and_convert_q(nxt);
+    zero_o_and_convert_q(nxt, true);
     cur = nxt;
   }
   finish();

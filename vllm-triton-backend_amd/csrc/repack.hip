@@ -8,6 +8,8 @@
 // describe), new rows from the linear tensors - into a flash-layout scratch cache in the caller's workspace with an
 // identity block table, and the prefill kernel runs on that. The pass moves 2x the K/V bytes once; prefill does
 // O(query_len) more work per key than that, so it is noise next to the attention itself.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mi355 {
@@ -232,10 +234,23 @@ mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, siz
   return r;
 }
 
+// A LONG prefill over an fp8 flash-layout cache: dequantise the sequences' keys into the 16-bit scratch once - exactly the
+// reference's (fp8 -> f32) * scale -> query type, :434-455 - and run the 64-rows-per-wave kernel on that, instead of the
+// register-staged kernel that widens every tile in every Q block (670 / 896 TFLOP/s at 1 / 16 x 4096 tokens). The pass
+// moves 3 bytes per cache element once, the attention does 2 q G flops per element: worth it when the sequences bring
+// many query rows (avg query_len * G >= 4096: the pass is then <= 15 % of the attention's time).
+static bool fp8_prefill_through_scratch(const mi355_attn_params& p) {
+  static const bool off = [] { const char* e = getenv("MI355_FP8_PREFILL_SCRATCH"); return e && e[0] == '0'; }();   // A/B
+  if (off || !is_fp8(p.kv_dtype) || p.k_new || p.max_seqlen_q <= 1 || p.max_seqlen_k < 2048) return false;
+  if (p.softcap > 0.0f || p.alibi_slopes || p.head_size != 128) return false;
+  const int64_t G = p.num_q_heads / p.num_kv_heads;
+  return (int64_t)p.num_tokens * G >= (int64_t)4096 * p.num_seqs;
+}
+
 bool repack_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) || (p.kv_dtype != p.q_dtype && !is_fp8(p.kv_dtype))) return false;
   const bool flash = p.k_x == p.head_size && p.k_stride_d == 1 && p.v_stride_d == 1;
-  if (!p.k_new && flash) return false;                       // nothing to repack: the kernels read that cache themselves
+  if (!p.k_new && flash && !fp8_prefill_through_scratch(p)) return false;   // nothing to repack: the kernels read that cache themselves
   if (p.only_decodes || p.max_seqlen_k <= 0) return false;
   if (p.head_size % 8 != 0 || p.page_size <= 0) return false;
   if (layout(p, 0).total > kRepackMaxBytes) return false;

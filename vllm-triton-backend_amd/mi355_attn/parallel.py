@@ -56,6 +56,9 @@ class LocalBatch:
     v_cache: torch.Tensor
     max_seqlen_q: int
     max_seqlen_k: int
+    # global token indices of EVERY rank's share, in rank order (host tensors): the assignment is deterministic and
+    # identical on every rank, so assembling the output needs no exchange of maps or counts
+    rank_token_index: Optional[List[torch.Tensor]] = None
 
 
 def shard_batch(rank: int, world_size: int, q, k_cache, v_cache, cu_seqlens_q, seqused_k, block_table) -> LocalBatch:
@@ -64,6 +67,8 @@ def shard_batch(rank: int, world_size: int, q, k_cache, v_cache, cu_seqlens_q, s
     kv = seqused_k.tolist()
     qlens = [cu[i + 1] - cu[i] for i in range(len(kv))]
     mine = assign_sequences(qlens, kv, world_size)[rank]
+    owned = assign_sequences(qlens, kv, world_size)
+    rank_tok = [torch.cat([torch.arange(cu[i], cu[i + 1]) for i in o]) if o else torch.zeros(0, dtype=torch.long) for o in owned]
     page = k_cache.shape[1]
     tok, pages, local_bt = [], [], []
     max_pages = 1
@@ -94,6 +99,7 @@ def shard_batch(rank: int, world_size: int, q, k_cache, v_cache, cu_seqlens_q, s
         v_cache=v_cache[page_idx] if len(pages) else v_cache[:0],
         max_seqlen_q=max(lq) if lq else 0,
         max_seqlen_k=max((kv[i] for i in mine), default=0),
+        rank_token_index=rank_tok,
     )
 
 
@@ -111,24 +117,23 @@ def shard_kv_heads(rank: int, world_size: int, q, k_cache, v_cache):
 
 
 def gather_outputs(local_out: torch.Tensor, local: LocalBatch, total_tokens: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
-    """Assemble the full [T, Hq, D] output on every rank from the batch-sharded pieces.
-    One all_gather of padded pieces + one of the token maps (RCCL over xGMI under backend "nccl")."""
+    """Assemble the full [T, Hq, D] output on every rank from the batch-sharded pieces: ONE all_gather_into_tensor of
+    the padded pieces (RCCL over xGMI under backend "nccl"). Counts and token maps are host arithmetic every rank
+    already has (`LocalBatch.rank_token_index`): no exchange of metadata, no device-to-host read."""
     world = dist.get_world_size(group)
-    counts = [torch.zeros(1, dtype=torch.int64, device=local_out.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([local_out.shape[0]], dtype=torch.int64, device=local_out.device), group=group)
-    counts = [int(c.item()) for c in counts]
+    maps = local.rank_token_index
+    assert maps is not None and len(maps) == world, "LocalBatch was built for another world size"
+    counts = [int(m.numel()) for m in maps]
     t_max = max(max(counts), 1)
-    pad_out = torch.zeros((t_max,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device)
+    dev = local_out.device
+    pad_out = torch.zeros((t_max,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=dev)
     pad_out[: local_out.shape[0]] = local_out
-    pad_idx = torch.full((t_max,), -1, dtype=torch.int64, device=local_out.device)
-    pad_idx[: local_out.shape[0]] = local.token_index.to(local_out.device)
-    outs = [torch.empty_like(pad_out) for _ in range(world)]
-    idxs = [torch.empty_like(pad_idx) for _ in range(world)]
-    dist.all_gather(outs, pad_out, group=group)
-    dist.all_gather(idxs, pad_idx, group=group)
-    full = torch.zeros((total_tokens,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device)
-    for o, ix, n in zip(outs, idxs, counts):
-        full[ix[:n]] = o[:n]
+    gathered = torch.empty((world * t_max,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=dev)
+    dist.all_gather_into_tensor(gathered, pad_out, group=group)
+    src = torch.cat([torch.arange(r * t_max, r * t_max + n) for r, n in enumerate(counts)]).to(dev)
+    dst = torch.cat(maps).to(dev)
+    full = torch.zeros((total_tokens,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=dev)
+    full[dst] = gathered[src]
     return full
 
 
@@ -164,13 +169,46 @@ def split_key_range(seq_len: int, page_size: int, world_size: int) -> List[tuple
 
 
 def all_gather_and_merge(local_out: torch.Tensor, local_lse: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> tuple:
-    """The exchange step: all_gather of (out as float32, lse) over the group - RCCL over xGMI with backend "nccl",
-    "gloo" in the CPU tests - then the merge on every rank. Payload per rank: T*H*(D+1)*4 bytes (decode: a few MB)."""
+    """The exchange step: ONE all_gather_into_tensor of a byte buffer holding the rank's partial output IN ITS OWN
+    16-bit type and its f32 lse - RCCL over xGMI with backend "nccl", "gloo" in the CPU tests - then the merge on every
+    rank: on the GPU one launch of the library's merge kernel (`mi355_merge_attention_partials`, the key-split merge of
+    the prefill path = reduce_segments on normalised partials), result in the query type; with CPU tensors (the gloo
+    tests) the torch restatement `merge_partial_attention`. Payload per rank: T*H*(2*D + 4) bytes. No host sync.
+    Returns (out [T, H, D], lse [T, H] f32); out is f32 on the CPU path, the query type on the GPU path."""
     world = dist.get_world_size(group)
-    o32 = local_out.to(torch.float32).contiguous()
+    T, H, D = local_out.shape
+    dev = local_out.device
+    fast = local_out.is_cuda and local_out.dtype in (torch.bfloat16, torch.float16) and world <= 8 and D % 8 == 0
+    o = local_out.contiguous() if fast else local_out.to(torch.float32).contiguous()
     l32 = local_lse.to(torch.float32).contiguous()
-    outs = [torch.empty_like(o32) for _ in range(world)]
-    lses = [torch.empty_like(l32) for _ in range(world)]
-    dist.all_gather(outs, o32, group=group)
-    dist.all_gather(lses, l32, group=group)
-    return merge_partial_attention(torch.stack(outs), torch.stack(lses))
+    ob, lb = o.numel() * o.element_size(), l32.numel() * 4
+    ob_pad = (ob + 255) & ~255                                   # keeps every rank's lse block (and the next rank's out) 256-byte aligned
+    per = ob_pad + ((lb + 255) & ~255)
+    send = torch.empty(per, dtype=torch.uint8, device=dev)
+    send[:ob].view(o.dtype).view(T, H, D).copy_(o)
+    send[ob_pad:ob_pad + lb].view(torch.float32).view(T, H).copy_(l32)
+    recv = torch.empty(world * per, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, per)
+    outs = recv[:, :ob].view(o.dtype).view(world, T, H, D)
+    lses = recv[:, ob_pad:ob_pad + lb].view(torch.float32).view(world, T, H)
+    if not fast:
+        return merge_partial_attention(outs, lses)
+    return merge_partial_attention_device(outs, lses)
+
+
+def merge_partial_attention_device(outs: torch.Tensor, lses: torch.Tensor) -> tuple:
+    """`merge_partial_attention` as ONE launch of the library's merge kernel (`mi355_merge_attention_partials`): outs
+    [R, T, H, D] bf16 / f16 on the GPU, lses [R, T, H] f32, R <= 8. Returns (out [T, H, D] in the partials' type, lse f32)."""
+    from . import _lib
+
+    R, T, H, D = outs.shape
+    dev = outs.device
+    part_out = outs.contiguous()           # (gathered blocks sit `per` bytes apart: packed once)
+    part_lse = lses.to(torch.float32).contiguous()
+    out = torch.empty((T, H, D), dtype=outs.dtype, device=dev)
+    lse = torch.empty((T, H), dtype=torch.float32, device=dev)
+    rc = _lib.load().mi355_merge_attention_partials(part_out.data_ptr(), part_lse.data_ptr(), R, out.data_ptr(), lse.data_ptr(),
+                                                    _lib.dtype_code(outs.dtype), T, H, D, H * D, D, H, _lib.current_stream_handle(dev))
+    _lib.check(rc, "mi355_merge_attention_partials")
+    return out, lse
