@@ -60,6 +60,8 @@ def test_64_rows_per_wave_prefill_kernel_vs_the_reference_2d_kernel(name):
                                (-1, -1), d["block_table"], 0.0, None, None, None, None, num_segments=1)
     launch(p, gpu_util.DEV)
     torch.cuda.synchronize()
-    assert _lib.last_kernel() == "prefill_mfma_pw", _lib.last_kernel()
+    import os
+    pinned = os.environ.get("MI355_PREFILL", "pw")          # (tests/test_gpu_variants.py pins other prefill kernels on this file)
+    assert _lib.last_kernel() == ("prefill_mfma_pw" if pinned == "pw" else "prefill_mfma"), _lib.last_kernel()
     atol, rtol = golden_io.tolerance(t["q"].dtype)
     torch.testing.assert_close(out.float().cpu(), t["out"], atol=atol, rtol=rtol)

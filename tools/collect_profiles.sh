@@ -1,26 +1,37 @@
 #!/bin/bash
-# Collect the round's measurement evidence on a GPU box into <out> (default gpurun_out/prof_r02); the summaries are then
+# Collect the round's measurement evidence on a GPU box into <out> (default gpurun_out/prof_r03); the summaries are then
 # copied by hand into profiles/<round>/. Counter passes are separate runs with --kernel-trace only (pool rule).
 #   bash tools/collect_profiles.sh [out]
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=${1:-$REPO/gpurun_out/prof_r02}
+OUT=${1:-$REPO/gpurun_out/prof_r03}
 mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)                  # (a relative path would be lost with the cd below)
 cd /tmp && export TMPDIR=/tmp
 echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes)"
 python3 $REPO/tools/collect_traffic.py $OUT/traffic > $OUT/traffic.log 2>&1; tail -60 $OUT/traffic.log
-mkdir -p $REPO/profiles/r02 && cp $OUT/traffic/traffic.json $REPO/profiles/r02/traffic.json   # bench.py reports it when it matches the built sources
+mkdir -p $REPO/profiles/r03 && cp $OUT/traffic/traffic.json $REPO/profiles/r03/traffic.json   # bench.py reports it when it matches the built sources
 echo "== bench.py (default protocol)"
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench.py failed"
 tail -c 3000 $OUT/bench.json
 echo "== rocprofv3 --kernel-trace --stats of bench.py, one leg per run (a kernel symbol serves several legs)"
-for leg in prefill decode decode_fp8 mixed; do
+for leg in prefill decode decode_fp8 mixed prefill_b8; do
   rm -rf $OUT/stats_$leg && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$leg -- python3 $REPO/bench.py --no-cpu-baseline --legs $leg > $OUT/stats_bench_$leg.json 2> $OUT/stats_$leg.err
   f=$(find $OUT/stats_$leg -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats_$leg.csv; cut -c1-230 $OUT/bench_kernel_stats_$leg.csv; fi
   grep -o '"kernel_us": [0-9.]*' $OUT/stats_bench_$leg.json | head -2
   rm -rf $OUT/stats_$leg
+done
+echo "== the 2D kernel's matrix: every prefill variant at 1 x 4096 / 16 x 4096, then kernel stats + MFMA busy of the variants on the 64-rows-per-wave kernel"
+bash $REPO/tools/sweeps/prefill_matrix.sh $OUT/prefill_matrix.log; cat $OUT/prefill_matrix.log
+for v in "f16:--dtype f16" "sw1024:--window 1024" "fp8:--kvdtype fp8" "f16_b16:--dtype f16 --batch 16" "sw1024_b16:--window 1024 --batch 16" "fp8_b16:--kvdtype fp8 --batch 16"; do
+  name=${v%%:*}; args=${v#*:}
+  rm -rf $OUT/stats_v && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_v -- python3 $REPO/tools/bench_prefill.py --iters 5 $args > $OUT/variant_$name.log 2>&1
+  f=$(find $OUT/stats_v -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats_variant_$name.csv; cut -c1-200 $OUT/bench_kernel_stats_variant_$name.csv; fi
+  rm -rf $OUT/stats_v
+  PMC_PASSES=1 python3 $REPO/tools/pmc_collect.py $OUT/pmc_v prefill_pw_kernel -- python3 $REPO/tools/bench_prefill.py --iters 5 $args > $OUT/pmc_variant_$name.txt 2>&1; grep -i "mfma\|busy" $OUT/pmc_variant_$name.txt | head -6
+  rm -rf $OUT/pmc_v
 done
 echo "== SQ counters, prefill_pw_kernel at C2"
 PMC_PASSES=0,1,2,3,4 MI355_PREFILL=pw python3 $REPO/tools/pmc_collect.py $OUT/pmc_prefill prefill_pw_kernel -- python3 $REPO/tools/bench_prefill.py --iters 5 > $OUT/pmc_prefill.txt 2>&1; cat $OUT/pmc_prefill.txt
@@ -32,6 +43,13 @@ if [ -f $REPO/tools/ab/pwstamp.so ]; then
   MI355_LIB=$REPO/tools/ab/pwstamp.so MI355_PREFILL=pw python3 $REPO/tools/pw_clock.py 1 16384 >> $OUT/pw_clock.log 2>&1
   grep -v amdgpu.ids $OUT/pw_clock.log
 fi
+echo "== seam stamps (diagnostic build)"
+if [ -f $REPO/tools/ab/pwseam.so ]; then
+  MI355_LIB=$REPO/tools/ab/pwseam.so MI355_PREFILL=pw MI355_PW_SEAM=1 python3 $REPO/tools/pw_clock.py 1 4096 > $OUT/pw_seam_final.log 2>&1; grep -v amdgpu.ids $OUT/pw_seam_final.log
+fi
+echo "== end-to-end protocol, attention only (tools/e2e_proxy.py)"
+python3 $REPO/tools/e2e_proxy.py > $OUT/e2e_proxy.log 2>&1; grep -v amdgpu.ids $OUT/e2e_proxy.log
+python3 $REPO/tools/e2e_proxy.py --kv-cache-dtype fp8 --output-lens 10 100 800 3200 12800 --sample-every 8 > $OUT/e2e_proxy_fp8.log 2>&1; grep -v amdgpu.ids $OUT/e2e_proxy_fp8.log | tail -8
 echo "== decode step latency in a graph"
 python3 $REPO/tools/decode_latency.py > $OUT/decode_latency.log 2>&1; tail -12 $OUT/decode_latency.log
 echo "== decode microbench C3 / C5"

@@ -306,6 +306,13 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 // x * tanh(s / x) (reference: apply_softcap, triton_unified_attention.py:24-29, restated with tanhf
 // so that |s/x| > 88 does not overflow)
 __device__ __forceinline__ float softcap_fn(float s, float cap) { return cap * tanhf(s / cap); }
+// The same for the 16-bit matrix-core kernels, where a score costs issue slots: tanh(z) = 1 - 2 / (1 + e^(2z)) as one
+// v_exp, one v_rcp and three more instructions (tanhf is a few dozen). Absolute error ~1e-6 * cap - three orders of
+// magnitude inside what a 16-bit P resolves; saturates cleanly (e^(2z) = inf -> 1, 0 -> -1). `k` = 2 * log2(e) / cap.
+__device__ __forceinline__ float softcap_fast(float s, float cap, float k) {
+  const float e = __builtin_amdgcn_exp2f(s * k);
+  return cap - 2.0f * cap * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // ---------------------------------------------------------------------------------------------
 // host side

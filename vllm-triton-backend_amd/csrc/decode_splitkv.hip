@@ -520,7 +520,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       for (int j = 0; j < 8; ++j) {
         const int key = tile * kTileKeys + (j >> 2) * 16 + grp * 4 + (j & 3);
         float x = sv[j] * scale_nat;
-        if (p.softcap > 0.0f) x = softcap_fn(x, p.softcap);
+        if (p.softcap > 0.0f) x = softcap_fast(x, p.softcap, 2.0f * kLog2e / p.softcap);
         if (key >= n_keys || key < first_key) x = -INFINITY;
         if (p.alibi_slopes) x += slope * (float)(key - ctx_len);
         sv[j] = x * kLog2e;

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   const float scale_nat = p.scale * k_scale;   // fp8: K is used un-scaled, its scale moves here
   const float scale2 = scale_nat * kLog2eP;
   const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
+  const float softcap_k = (FEAT && p.softcap > 0.0f) ? 2.0f * kLog2eP / p.softcap : 0.0f;
 
   // ---- staging: thread t loads pieces t + 256*i of the 64 x PPR tile ------------------------------
   // Load round i of a wave touches exactly one 16-key group, so the page lookup is wave-uniform:
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
           for (int r = 0; r < 16; ++r) {
             const int key = key_base + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
             float x = s_acc[kb][r] * scale_nat;
-            if (p.softcap > 0.0f) x = softcap_fn(x, p.softcap);
+            if (p.softcap > 0.0f) x = softcap_fast(x, p.softcap, softcap_k);
             bool ok = row_ok && key <= q_abs && key < seq_len;
             if (p.sliding_window > 0) ok = ok && (q_abs - key) < p.sliding_window;
             x = ok ? x : -INFINITY;
@@ -563,13 +564,17 @@ constexpr float kDeferThr = 8.0f;
 // other's MFMAs, 4 stages - was built and measured 4 % SLOWER than the plain 8-wave kernel: the chip is
 // at its 1.4 kW package power limit under this kernel (tools/clock_watch.py), so re-ordering the same
 // work buys nothing; only doing less work per FLOP does. It is not kept.)
-template <typename T, int NW, int NST>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(const PrefillArgs a) {
-  constexpr int D = 128;
-  constexpr int ROWB = D * 2;                 // 256-byte rows, 16 chunks of 16 B
+// (The row geometry is written for D = 128 and D = 256 - 512-byte rows, a wave's LDS-DMA instruction covers two key rows
+// of 32 chunks - but only D = 128 is instantiated: see launch_prefill for what the D = 256 form measured.)
+template <typename T, int NW, int NST, int D = 128>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefill_dma_kernel(const PrefillArgs a) {
+  static_assert(D == 128 || D == 256, "rows of 16 or 32 chunks");
+  constexpr int ROWB = D * 2;                 // 256-byte rows of 16 chunks of 16 B (D = 256: 512 bytes, 32 chunks)
+  constexpr int CPRW = ROWB / 16;             // chunks per row
+  constexpr int RPW = 64 / CPRW;              // key rows one wave's LDS-DMA instruction covers (4, or 2)
   constexpr int KBUF = kTileN * ROWB, STAGE = 2 * KBUF;   // K tile then V tile
   constexpr int KSTEPS = D / 16, DBLK = D / 32;
-  constexpr int RP = 4 * NW;                  // key rows one LDS-DMA piece covers (all waves, 4 rows each)
+  constexpr int RP = RPW * NW;                // key rows one LDS-DMA piece covers (all waves, RPW rows each)
   constexpr int NP = kTileN / RP;             // pieces per tile: each is one K and one V instruction per wave
   constexpr int PD = NST - 1;                 // prefetch distance in tiles
   constexpr int IPT = 2 * NP;                 // LDS-DMA instructions per tile per wave
@@ -659,13 +664,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
   const int page_mask = p.page_size - 1;
-  const int rowin = tid >> 4, ch = tid & 15;      // row within a piece (0 .. RP-1), 16-byte chunk
-  const int rig = rowin & 15;                     // row within its 16-key group
-  const int grp_in_piece = __builtin_amdgcn_readfirstlane(rowin >> 4);   // wave-uniform: a wave's 4 rows share a group
-  const int fk = rig;
-  const int fv = ((rig & 3) << 2) | ((rig >> 2) & 3);
-  uint32_t k_voff = (uint32_t)(rig * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
-  uint32_t v_voff = (uint32_t)(rig * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
+  const int rowin = tid / CPRW, ch = tid % CPRW;  // row within a piece (0 .. RP-1), 16-byte chunk
+  // piece i covers rows RP i + rowin of the tile: with RP >= 16 a lane's row within its 16-key group is the same for
+  // every piece; with RP = 8 (D = 256) odd pieces are the group's second half
+  auto rig_of = [&](int i) { return (RP * i + rowin) & 15; };              // row within its 16-key group
+  auto grp_of = [&](int i) { return __builtin_amdgcn_readfirstlane((RP * i + rowin) >> 4); };   // wave-uniform: a wave's rows share a group
+  auto fk_of = [&](int r) { return r; };
+  auto fv_of = [&](int r) { return ((r & 3) << 2) | ((r >> 2) & 3); };
+  // (the swizzles flip the low four bits of the chunk index: inside each 256-byte half of a 512-byte row)
+  uint32_t k_voff[RP >= 16 ? 1 : 2], v_voff[RP >= 16 ? 1 : 2];
+#pragma unroll
+  for (int j = 0; j < (RP >= 16 ? 1 : 2); ++j) {
+    const int r = rig_of(j);
+    k_voff[j] = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk_of(r)) << 4));
+    v_voff[j] = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv_of(r)) << 4));
+  }
   const uint32_t lds_wave = (uint32_t)(wave * 64 * 16);        // + i*RP*ROWB (+KBUF for V) + stage
 
   const int last_entry = (last_group << 4) >> a.page_shift;
@@ -700,18 +713,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   };
   // piece i of a tile = key rows RP*i .. RP*i+RP-1: one K and one V LDS-DMA per lane (1 KiB each per wave)
   auto dma_piece = [&](int tile, char* stage, int i) {
-    const int gi = min(tile * 4 + i * (RP / 16) + grp_in_piece, last_group);
+    const int gi = min(tile * 4 + grp_of(i), last_group);
     const int key0 = gi << 4;
     const int slot0 = key0 & page_mask;
     int page;
     if constexpr (BT_IN_LDS) page = __builtin_amdgcn_readfirstlane(bt_lds[key0 >> a.page_shift]);
     else page = __builtin_amdgcn_readlane(bt_cur, (key0 >> a.page_shift) & 63);
-    uint32_t kvo = k_voff, vvo = v_voff;
+    uint32_t kvo = k_voff[RP >= 16 ? 0 : (i & 1)], vvo = v_voff[RP >= 16 ? 0 : (i & 1)];
     if (key0 + 16 > seq_len) {            // wave-uniform: the sequence ends inside this group -> rows past it
                                           // fetch its last row instead (never stale cache contents)
+      const int rig = rig_of(i);
       const int r = min(rig, max(seq_len - 1 - key0, 0));
-      kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk) << 4));
-      vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv) << 4));
+      kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((ch ^ fk_of(rig)) << 4));
+      vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((ch ^ fv_of(rig)) << 4));
     }
     // K and V caches are two views of one tensor in vLLM: with equal strides (wave-uniform test, one scalar offset
     // serves both) the 64-bit page arithmetic is done once
@@ -734,15 +748,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
 
   // ---- per-lane LDS read addresses (swizzle folded in) ---------------------------------------------
   // K fragment ks of 32-key block kb: row 32kb + qr, logical chunk 2ks + half
-  uint32_t k_rd[KSTEPS];
+  // (D = 256: chunks 16 .. 31 are the row's second 256-byte half, same swizzle: + 256 bytes as an immediate, not a register)
+  constexpr int KRD = KSTEPS < 8 ? KSTEPS : 8, VRD = DBLK < 4 ? DBLK : 4;
+  uint32_t k_rd[KRD];
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = (uint32_t)(qr * ROWB + (((2 * ks + half) ^ (qr & 15)) << 4));
+  for (int ks = 0; ks < KRD; ++ks) k_rd[ks] = (uint32_t)(qr * ROWB + (((2 * ks + half) ^ (qr & 15)) << 4));
   // V transposed read of k-step sk (16 keys), output block b: row 16sk + 4half + q4 (+8), logical
   // byte column 64b + 32g1 + 8pp  ->  chunk 4b + 2g1 + (pp>>1), sub-offset 8(pp&1)
   const int gq1 = (lane >> 4) & 1, li = lane & 15, q4 = li >> 2, pp = li & 3;
-  uint32_t v_rd0[DBLK], v_rd1[DBLK];
+  uint32_t v_rd0[VRD], v_rd1[VRD];
 #pragma unroll
-  for (int b = 0; b < DBLK; ++b) {
+  for (int b = 0; b < VRD; ++b) {
     const int lc = 4 * b + 2 * gq1 + (pp >> 1);
     const int r0 = 4 * half + q4, r1 = r0 + 8;
     const int f0 = ((r0 & 3) << 2) | ((r0 >> 2) & 3), f1 = ((r1 & 3) << 2) | ((r1 >> 2) & 3);
@@ -752,9 +768,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
   // ds_read's immediate offset reaches 64 KiB: stages 0 and 1 are immediates on the addresses above, a stage beyond
   // that costs one v_add per read. (Per-lane addresses of its own for that stage, 16 more VGPRs, measured 0.7 %
   // SLOWER sustained than the adds.)
-  auto k_addr = [&](const char* stage, int ks) -> const char* { return stage + k_rd[ks]; };
-  auto v_addr0 = [&](const char* stage, int b) -> const char* { return stage + v_rd0[b]; };
-  auto v_addr1 = [&](const char* stage, int b) -> const char* { return stage + v_rd1[b]; };
+  auto k_addr = [&](const char* stage, int ks) -> const char* { return stage + k_rd[ks % KRD] + (ks / KRD) * 256; };
+  auto v_addr0 = [&](const char* stage, int b) -> const char* { return stage + v_rd0[b % VRD] + (b / VRD) * 256; };
+  auto v_addr1 = [&](const char* stage, int b) -> const char* { return stage + v_rd1[b % VRD] + (b / VRD) * 256; };
 
   float m_ref = 0.0f, l_run = 0.0f;
   bool started = !row_ok;               // padding rows never see a key: do not let them force the slow path
@@ -811,26 +827,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
     s_acc[0] = cinit; s_acc[1] = cinit;
     asm volatile("" : "+v"(s_acc[0]), "+v"(s_acc[1]));
 #else
-    pu32x4_t kf[KSTEPS];
+    // the fragments of the two 32-key blocks as one stream of 2 KSTEPS reads through a ring of KW registers (a whole
+    // block at D = 128; half of one at D = 256, where 16 fragments would be 64 registers)
+    constexpr int KW = KSTEPS < 8 ? KSTEPS : 8;
+    auto k_frag_addr = [&](int m) { return k_addr(stage, m % KSTEPS) + (m / KSTEPS) * 32 * ROWB; };
+    pu32x4_t kf[KW];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *(const pu32x4_t*)k_addr(stage, ks);
-    __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
+    for (int m = 0; m < KW; ++m) kf[m] = *(const pu32x4_t*)k_frag_addr(m);
+    __builtin_amdgcn_sched_group_barrier(0x100, KW, 0);
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      s_acc[0] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], ks == 0 ? cinit : s_acc[0]);
-      kf[ks] = *(const pu32x4_t*)(k_addr(stage, ks) + 32 * ROWB);
+    for (int m = 0; m < 2 * KSTEPS; ++m) {
+      const int kb = m / KSTEPS, ks = m % KSTEPS;
+      s_acc[kb] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[m % KW]), qf[ks], ks == 0 ? cinit : s_acc[kb]);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (m + KW < 2 * KSTEPS) {
+        kf[m % KW] = *(const pu32x4_t*)k_frag_addr(m + KW);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
 #ifndef MI355_ABLATE_DMA
-      if (prefetch && (ks % (KSTEPS / NP)) == 1) {
+      if (kb == 0 && prefetch && (ks % (KSTEPS / NP)) == 1) {
         dma_piece(tile + PD, next_stage, ks / (KSTEPS / NP));
       }
 #endif
-    }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      s_acc[1] = pmma<T>::run(__builtin_bit_cast(ps16x8_t, kf[ks]), qf[ks], ks == 0 ? cinit : s_acc[1]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
 #endif
 #ifdef MI355_PROFILE_PHASES
@@ -1025,10 +1043,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void prefill_dma_kernel(c
         *(pu32x2_t*)(ost + qr * ORS + (32 * b + 8 * c + 4 * half) * 2) = w;
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same wave reads other lanes' pieces back: LDS is in order per wave
-    const int orow = lane >> 4, och = lane & 15;
+    const int orow = lane / CPRW, och = lane % CPRW;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = 4 * j + orow;
+    for (int j = 0; j < 32 / RPW; ++j) {
+      const int r = RPW * j + orow;
       const int m = wave * 32 + r;                       // row inside the Q block
       const int tok = tok0 + m / G;
       const pu32x4_t v = *(const pu32x4_t*)(ost + r * ORS + och * 16);
@@ -1305,7 +1323,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream, cons
   return rc;
 }
 
-template <typename T, int NW, int NST>
+template <typename T, int NW, int NST, int D = 128>
 static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
   PrefillArgs a;
   a.p = p;
@@ -1321,15 +1339,15 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, co
   a.tiles_per_key_split = ks ? ks->tiles_per_split : 0;
   a.out_split_stride = ks ? ks->out_split_stride : 0;
   a.lse_split_stride = ks ? ks->lse_split_stride : 0;
-  size_t lds = (size_t)NST * 2 * kTileN * 256;   // NST stages of K + V tiles, unpadded
+  size_t lds = (size_t)NST * 2 * kTileN * (2 * D);   // NST stages of K + V tiles, unpadded
   if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix (the caller checked that it fits)
   static std::atomic<uint64_t> lds_opt_in{0};
-  const int rc0 = ensure_dynamic_lds((const void*)prefill_dma_kernel<T, NW, NST>, (int)((size_t)NST * 2 * kTileN * 256 + (NST >= 3 ? bt_lds_max_bytes(NST) : 0)),
+  const int rc0 = ensure_dynamic_lds((const void*)prefill_dma_kernel<T, NW, NST, D>, (int)((size_t)NST * 2 * kTileN * (2 * D) + (NST >= 3 ? bt_lds_max_bytes(NST) : 0)),
                                      lds_opt_in, "hipFuncSetAttribute(prefill_dma)");
   if (rc0 != MI355_OK) return rc0;
-  hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(NW * 64), lds, stream, a);
+  hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST, D>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(NW * 64), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_dma_kernel launch");
-  if (rc == MI355_OK) set_kernel_name("prefill_mfma");
+  if (rc == MI355_OK) set_kernel_name(D == 256 ? "prefill_mfma_d256" : "prefill_mfma");
   return rc;
 }
 
@@ -1377,6 +1395,10 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
       return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream, ks) : launch_prefill_dma<f16_t, 8, 3>(p, stream, ks);
     return bf ? launch_prefill_dma<bf16_t, 4, 2>(p, stream, ks) : launch_prefill_dma<f16_t, 4, 2>(p, stream, ks);
   }
+  // (Head size 256 on the LDS-DMA form - prefill_dma_kernel<T, 4, 2, 256>, one workgroup per CU - was built in round 3 and
+  // measured 112 TFLOP/s against the register-staged kernel's 494: without staging registers hipcc still moves several
+  // hundred values per tile between VGPRs and accumulator registers (432 v_accvgpr_read + 225 v_accvgpr_write per tile
+  // in the ISA, 750 bytes of scratch). Head size 256 needs the hand-owned register file of prefill_pw_kernel.)
 #define MI355_PREFILL_CASE(KV, DD)                                                                        \
   case DD:                                                                                                \
     if (feat) return bf ? launch_prefill_t<bf16_t, KV<bf16_t>, DD, true>(p, stream, ks) : launch_prefill_t<f16_t, KV<f16_t>, DD, true>(p, stream, ks); \

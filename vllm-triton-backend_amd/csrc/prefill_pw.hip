@@ -749,26 +749,18 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   // ---- an item's first tiles on their way: K0 K1 V0 | K2 V1 (twenty pieces) ------------------------------
   int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration (V's = K's of one iteration earlier)
-  int ft_pg[3] = {0, 0, 0};                      // block-table entries of the item's first three tiles
-  bool ft_any = false;
-  // the scalar side: ring offsets back to whole groups, the first four block-table entries
-  auto first_tiles_begin = [&](const Item& I) __attribute__((always_inline)) {
+  auto issue_first_tiles = [&](const Item& I) __attribute__((always_inline)) {
     if (k_tail) { set_k_offsets(15); k_tail = false; }     // the previous item may have ended inside a group
     if (v_tail) { set_v_offsets(15); v_tail = false; }
-    ft_any = I.tile_hi > I.tile_lo;
-    if (!ft_any) return;
+    if (I.tile_hi <= I.tile_lo) return;
+    int pk0, pk1, pk2, pv0, pv1;
     const int eo0 = entry_off(I, I.tile_lo), eo1 = entry_off(I, I.tile_lo + 1), eo2 = entry_off(I, I.tile_lo + 2), eo3 = entry_off(I, I.tile_lo + 3);
     if (sa.num_seqs == 1 && sa.key_splits == 1 && eo0 == spec_off[0] && eo1 == spec_off[1] && eo2 == spec_off[2] && eo3 == spec_off[3]) {
-      ft_pg[0] = spec_pg[0]; ft_pg[1] = spec_pg[1]; ft_pg[2] = spec_pg[2]; pg_k = spec_pg[3];     // the speculative entries are the right ones
+      pk0 = spec_pg[0]; pk1 = spec_pg[1]; pk2 = spec_pg[2]; pg_k = spec_pg[3];     // the speculative entries are the right ones
     } else {
-      scalar_load4((const int32_t*)I.bt64, eo0 >> 2, eo1 >> 2, eo2 >> 2, eo3 >> 2, ft_pg[0], ft_pg[1], ft_pg[2], pg_k);
+      scalar_load4((const int32_t*)I.bt64, eo0 >> 2, eo1 >> 2, eo2 >> 2, eo3 >> 2, pk0, pk1, pk2, pg_k);
     }
-    pg_v = ft_pg[2];                             // K and V share the block table
-  };
-  // group g of K0 K1 V0 K2 V1 (four LDS-DMA pieces each)
-  auto first_tiles_group = [&](const Item& I, auto GC) __attribute__((always_inline)) {
-    constexpr int g = decltype(GC)::value;
-    if (!ft_any) return;
+    pv0 = pk0; pv1 = pk1; pg_v = pk2;            // K and V share the block table
     auto group = [&](int tile, int page, auto ISV, uint32_t lds_dst) {
       constexpr bool isv = decltype(ISV)::value != 0;
       tail_check(I, tile, ISV);
@@ -776,15 +768,11 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) pw_glds16(isv ? voff[i] : koff[i], base, lds_dst + lds_wave + i * 1024);
     };
-    if constexpr (g == 0) group(I.tile_lo, ft_pg[0], ic<0>{}, kLdsK);
-    if constexpr (g == 1) group(I.tile_lo + 1, ft_pg[1], ic<0>{}, kLdsK + kSlotBytes);
-    if constexpr (g == 2) group(I.tile_lo, ft_pg[0], ic<1>{}, kLdsV);
-    if constexpr (g == 3) group(I.tile_lo + 2, ft_pg[2], ic<0>{}, kLdsK + 2 * kSlotBytes);
-    if constexpr (g == 4) group(I.tile_lo + 1, ft_pg[1], ic<1>{}, kLdsV + kSlotBytes);
-  };
-  auto issue_first_tiles = [&](const Item& I) __attribute__((always_inline)) {
-    first_tiles_begin(I);
-    sfor<5>([&](auto GC) __attribute__((always_inline)) { first_tiles_group(I, GC); });
+    group(I.tile_lo, pk0, ic<0>{}, kLdsK);
+    group(I.tile_lo + 1, pk1, ic<0>{}, kLdsK + kSlotBytes);
+    group(I.tile_lo, pv0, ic<1>{}, kLdsV);
+    group(I.tile_lo + 2, pk2, ic<0>{}, kLdsK + 2 * kSlotBytes);
+    group(I.tile_lo + 1, pv1, ic<1>{}, kLdsV + kSlotBytes);
   };
   // The next item's loads, hung in front of the output's first row tile (hook 0 of epilogue). Dealt over the output's four
   // row tiles they left the address unit to the output's own work - the seam's stamps shrank by 2.4 us - and the launch
@@ -795,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     constexpr int part = decltype(PART)::value;
     if constexpr (part == 0) {
       issue_q(I, -1);
-      sfor<5>([&](auto GC) __attribute__((always_inline)) { first_tiles_group(I, GC); });
+      issue_first_tiles(I);
     }
   };
 
@@ -1179,7 +1167,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (fast_fetch) vb64 = group_base_fast(cur, t + 2, pg_v, ic<1>{});
           else { tail_check(cur, t + 2, ic<1>{}); vb64 = group_base(cur, t + 2, pg_v, ic<1>{}); }
-          pg_v = pg_k;
+          asm volatile("s_mov_b32 %0, %1" : "=s"(pg_v) : "s"(__builtin_amdgcn_readfirstlane(pg_k)));      // (a scalar copy: the compiler otherwise parks it in a VGPR and does V's page arithmetic on the VALU, v_mul_lo/hi + two v_readfirstlane)
           if constexpr (fast_fetch) pw_sload(pg_k, cur.bt64, entry_off_fast(t + 4));
           else pw_sload(pg_k, cur.bt64, entry_off(cur, t + 4));
           __builtin_amdgcn_sched_barrier(0);
@@ -1588,7 +1576,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     PW_SEAM_STAMP(4);
     const bool more = dynamic ? acquire(nxt, read_published(), true) : acquire(nxt, 0, false);
     PW_SEAM_STAMP(5);
-    if (more) first_tiles_begin(nxt);
     PW_SEAM_STAMP(6);
     epilogue(cur, [&](auto PART) __attribute__((always_inline)) { if (more) next_item_loads(nxt, PART); });
 #ifdef MI355_PW_STAMP
