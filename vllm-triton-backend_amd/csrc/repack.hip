@@ -106,36 +106,91 @@ struct CachePiece {
   }
 };
 
-// grid (pages_per_seq, num_seqs, Hk), 256 threads: one scratch page (16 keys x D) of one sequence and KV head per
-// workgroup, moved as 16-byte pieces (8 head dims of one key). A d-major V (v0 layout: the 16 keys of a page are
-// contiguous per head dim) is read along the keys, 8 per load, and turned through LDS; reading it along d would be
-// eight 2-byte loads per piece.
+// grid (ceil(pages_per_seq / kPagesPerWg), num_seqs, Hk), 256 threads: kPagesPerWg consecutive scratch pages (16 keys x D
+// each) of one sequence and KV head per workgroup, moved as 16-byte pieces (8 head dims of one key). A d-major V (v0
+// layout: the 16 keys of a page are contiguous per head dim) is read along the keys, 8 per load, and turned through LDS;
+// reading it along d would be eight 2-byte loads per piece.
+// (Round 3: four pages per workgroup instead of one. One page is a single piece of K and of V per thread behind three
+// dependent loads - lengths, block table, data: latency bound at ~1.5 TB/s on the 25 MB of a 4096-token sequence. With
+// four pages a thread has its block-table entries and then eight pieces in flight together.)
+constexpr int kPagesPerWg = 4;
+
 template <typename QT, typename KVT>
 __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   const mi355_attn_params& p = a.p;
-  const int pg = blockIdx.x, seq = blockIdx.y, h = blockIdx.z;
-  if (threadIdx.x == 0 && h == 0) a.bt_dst[(int64_t)seq * a.pages_per_seq + pg] = seq * a.pages_per_seq + pg;
+  const int pg0 = blockIdx.x * kPagesPerWg, seq = blockIdx.y, h = blockIdx.z;
+  if (h == 0 && threadIdx.x < kPagesPerWg && pg0 + (int)threadIdx.x < a.pages_per_seq)
+    a.bt_dst[(int64_t)seq * a.pages_per_seq + pg0 + threadIdx.x] = seq * a.pages_per_seq + pg0 + threadIdx.x;
   const int seq_len = p.seqused_k[seq];
   const int q_start = p.cu_seqlens_q[seq], q_len = p.cu_seqlens_q[seq + 1] - q_start;
   if (q_len <= 0 || (a.skip_single && q_len == 1)) return;
-  const int j0 = pg * kRepackPage;
-  if (j0 >= seq_len) return;
+  if (pg0 * kRepackPage >= seq_len) return;
   const int ctx = seq_len - q_len;
   const bool use_new = p.k_new != nullptr && (q_len > 1 || p.new_kv_all_rows);   // generic_attn.hip: same rule
   const int D = p.head_size, Hk = p.num_kv_heads, chunks = D >> 3;
   const int pieces = kRepackPage * chunks;
-  const int64_t dst_page = ((int64_t)seq * a.pages_per_seq + pg) * kRepackPage * Hk * D;
   const uint16_t* kn = (const uint16_t*)p.k_new;
   const uint16_t* vn = (const uint16_t*)p.v_new;
   constexpr bool kFp8 = CachePiece<QT, KVT>::kFp8;
   const float k_scale = (kFp8 && p.k_scale) ? p.k_scale[0] : 1.0f;
   const float v_scale = (kFp8 && p.v_scale) ? p.v_scale[0] : 1.0f;
+  const int32_t* bt_row = p.block_table + (int64_t)seq * p.block_table_stride;
 
-  // V of a page that comes from the cache as a whole (no new-token rows in it), d-major source
   __shared__ uint16_t vt[256][kRepackPage + 2];
+  // the common case in one go: every page's pieces are one per thread (D = 128: 256 pieces), all from the cache or all
+  // from the linear tensors, V row-major -> the block-table entries, then all loads, then all stores
+  const bool simple = pieces == 256 && !a.v_keys_contiguous;
+  if (simple) {
+    const int c = threadIdx.x % chunks, slot = threadIdx.x / chunks, d0 = 8 * c;
+    int page[kPagesPerWg];
+#pragma unroll
+    for (int u = 0; u < kPagesPerWg; ++u) {
+      const int j = (pg0 + u) * kRepackPage + slot;
+      page[u] = (j < seq_len && !(use_new && j >= ctx)) ? bt_row[j / p.page_size] : 0;
+    }
+    uint4 kk[kPagesPerWg], vv[kPagesPerWg];
+#pragma unroll
+    for (int u = 0; u < kPagesPerWg; ++u) {
+      const int j = (pg0 + u) * kRepackPage + slot;
+      kk[u] = uint4{0u, 0u, 0u, 0u}; vv[u] = uint4{0u, 0u, 0u, 0u};   // slots past the sequence end are zero-filled
+      if (j < seq_len) {
+        if (use_new && j >= ctx) {
+          const int64_t off = (int64_t)(q_start + j - ctx) * p.new_stride_token + (int64_t)h * p.new_stride_head + d0;
+          if (a.vec_new) { kk[u] = *(const uint4*)(kn + off); vv[u] = *(const uint4*)(vn + off); }
+          else { kk[u] = gather8(kn, off, 1); vv[u] = gather8(vn, off, 1); }
+        } else {
+          const int o = j % p.page_size;
+          const int64_t kb = (int64_t)page[u] * p.k_stride_page + (int64_t)o * p.k_stride_slot + (int64_t)h * p.k_stride_head;
+          kk[u] = CachePiece<QT, KVT>::load(p.k_cache, a.vec_k, k_scale, [&](int i) {
+            const int d = d0 + i;
+            return kb + (int64_t)(d / p.k_x) * p.k_stride_dx + (int64_t)(d % p.k_x) * p.k_stride_d;
+          });
+          const int64_t vb = (int64_t)page[u] * p.v_stride_page + (int64_t)o * p.v_stride_slot + (int64_t)h * p.v_stride_head;
+          vv[u] = CachePiece<QT, KVT>::load(p.v_cache, a.vec_v, v_scale, [&](int i) { return vb + (int64_t)(d0 + i) * p.v_stride_d; });
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPagesPerWg; ++u) {
+      if (pg0 + u >= a.pages_per_seq) break;
+      const int64_t dst = ((int64_t)seq * a.pages_per_seq + pg0 + u) * kRepackPage * Hk * D + ((int64_t)slot * Hk + h) * D + d0;
+      *(uint4*)(a.k_dst + dst) = kk[u];
+      *(uint4*)(a.v_dst + dst) = vv[u];
+    }
+    return;
+  }
+
+  for (int u = 0; u < kPagesPerWg; ++u) {
+  const int pg = pg0 + u;
+  if (pg >= a.pages_per_seq) break;
+  const int j0 = pg * kRepackPage;
+  if (j0 >= seq_len) break;
+  const int64_t dst_page = ((int64_t)seq * a.pages_per_seq + pg) * kRepackPage * Hk * D;
+  if (u > 0) __syncthreads();                   // vt is reused
+  // V of a page that comes from the cache as a whole (no new-token rows in it), d-major source
   const bool turn_v = a.v_keys_contiguous && !(use_new && j0 + kRepackPage > ctx);
   if (turn_v) {
-    const int page = p.block_table[(int64_t)seq * p.block_table_stride + j0 / p.page_size];
+    const int page = bt_row[j0 / p.page_size];
     const int o0 = j0 % p.page_size;
     const int64_t vb = (int64_t)page * p.v_stride_page + (int64_t)h * p.v_stride_head + o0;
     for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
@@ -163,7 +218,7 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
           vv = gather8(vn, off, 1);
         }
       } else {
-        const int page = p.block_table[(int64_t)seq * p.block_table_stride + j / p.page_size];
+        const int page = bt_row[j / p.page_size];
         const int o = j % p.page_size;
         const int64_t kb = (int64_t)page * p.k_stride_page + (int64_t)o * p.k_stride_slot + (int64_t)h * p.k_stride_head;
         kk = CachePiece<QT, KVT>::load(p.k_cache, a.vec_k, k_scale, [&](int i) {
@@ -184,6 +239,7 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
     const int64_t dst = dst_page + ((int64_t)slot * Hk + h) * D + d0;
     *(uint4*)(a.k_dst + dst) = kk;
     *(uint4*)(a.v_dst + dst) = vv;
+  }
   }
 }
 
@@ -285,7 +341,7 @@ int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool s
   a.vec_new = p.k_new && aligned16(p.k_new) && aligned16(p.v_new) && p.new_stride_token % 8 == 0 && p.new_stride_head % 8 == 0;
   a.v_keys_contiguous = p.v_stride_slot == 1 && p.v_stride_d % 8 == 0 && p.page_size % kRepackPage == 0 && p.head_size <= 256 && aligned(p.v_cache);
   for (int64_t s : {p.v_stride_page, p.v_stride_head}) a.v_keys_contiguous = a.v_keys_contiguous && s % 8 == 0;
-  dim3 grid(a.pages_per_seq, p.num_seqs, p.num_kv_heads);
+  dim3 grid((a.pages_per_seq + kPagesPerWg - 1) / kPagesPerWg, p.num_seqs, p.num_kv_heads);
   const bool bf = p.q_dtype == MI355_BF16;
   if (p.kv_dtype == MI355_FP8_E4M3) {
     if (bf) hipLaunchKernelGGL((repack_kernel<bf16_t, e4m3_t>), grid, dim3(256), 0, stream, a);
