@@ -425,6 +425,32 @@ def test_prefill_pw_kernel_keeps_the_compiler_out_of_the_accumulator_registers(t
     assert "ScratchSize: 0" in text.split("prefill_pw_kernel")[-1] or ".private_segment_fixed_size: 0" in text
 
 
+def test_head_size_256_prefill_keeps_the_compiler_out_of_its_accumulator_registers(tmp_path):
+    """prefill_mfma_kernel at head size 256 keeps O^T (a[0..127]) and the Q fragments (a[128..191]) in accumulator
+    registers that only its asm statements name (round 3: as C++ values hipcc spilled and shuffled hundreds of values per
+    tile). The build must show no compiler-emitted v_accvgpr_* outside the asm blocks and no scratch, in every D = 256
+    instantiation (16-bit and fp8 caches, with and without the feature set)."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "vllm-triton-backend_amd", "csrc", "prefill_mfma.hip")
+    out = tmp_path / "prefill_mfma.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                    src, "-o", str(out)], check=True, capture_output=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py"), str(out), "Li256E"], capture_output=True, text=True, check=True)
+    names = [l for l in r.stdout.splitlines() if l.startswith("== ")]
+    line = [l for l in r.stdout.splitlines() if l.startswith("compiler accvgpr/scratch outside asm:")]
+    assert len(names) == len(line) == 12, r.stdout[-1500:]          # {bf16, f16} x {same, e4m3, e5m2} x {plain, feat}
+    assert all(l.split(":")[1].split()[0] == "0" for l in line), r.stdout[-2000:]
+    text = out.read_text()
+    for m in re.finditer(r"\.amdhsa_kernel (\S*prefill_mfma_kernel\S*Li256E\S*)(.*?)\.end_amdhsa_kernel", text, re.S):
+        assert re.search(r"\.amdhsa_private_segment_fixed_size\s+0\b", m.group(2)), m.group(1)
+
+
 def test_fp8_decode_loop_keeps_its_two_register_sets_apart(tmp_path):
     """The fp8 decode kernel (head size <= 128) keeps TWO tiles of K/V in flight in two register sets that the tile
     loop must address at compile time. When the loop body grew past the unroller's limit the sets were indexed at run

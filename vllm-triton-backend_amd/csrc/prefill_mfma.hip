@@ -25,6 +25,8 @@
 // Launch grid mirrors the reference's static upper bound (T / BLOCK_Q + S Q-blocks, :886-889,
 // :935-943), heaviest (latest) Q blocks first.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 #include <cstring>
 
 #include "common.h"
@@ -77,6 +79,36 @@ template <> struct pmma<f16_t> {
   }
 };
 
+// f(integral_constant<0>) ... f(integral_constant<N-1>), in order
+template <typename F, int... I>
+__device__ __forceinline__ void pm_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void pm_for(F&& f) { pm_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// Head size 256 (round 3): O^T (128 registers per lane) and the Q fragments (64) live in accumulator registers that
+// only these statements name - a[0..127] and a[128..191], literal operands the register allocator never sees. As C++
+// values hipcc could not give them homes: with the 64 staging registers beside them it spilled ~30 VGPRs and moved several
+// hundred values per tile between VGPRs and accumulator registers (440-520 TFLOP/s). The rest of the kernel (S, P, the
+// K / V fragments, staging) stays ordinary code and fits the 256 VGPRs; tests/test_cpu_host.py audits the build.
+template <typename T> struct pmma_own;
+#define MI355_DEF_PMMA_OWN(TAG, MFMA)                                                                              \
+  template <> struct pmma_own<TAG> {                                                                              \
+    /* S(VGPR) += K(VGPR) . Q(AGPR) */                                                                             \
+    template <int QA> static __device__ __forceinline__ void qk(pf32x16_t& s, const pu32x4_t& k) {                \
+      asm volatile(MFMA " %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(k), "n"(QA), "n"(QA + 3));                       \
+    }                                                                                                             \
+    /* O(AGPR) += V(VGPR) . P(VGPR) */                                                                             \
+    template <int OA> static __device__ __forceinline__ void pv(const ps16x8_t& v, const ps16x8_t& pf) {          \
+      asm volatile(MFMA " a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(v), "v"(pf), "n"(OA), "n"(OA + 15));              \
+    }                                                                                                             \
+  };
+MI355_DEF_PMMA_OWN(bf16_t, "v_mfma_f32_32x32x16_bf16")
+MI355_DEF_PMMA_OWN(f16_t, "v_mfma_f32_32x32x16_f16")
+#undef MI355_DEF_PMMA_OWN
+template <int IDX> __device__ __forceinline__ void pm_acc_write(uint32_t v) { asm volatile("v_accvgpr_write_b32 a%c0, %1" :: "n"(IDX), "v"(v)); }
+template <int IDX> __device__ __forceinline__ float pm_acc_read() { float r; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "n"(IDX)); return r; }
+constexpr int kOwnO = 0, kOwnQ = 128;      // accumulator-register map of the hand-owned form
+
 // largest i with cu[i] / block_q + i <= qblock (reference: find_seq_idx in Q-block mode, :32-52)
 __device__ __forceinline__ int find_seq_by_qblock(const int32_t* __restrict__ cu, int num_seqs, int qblock, int block_q) {
   int left = 0, right = num_seqs;
@@ -118,6 +150,8 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
 
   constexpr int KBUF = kTileN * RSK, VBUF = kTileN * RSV, BUF = KBUF + VBUF;   // one stage: K tile then V tile
   extern __shared__ __attribute__((aligned(16))) char smem[];                    // two stages
+  constexpr bool AOWN = D >= 256;          // O^T and Q in hand-owned accumulator registers (see pmma_own)
+  if constexpr (AOWN) asm volatile("" ::: "a255");     // the kernel owns all 256 accumulator registers
 
   const mi355_attn_params& p = a.p;
   const int tid = threadIdx.x;
@@ -286,11 +320,20 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   constexpr bool EARLY_K = D >= 256;
 
   float m_run = -INFINITY, l_run = 0.0f;
-  pf32x16_t o_acc[DBLK];
+  pf32x16_t o_acc[AOWN ? 1 : DBLK];
+  if constexpr (AOWN) {
+    pm_for<16 * DBLK>([&](auto I) { pm_acc_write<kOwnO + decltype(I)::value>(0u); });
+    pm_for<KSTEPS>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      const pu32x4_t w = __builtin_bit_cast(pu32x4_t, qf[ks]);
+      pm_for<4>([&](auto E) { pm_acc_write<kOwnQ + 4 * ks + decltype(E)::value>(w[decltype(E)::value]); });
+    });
+  } else {
 #pragma unroll
-  for (int b = 0; b < DBLK; ++b)
+    for (int b = 0; b < DBLK; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) o_acc[b][r] = 0.0f;
+  }
 
   if (tile_lo < tile_hi) {
     lookup_pages(tile_lo);
@@ -302,8 +345,10 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
 
   // Make the Q fragments' loads retire HERE: otherwise the compiler's in-loop wait for them
   // (needed on the first iteration only) is a vmcnt(0) that also drains every K/V prefetch.
+  if constexpr (!AOWN) {
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
 
   // per-lane offsets of the LDS reads inside a stage
   const int k_rd_off = qr * RSK + half * 16;                                          // + kb*32*RSK + ks*32
@@ -337,8 +382,24 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
       constexpr int KW = D >= 256 ? 4 : (KSTEPS < 8 ? KSTEPS : 8);
       pu32x4_t kf[KW];
 #pragma unroll
-      for (int m = 0; m < KW; ++m) kf[m] = *(const pu32x4_t*)(k_rd + (m / KSTEPS) * 32 * RSK + (m % KSTEPS) * 32);
+      for (int m = 0; m < KW; ++m)
+        kf[m] = AOWN ? *(const pu32x4_t*)(k_rd + (m & 1) * 32 * RSK + (m >> 1) * 32)          // (the hand-owned form alternates the two blocks)
+                     : *(const pu32x4_t*)(k_rd + (m / KSTEPS) * 32 * RSK + (m % KSTEPS) * 32);
       __builtin_amdgcn_sched_group_barrier(0x100, KW, 0);       // DS reads
+      if constexpr (AOWN) {
+        // (asm statements stay in source order: fragment m + KW is requested right behind the instruction that retires
+        // fragment m's registers, KW instructions before it is needed)
+        // the two 32-key blocks' chains ALTERNATE: an accumulate chain runs at the matrix pipe's full rate only with
+        // another instruction between two of its steps (tools/probes/issue_model.hip: distance 2)
+        pm_for<2 * KSTEPS>([&](auto M) __attribute__((always_inline)) {
+          constexpr int m = decltype(M)::value, kb = m & 1, ks = m >> 1;
+          pmma_own<T>::template qk<kOwnQ + 4 * ks>(s_acc[kb], kf[m % KW]);
+          if constexpr (m + KW < 2 * KSTEPS)
+            kf[m % KW] = *(const pu32x4_t*)(k_rd + ((m + KW) & 1) * 32 * RSK + ((m + KW) >> 1) * 32);
+        });
+        // the matrix pipe's results are readable (the compiler does not know these statements are matrix instructions)
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s_acc[0]), "+v"(s_acc[1]));
+      } else
 #pragma unroll
       for (int m = 0; m < 2 * KSTEPS; ++m) {
         const int kb = m / KSTEPS, ks = m % KSTEPS;
@@ -393,6 +454,12 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
       }
       mx = fmaxf(mx, lane_xor32(mx));  // the other half-wave holds the other 32 keys of this query row
       float m_new = fmaxf(m_run, mx);
+      if constexpr (AOWN) {
+        // rescaling O is 128 read-multiply-write round trips through the accumulator registers: the row's reference only
+        // moves when its maximum has grown by more than 2^8 since (P <= 2^8 then: exact in f32 sums, far inside bf16 / f16;
+        // softmax is shift invariant) - the deferral of prefill_dma_kernel
+        if (m_run > -INFINITY && mx <= m_run + 8.0f) m_new = m_run;
+      }
       if (!(m_new > -INFINITY)) m_new = 0.0f;                     // row fully masked so far (:486-489)
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.0f;
@@ -421,10 +488,18 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
       // ---- O^T = alpha * O^T + V^T . P^T -----------------------------------------------------------
       const bool rescale = !__all(alpha == 1.0f);                 // exact: skipped only when no row's max moved
       if (rescale) {
+        if constexpr (AOWN) {
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the previous tile's last P.V results are in their registers
+          pm_for<16 * DBLK>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = kOwnO + decltype(I)::value;
+            pm_acc_write<i>(__builtin_bit_cast(uint32_t, pm_acc_read<i>() * alpha));
+          });
+        } else {
 #pragma unroll
         for (int b = 0; b < DBLK; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o_acc[b][r] *= alpha;
+        }
       }
       // transposed V reads run VW k-steps (a 32-wide output block; half of one at D = 256, for registers) ahead of
       // the MFMAs that consume them
@@ -436,8 +511,20 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
         dst[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4_t*)(va + 8 * RSV));
       };
 #pragma unroll
-      for (int m = 0; m < VW; ++m) read_v_step(m, vt[m]);
+      for (int m = 0; m < VW; ++m) read_v_step(AOWN ? (4 * (m & 1) + (m >> 1)) : m, vt[m]);     // (hand-owned form: blocks 0, 1 alternate)
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * VW, 0);
+      if constexpr (AOWN) {
+        asm volatile("s_nop 1" ::: "memory");                   // VALU-written P -> matrix instruction
+        // step i of the stream: output blocks 2p, 2p + 1 alternate (accumulate chains at distance 2, see above)
+        auto pv_step = [](int i) { const int pr = i >> 3, j = i & 7; return 4 * (2 * pr + (j & 1)) + (j >> 1); };   // -> m = 4 b + sk
+        pm_for<4 * DBLK>([&](auto I) __attribute__((always_inline)) {
+          constexpr int i = decltype(I)::value, pr = i >> 3, j = i & 7, b = 2 * pr + (j & 1), sk = j >> 1;
+          const ps16x4_t v0 = vt[i % VW][0], v1 = vt[i % VW][1];
+          const ps16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          pmma_own<T>::template pv<kOwnO + 16 * b>(vf, pf[sk]);
+          if constexpr (i + VW < 4 * DBLK) read_v_step(pv_step(i + VW), vt[i % VW]);
+        });
+      } else
 #pragma unroll
       for (int m = 0; m < 4 * DBLK; ++m) {
         const ps16x4_t v0 = vt[m % VW][0], v1 = vt[m % VW][1];
@@ -467,18 +554,30 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   // O leaves through LDS as whole rows, 16 bytes per lane, nontemporal (see prefill_dma_kernel's epilogue); the
   // 8-byte pieces of the accumulator layout go out directly only when the output rows are not 16-byte aligned.
   const bool wide_store = (((uintptr_t)out_base & 15) == 0) && (p.out_stride_token % 8 == 0) && (p.out_stride_head % 8 == 0);
+  // register 4 c + i of output block b, wherever O lives
+  auto o_quad = [&](auto B, auto C, float (&o)[4]) __attribute__((always_inline)) {
+    constexpr int b = decltype(B)::value, c = decltype(C)::value;
+    if constexpr (AOWN) {
+      o[0] = pm_acc_read<kOwnO + 16 * b + 4 * c>(); o[1] = pm_acc_read<kOwnO + 16 * b + 4 * c + 1>();
+      o[2] = pm_acc_read<kOwnO + 16 * b + 4 * c + 2>(); o[3] = pm_acc_read<kOwnO + 16 * b + 4 * c + 3>();
+    } else {
+      o[0] = o_acc[b][4 * c]; o[1] = o_acc[b][4 * c + 1]; o[2] = o_acc[b][4 * c + 2]; o[3] = o_acc[b][4 * c + 3];
+    }
+  };
+  if constexpr (AOWN) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");   // the last P.V results are in their registers
   if (wide_store) {
     constexpr int ORS = D * 2 + 16;                      // padded row stride of the parked rows
     constexpr int CPR = D / 8, RPI = 64 / CPR;           // 16-byte chunks per row, rows per store instruction
     char* ost = smem + wave * (32 * ORS);                // every wave is past the last tile's barrier: the stages are idle
-#pragma unroll
-    for (int b = 0; b < DBLK; ++b)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
-                            pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+    pm_for<DBLK>([&](auto B) __attribute__((always_inline)) {
+      pm_for<4>([&](auto C) __attribute__((always_inline)) {
+        constexpr int b = decltype(B)::value, c = decltype(C)::value;
+        float o[4];
+        o_quad(B, C, o);
+        const pu32x2_t w = {pmma<T>::pack2(o[0] * inv, o[1] * inv), pmma<T>::pack2(o[2] * inv, o[3] * inv)};
         *(pu32x2_t*)(ost + qr * ORS + (32 * b + 8 * c + 4 * half) * 2) = w;
-      }
+      });
+    });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const int orow = lane / CPR, och = lane % CPR;
 #pragma unroll
@@ -493,14 +592,15 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
     }
   } else if (row_ok) {
     uint16_t* op = out_base + (int64_t)(q_start + tok_local) * p.out_stride_token + (int64_t)hq * p.out_stride_head + 4 * half;
-#pragma unroll
-    for (int b = 0; b < DBLK; ++b)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const pu32x2_t w = {pmma<T>::pack2(o_acc[b][4 * c + 0] * inv, o_acc[b][4 * c + 1] * inv),
-                            pmma<T>::pack2(o_acc[b][4 * c + 2] * inv, o_acc[b][4 * c + 3] * inv)};
+    pm_for<DBLK>([&](auto B) __attribute__((always_inline)) {
+      pm_for<4>([&](auto C) __attribute__((always_inline)) {
+        constexpr int b = decltype(B)::value, c = decltype(C)::value;
+        float o[4];
+        o_quad(B, C, o);
+        const pu32x2_t w = {pmma<T>::pack2(o[0] * inv, o[1] * inv), pmma<T>::pack2(o[2] * inv, o[3] * inv)};
         if (32 * b + 8 * c + 4 * half < a.d_valid) *(pu32x2_t*)(op + 32 * b + 8 * c) = w;
-      }
+      });
+    });
   }
 }
 
