@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
     }
   };
   auto write_lds = [&](int tile, char* stage) { write_lds_k(stage); write_lds_v(tile, stage); };
-  constexpr bool EARLY_K = D >= 256;
+  // (head size 256 before round 3: K written early so that its 32 staging registers were free during P.V. With O and Q in
+  // accumulator registers there is room, and the early write only cut the loads' flight time to half a tile)
+  constexpr bool EARLY_K = false;
 
   float m_run = -INFINITY, l_run = 0.0f;
   pf32x16_t o_acc[AOWN ? 1 : DBLK];
