@@ -139,8 +139,11 @@ def test_workspace_bytes_of_the_prefill_paths(lib):
     p = _c3_like_params(lib, addr)
     p.num_tokens, p.num_seqs, p.max_seqlen_q, p.max_seqlen_k = 4096, 1, 4096, 4096
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters
-    p.q_dtype = p.kv_dtype = lib.dtype_code(torch.float16)           # f16 stays on the 8-wave kernel: no scratch at all
+    p.q_dtype = p.kv_dtype = lib.dtype_code(torch.float16)           # f16: the same kernel (round 3), the same counters
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters
+    p.alibi_slopes = addr                                             # ALiBi stays on the 8-wave kernel: no scratch at all
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+    p.alibi_slopes = 0
     p.q_dtype = p.kv_dtype = lib.dtype_code(torch.bfloat16)
     # a 512-token chunk against 8192 keys: (512/32 + 1) * 8 = 136 workgroups -> 4 key splits of partial out (bf16) + lse (f32)
     p.num_tokens, p.max_seqlen_q, p.max_seqlen_k = 512, 512, 8192
@@ -154,9 +157,10 @@ def test_workspace_bytes_of_the_prefill_paths(lib):
     p.num_tokens, p.max_seqlen_q, p.max_seqlen_k = 2048, 2048, 32768
     rows = 2048 * 32
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters + 2 * rows * 128 * 2 + 2 * rows * 4
-    # with a sliding window the register-staged kernel serves it: (2048/32 + 1) * 8 = 520 workgroups -> no split
+    # with a sliding window a Q block sees ~1024 + 64 keys whatever the context: no split, the 64-rows-per-wave kernel's
+    # sliding-window form (round 3) and its counters
     p.sliding_window = 1024
-    assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters
     p.sliding_window = 0
     # legacy op: v0 layout (K [nb, Hk, D/8, 16, 8], V [nb, Hk, D, 16]) + linear new keys, 2 sequences, bound 4096 keys:
     # counters, identity block table, K and V scratch of 2 * 256 pages

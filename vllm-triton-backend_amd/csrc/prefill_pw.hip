@@ -430,8 +430,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
   refresh_lane();
   // x / G, x % G, x / BQ for x >= 0: shifts when the divisor is a power of two (every GQA ratio in use), else the division
-  auto div_g = [&](int x) { return sa.g_shift >= 0 ? (x >> sa.g_shift) : x / sa.G; };
-  auto mod_g = [&](int x) { return sa.g_shift >= 0 ? (x & (sa.G - 1)) : x % sa.G; };
+  // x / G and x % G for a row index 0 <= x < 256 (G <= 256): one 24-bit multiply by ceil(2^16 / G) and a shift, branch
+  // free. (As "shift if G is a power of two, else divide" hipcc built a diamond of scalar branches around every call:
+  // the mask of a diagonal tile alone was ~230 instructions and two dozen branches per sub-block.)
+  const unsigned g_inv24 = (65536u + (unsigned)sa.G - 1u) / (unsigned)sa.G;
+  auto div_g = [&](int x) { return (int)(__umul24((unsigned)x, g_inv24) >> 16); };
+  auto mod_g = [&](int x) { return x - div_g(x) * sa.G; };
   auto div_bq = [&](int x) { return sa.bq_shift >= 0 ? (x >> sa.bq_shift) : x / sa.BQ; };
 
   // ---- work items ---------------------------------------------------------------------------------------
@@ -496,6 +500,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           spec_off[i] = __builtin_amdgcn_readfirstlane(min(((i * 4 + wave) << 4) >> sa.page_shift, (int)sa.bt_stride - 1) << 2);
           spec_pg[i] = *(const __attribute__((address_space(4))) int*)(b0 + (uint32_t)spec_off[i]);
         }
+      } else {       // (defined on every path: a value carried from the previous item would have to live through its tile loop)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { spec_off[i] = 0; spec_pg[i] = 0; }
       }
       int seq, q_start, q_len, seq_len;
       const int qr_o = lane_o & 31;
@@ -580,6 +587,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // barrier) when have_idx. false: the list is exhausted
   auto acquire = [&](Item& I, int idx, bool have_idx) -> bool {
     const int items_per_head = sa.num_qblocks * sa.key_splits;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { spec_off[i] = 0; spec_pg[i] = 0; }     // (dead on the "list exhausted" path too: see setup_idx)
     while (true) {
       if (!have_idx) {
         if (dynamic) {             // (an empty item: the next ticket is needed at once)
@@ -603,17 +612,20 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // tiles), -1 = a padding row. Recomputed where it is needed (Q conversion, the mask, the output) rather than kept in
   // registers across the tile loop.
   auto row_lim = [&](const Item& I, int sb) __attribute__((always_inline)) {
-    const int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + (lane_o & 31);
+    int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + (lane_o & 31);
+    asm volatile("" : "+v"(m_row));   // (the quotient below is three instructions: not worth a register held across the item loop)
     const int tok = I.tok0 + div_g(m_row);
     return ((m_row < sa.BQ * sa.G) && (tok < I.q_len)) ? min(I.ctx_len + tok, I.seq_len - 1) : -1;
   };
   // first visible key of the same row under a sliding window (keys j with position - j < window)
   auto row_lo = [&](const Item& I, int sb) __attribute__((always_inline)) {
-    const int m_row = wave * 64 + sb * 16 + (lane_o & 15);
+    int m_row = wave * 64 + sb * 16 + (lane_o & 15);
+    asm volatile("" : "+v"(m_row));
     return I.ctx_len + I.tok0 + div_g(m_row) - sa.window + 1;
   };
   auto row_of = [&](const Item& I, int sb, int& tok_local, int& hq) __attribute__((always_inline)) {
-    const int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + (lane_o & 31);   // M16: sb = 2 x + rt
+    int m_row = M16 ? wave * 64 + sb * 16 + (lane_o & 15) : wave * 64 + sb * 32 + (lane_o & 31);   // M16: sb = 2 x + rt
+    asm volatile("" : "+v"(m_row));
     tok_local = I.tok0 + div_g(m_row);
     hq = head * sa.G + mod_g(m_row);
     return (m_row < sa.BQ * sa.G) && (tok_local < I.q_len);
@@ -1028,12 +1040,16 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     asm volatile("s_nop 7\n\ts_nop 3"
                  : "+v"(S16[0][0][0]), "+v"(S16[0][0][1]), "+v"(S16[0][0][2]), "+v"(S16[0][0][3]),
                    "+v"(S16[0][1][0]), "+v"(S16[0][1][1]), "+v"(S16[0][1][2]), "+v"(S16[0][1][3]));
+    int key0 = t * kPwTile + 4 * g4;        // this lane's first key of key tile 0 (opaque: lane constants folded with it
+    asm volatile("" : "+v"(key0));          // would be hoisted out of the item loop, and there is no register for them)
     sfor<2>([&](auto RT) __attribute__((always_inline)) {
+      const int rlim = row_lim(cur, 2 * x + decltype(RT)::value) - key0;
+      const int rlow = SW && sa.window > 0 ? row_lo(cur, 2 * x + decltype(RT)::value) - key0 : -(1 << 30);
       sfor<4>([&](auto KT) __attribute__((always_inline)) {
         constexpr int rt = decltype(RT)::value, kt = decltype(KT)::value;
-        const int rel = row_lim(cur, 2 * x + rt) - t * kPwTile - 16 * kt - 4 * g4;     // visible: r <= rel
+        const int rel = rlim - 16 * kt;     // visible: r <= rel
         if constexpr (SW) {
-          const int rlo = sa.window > 0 ? row_lo(cur, 2 * x + rt) - t * kPwTile - 16 * kt - 4 * g4 : -1;     // ... and r >= rlo
+          const int rlo = rlow - 16 * kt;     // ... and r >= rlo
 #pragma unroll
           for (int r = 0; r < 4; ++r) S16[0][rt][kt][r] = (r <= rel && r >= rlo) ? S16[0][rt][kt][r] : -INFINITY;
         } else
@@ -1335,7 +1351,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           typedef __attribute__((address_space(1))) wu32x4_t* grow_t;
           auto row_off = [&](int j, uint32_t& tq) {
             const uint32_t m = (uint32_t)(wave * 64 + x * 32 + 4 * j + orow);
-            tq = sa.g_shift >= 0 ? (m >> sa.g_shift) : ((m * g_inv) >> 16);
+            tq = __umul24(m, g_inv) >> 16;
             return tq * st_b + (m - tq * (uint32_t)G) * sh_b + (uint32_t)och * 16u;
           };
           if (__builtin_expect(whole_block, 1)) {
@@ -1393,7 +1409,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         typedef __attribute__((address_space(1))) wu32x4_t* grow_t;
         auto row_off = [&](int j, uint32_t& tq) {
           const uint32_t m = (uint32_t)(wave * 64 + sb * 32 + 4 * j + orow);
-          tq = sa.g_shift >= 0 ? (m >> sa.g_shift) : ((m * g_inv) >> 16);      // token and query head of row m inside the block
+          tq = __umul24(m, g_inv) >> 16;      // token and query head of row m inside the block
           return tq * st_b + (m - tq * (uint32_t)G) * sh_b + (uint32_t)och * 16u;
         };
         if (__builtin_expect(whole_block, 1)) {
