@@ -88,7 +88,7 @@ struct PwArgs {
   int page_shift;  // log2(page_size)
   int key_splits;  // a work item (Q block, KV head, s) attends the s-th even share of its Q block's key tiles (prefill_mfma.hip)
   int num_qblocks; // static upper bound of the Q blocks of the batch (num_tokens / block_q + num_seqs)
-  int g_shift, bq_shift;   // log2 of group / block_q when they are powers of two, else -1 (divisions become shifts)
+  int g_inv, bq_shift;     // ceil(2^16 / group): x / group == (x * g_inv) >> 16 for x < 256; log2 of block_q when it is a power of two, else -1
   int* tickets;    // [2 * num_kv_heads] zero on entry, zero on exit (head of the caller's workspace), or null: static deal
   int slots;       // workgroups per KV head: the grid is slots * num_kv_heads workgroups, each walking several items
   int64_t out_split_stride, lse_split_stride;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     int* tickets;
     int q_st, q_sh, out_st, out_sh;    // elements; the host admits [0, 2^22)
     int64_t lse_st, bt_stride, out_split_stride, lse_split_stride;
-    int num_seqs, key_splits, num_qblocks, slots, G, BQ, g_shift, bq_shift, page_shift, skip_decodes, only_decodes, num_kv_heads;
+    int num_seqs, key_splits, num_qblocks, slots, G, BQ, g_inv, bq_shift, page_shift, skip_decodes, only_decodes, num_kv_heads;
     int window, non_causal;
   };
   int lane_o = lane;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sa.lse_st = kp->p.lse_stride_token; sa.bt_stride = kp->p.block_table_stride;
     sa.out_split_stride = kp->out_split_stride; sa.lse_split_stride = kp->lse_split_stride;
     sa.num_seqs = kp->p.num_seqs; sa.key_splits = kp->key_splits; sa.num_qblocks = kp->num_qblocks; sa.slots = kp->slots;
-    sa.G = kp->group; sa.BQ = kp->block_q; sa.g_shift = kp->g_shift; sa.bq_shift = kp->bq_shift; sa.page_shift = kp->page_shift;
+    sa.G = kp->group; sa.BQ = kp->block_q; sa.g_inv = kp->g_inv; sa.bq_shift = kp->bq_shift; sa.page_shift = kp->page_shift;
     sa.skip_decodes = kp->p.skip_decodes; sa.only_decodes = kp->p.only_decodes; sa.num_kv_heads = kp->p.num_kv_heads;
     sa.window = SW ? kp->p.sliding_window : 0; sa.non_causal = kp->p.non_causal;
   };
@@ -433,9 +433,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // x / G and x % G for a row index 0 <= x < 256 (G <= 256): one 24-bit multiply by ceil(2^16 / G) and a shift, branch
   // free. (As "shift if G is a power of two, else divide" hipcc built a diamond of scalar branches around every call:
   // the mask of a diagonal tile alone was ~230 instructions and two dozen branches per sub-block.)
-  const unsigned g_inv24 = (65536u + (unsigned)sa.G - 1u) / (unsigned)sa.G;
-  auto div_g = [&](int x) { return (int)(__umul24((unsigned)x, g_inv24) >> 16); };
-  auto mod_g = [&](int x) { return x - div_g(x) * sa.G; };
+  auto div_g = [&](int x) { return (int)(__umul24((unsigned)x, (unsigned)sa.g_inv) >> 16); };
+  auto mod_g = [&](int x) { return x - (int)__umul24((unsigned)div_g(x), (unsigned)sa.G); };
   auto div_bq = [&](int x) { return sa.bq_shift >= 0 ? (x >> sa.bq_shift) : x / sa.BQ; };
 
   // ---- work items ---------------------------------------------------------------------------------------
@@ -805,15 +804,19 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     if (zero_o) sfor<128>([&](auto IC) { acc_zero<kAO + decltype(IC)::value>(); });
     // the item's query rows have landed (and everything older: its first tiles, the previous item's output)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // One row's registers share one scale, 0 for a padding row (its raw words are the sequence's last query row: x 0
+    // zeroes them, and were that row not finite, the NaN stays in a row that is never stored). Straight-line: with
+    // "valid ? read : 0" per register hipcc wrapped every one of the 64 reads in an exec-mask branch - 940 instructions,
+    // ~1.8 us of every seam at one wave per SIMD; 6 per register now.
     sfor<2>([&](auto SB) {
-      sfor<8>([&](auto KS) {
-        // (M16: registers kAQ + 32 x + 16 rt + 4 ks are Q'[x][rt][ks]: with ks8 = 4 rt + ks the same index arithmetic)
-        constexpr int sb = decltype(SB)::value, ks = decltype(KS)::value;
-        const bool valid = row_lim(I, M16 ? 2 * sb + (ks >> 2) : sb) >= 0;
-        sfor<4>([&](auto E) {
-          constexpr int e = decltype(E)::value, idx = kAQ + 32 * sb + 4 * ks + e;
-          const uint32_t v = valid ? acc_read_u32<idx>() : 0u;
-          acc_write<idx>(pw_pack<T>(pw_lo<T>(v) * scale2, pw_hi<T>(v) * scale2));
+      sfor<(M16 ? 2 : 1)>([&](auto RT) {
+        // (M16: registers kAQ + 32 x + 16 rt + 4 ks are Q'[x][rt][ks])
+        constexpr int sb = decltype(SB)::value, rt = decltype(RT)::value, n = M16 ? 16 : 32;
+        const float sc = row_lim(I, M16 ? 2 * sb + rt : sb) >= 0 ? scale2 : 0.0f;
+        sfor<n>([&](auto E) {
+          constexpr int idx = kAQ + 32 * sb + n * rt + decltype(E)::value;
+          const uint32_t v = acc_read_u32<idx>();
+          acc_write<idx>(pw_pack<T>(pw_lo<T>(v) * sc, pw_hi<T>(v) * sc));
         });
       });
     });
@@ -1291,7 +1294,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // four first): the seam hangs the next item's loads there.
   auto epilogue = [&](const Item& I, auto hook) __attribute__((always_inline)) {
     const int G = sa.G;
-    const uint32_t g_inv = (65536u + (uint32_t)G - 1u) / (uint32_t)G;   // m / G == (m * g_inv) >> 16 for m < 256, G <= 256
+    const uint32_t g_inv = (uint32_t)sa.g_inv;   // m / G == (m * g_inv) >> 16 for m < 256, G <= 256
     const int lane = lane_o, qr = lane_o & 31, half = lane_o >> 5;
     char* ost = smem + kLdsO + wave * (32 * kPwORS);
     const bool wide_store = __builtin_amdgcn_readfirstlane((int)((((uintptr_t)I.out_base & 15) == 0) && (sa.out_st % 8 == 0) && (sa.out_sh % 8 == 0))) != 0;
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           const bool row_ok = row_of(I, 2 * x + rt, tok_local, hq);
           if (I.lse_base && row_ok && g4o == 0)
             I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? (__builtin_amdgcn_logf(l) - R16[x][rt][0]) * 0.6931471805599453f : -INFINITY;   // P = 2^(score + R)
-          const float inv = (row_ok && l > 0.0f) ? 1.0f / l : 0.0f;
+          const float inv = (row_ok && l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;   // (1 ulp: the output is rounded to 16 bits next)
           l2[rt] = l; ok2[rt] = row_ok;
           if (__builtin_expect(wide_store, 1)) {
             tile_out(RT, inv, [&](auto DB, wu32x2_t w2) __attribute__((always_inline)) {
@@ -1352,7 +1355,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           auto row_off = [&](int j, uint32_t& tq) {
             const uint32_t m = (uint32_t)(wave * 64 + x * 32 + 4 * j + orow);
             tq = __umul24(m, g_inv) >> 16;
-            return tq * st_b + (m - tq * (uint32_t)G) * sh_b + (uint32_t)och * 16u;
+            return __umul24(tq, st_b) + __umul24(m - __umul24(tq, (uint32_t)G), sh_b) + (uint32_t)och * 16u;   // (full-rate 24-bit multiplies: strides are below 2^22 elements)
           };
           if (__builtin_expect(whole_block, 1)) {
 #pragma unroll
@@ -1387,7 +1390,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       const bool row_ok = row_of(I, sb, tok_local, hq);
       if (I.lse_base && row_ok && half == 0)    // P = exp2(score): ln of the sum is the lse
         I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? __builtin_amdgcn_logf(l) * 0.6931471805599453f : -INFINITY;
-      const float inv = (row_ok && l > 0.0f) ? 1.0f / l : 0.0f;
+      const float inv = (row_ok && l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;   // (1 ulp: the output is rounded to 16 bits next)
       float amax = 0.0f;
       if (__builtin_expect(wide_store, 1)) {
         // the sub-block leaves as whole 256-byte rows, 16 bytes per lane (a lane's own 8-byte pieces touch 32 rows per
@@ -1410,7 +1413,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         auto row_off = [&](int j, uint32_t& tq) {
           const uint32_t m = (uint32_t)(wave * 64 + sb * 32 + 4 * j + orow);
           tq = __umul24(m, g_inv) >> 16;      // token and query head of row m inside the block
-          return tq * st_b + (m - tq * (uint32_t)G) * sh_b + (uint32_t)och * 16u;
+          return __umul24(tq, st_b) + __umul24(m - __umul24(tq, (uint32_t)G), sh_b) + (uint32_t)och * 16u;   // (full-rate 24-bit multiplies: strides are below 2^22 elements)
         };
         if (__builtin_expect(whole_block, 1)) {
 #pragma unroll
@@ -1634,7 +1637,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = kPwRows / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
-  a.g_shift = (a.group & (a.group - 1)) == 0 ? __builtin_ctz((unsigned)a.group) : -1;
+  a.g_inv = (65536 + a.group - 1) / a.group;
   a.bq_shift = (a.block_q & (a.block_q - 1)) == 0 ? __builtin_ctz((unsigned)a.block_q) : -1;
   a.key_splits = key_splits;
   a.out_split_stride = out_split_stride;
