@@ -58,6 +58,7 @@ namespace mi355 {
 
 typedef __attribute__((ext_vector_type(16))) float wf32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int wu32x4_t;
+typedef __attribute__((ext_vector_type(4))) float wf32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int wu32x2_t;
 
 constexpr int kPwTile = 64;          // keys per KV tile
@@ -113,6 +114,23 @@ __device__ __forceinline__ void a_exp2x2_ho(float r0, float r1, float x0, float 
   asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" :: "v"(r0), "v"(r1), "v"(x0), "v"(x1));
 }
 __device__ __forceinline__ void a_exp_ho(float r, float x) { asm volatile("v_exp_f32 %0, %1" :: "v"(r), "v"(x)); }
+// Four scores of one lane (registers r = 0..3 of a 16x16 score tile = four consecutive keys) against a bound, hand-owned
+// like the forms above. HI: masked (-> ninf) where r > c; LO: where r < c. Three mask registers in rotation put two
+// instructions between every compare and the select that reads it (a VALU-written SGPR wants two wait states before a
+// VALU reads it: the compiler's own cmp / s_nop 1 / cndmask per element was 3 issue slots, this is 2).
+template <bool LO> __device__ __forceinline__ void pw_mask_quad_ho(const wf32x4_t& sq, int c, float ninf) {
+  unsigned long long m0, m1;
+  if constexpr (!LO)
+    asm volatile("v_cmp_gt_i32 %0, 0, %6\n\tv_cmp_gt_i32 %1, 1, %6\n\tv_cmp_gt_i32 vcc, 2, %6\n\t"
+                 "v_cndmask_b32 %2, %2, %7, %0\n\tv_cmp_gt_i32 %0, 3, %6\n\tv_cndmask_b32 %3, %3, %7, %1\n\t"
+                 "v_cndmask_b32 %4, %4, %7, vcc\n\tv_cndmask_b32 %5, %5, %7, %0"
+                 : "=&s"(m0), "=&s"(m1) : "v"(sq[0]), "v"(sq[1]), "v"(sq[2]), "v"(sq[3]), "v"(c), "v"(ninf) : "vcc");
+  else
+    asm volatile("v_cmp_lt_i32 %0, 0, %6\n\tv_cmp_lt_i32 %1, 1, %6\n\tv_cmp_lt_i32 vcc, 2, %6\n\t"
+                 "v_cndmask_b32 %2, %2, %7, %0\n\tv_cmp_lt_i32 %0, 3, %6\n\tv_cndmask_b32 %3, %3, %7, %1\n\t"
+                 "v_cndmask_b32 %4, %4, %7, vcc\n\tv_cndmask_b32 %5, %5, %7, %0"
+                 : "=&s"(m0), "=&s"(m1) : "v"(sq[0]), "v"(sq[1]), "v"(sq[2]), "v"(sq[3]), "v"(c), "v"(ninf) : "vcc");
+}
 // instruction q (0..47) of a sub-block's exponential / pack stream in the 16x16x32 form: kind 0 / 1 = exponential of the
 // word's first / second score, 2 = pack; j = the word
 struct PwEOp { int kind, j; };
@@ -227,7 +245,6 @@ MI355_DEF_PW_OPS(bf16_t, "v_mfma_f32_32x32x16_bf16", "v_cvt_pk_bf16_f32")
 #undef MI355_DEF_PW_OPS
 
 // The same contractions on v_mfma_f32_16x16x32_{bf16,f16} (M16 instantiation of the kernel): 4-register accumulators.
-typedef __attribute__((ext_vector_type(4))) float wf32x4_t;
 template <typename T> struct pw_ops16;
 #define MI355_DEF_PW_OPS16(TAG, MFMA, CVT, ONES)                                                                    \
   template <> struct pw_ops16<TAG> {                                                                              \
@@ -1045,21 +1062,34 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
                    "+v"(S16[0][1][0]), "+v"(S16[0][1][1]), "+v"(S16[0][1][2]), "+v"(S16[0][1][3]));
     int key0 = t * kPwTile + 4 * g4;        // this lane's first key of key tile 0 (opaque: lane constants folded with it
     asm volatile("" : "+v"(key0));          // would be hoisted out of the item loop, and there is no register for them)
-    sfor<2>([&](auto RT) __attribute__((always_inline)) {
-      const int rlim = row_lim(cur, 2 * x + decltype(RT)::value) - key0;
-      const int rlow = SW && sa.window > 0 ? row_lo(cur, 2 * x + decltype(RT)::value) - key0 : -(1 << 30);
-      sfor<4>([&](auto KT) __attribute__((always_inline)) {
-        constexpr int rt = decltype(RT)::value, kt = decltype(KT)::value;
-        const int rel = rlim - 16 * kt;     // visible: r <= rel
-        if constexpr (SW) {
-          const int rlo = rlow - 16 * kt;     // ... and r >= rlo
-#pragma unroll
-          for (int r = 0; r < 4; ++r) S16[0][rt][kt][r] = (r <= rel && r >= rlo) ? S16[0][rt][kt][r] : -INFINITY;
-        } else
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S16[0][rt][kt][r] = (r <= rel) ? S16[0][rt][kt][r] : -INFINITY;
+    float ninf = -INFINITY;
+    asm volatile("" : "+v"(ninf));
+    // which bound this tile crosses for the wave (the two terms of need_mask): the causal diagonal / the sequence's end,
+    // or - sliding window - the lower edge; a tile rarely crosses both
+    const bool need_hi = !SW || (t * kPwTile + kPwTile - 1 > cur.ctx_len + cur.w_tok_lo) || (t * kPwTile + kPwTile > cur.seq_len);
+    const bool need_lo = SW && sa.window > 0 && t * kPwTile < cur.ctx_len + cur.w_tok_hi - sa.window + 1;
+    if (need_hi) {
+      sfor<2>([&](auto RT) __attribute__((always_inline)) {
+        constexpr int rt = decltype(RT)::value;
+        const int rlim = row_lim(cur, 2 * x + rt) - key0;        // visible: r <= rlim - 16 kt
+        sfor<4>([&](auto KT) __attribute__((always_inline)) {
+          constexpr int kt = decltype(KT)::value;
+          pw_mask_quad_ho<false>(S16[0][rt][kt], rlim - 16 * kt, ninf);
+        });
       });
-    });
+    }
+    if constexpr (SW) {
+      if (need_lo) {
+        sfor<2>([&](auto RT) __attribute__((always_inline)) {
+          constexpr int rt = decltype(RT)::value;
+          const int rlow = row_lo(cur, 2 * x + rt) - key0;       // ... and r >= rlow - 16 kt
+          sfor<4>([&](auto KT) __attribute__((always_inline)) {
+            constexpr int kt = decltype(KT)::value;
+            pw_mask_quad_ho<true>(S16[0][rt][kt], rlow - 16 * kt, ninf);
+          });
+        });
+      }
+    }
   };
   // MFMA g (0..31) of O_x += V^T.P_x^T: d tile g >> 2, 32-key block (g >> 1) & 1, row tile g & 1
   auto pv16 = [&](auto X, auto GC) __attribute__((always_inline)) {
