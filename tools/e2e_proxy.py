@@ -172,7 +172,8 @@ def main():
             cum_wall_s += wall * k
             done = target
             results.append((target, cum_gpu_us, cum_wall_s))
-    print(f"decode step: {L} layers per replay, ONE launch per layer (kernel: {decode_kernel}), metadata copied H2D per step")
+    print(f"decode step: {L} layers per replay, one call per layer with the cache write fused into the decode launch (kernel: {decode_kernel}; "
+          f"a plan with more splits than the in-kernel merge takes adds the merge launch), metadata copied H2D per step")
     print(f"{'out':>6} {'kv at end':>9} {'attention total ms':>19} {'incl. prefill ms':>17} {'us / token':>11} {'us / token / layer':>19} {'node floor':>11} {'host wall ms':>13}")
     for target, gpu_us, wall_s in results:
         per_tok = gpu_us / target

@@ -65,6 +65,29 @@ __global__ __launch_bounds__(256) void cache_write_elem_kernel(const CacheArgs a
   }
 }
 
+// 16-bit source -> fp8 cache, contiguous head rows: one lane quantises 16 elements of K and of V (two 16-byte loads,
+// one 16-byte store each; the element kernel above stores single bytes: 4096 tokens took it ~40 us)
+template <typename ST, typename CT>
+__global__ __launch_bounds__(256) void cache_write_fp8_vec_kernel(const CacheArgs a) {
+  const mi355_cache_params& p = a.p;
+  const int ppt = p.num_kv_heads * (p.head_size / 16);          // pieces per token
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = (int)(gi / ppt), piece = (int)(gi % ppt);
+  if (t >= p.num_tokens) return;
+  const int64_t slot = slot_of(p, t);
+  if (slot < 0) return;
+  const int64_t page = slot / p.page_size, off = slot % p.page_size;
+  const int h = piece / (p.head_size / 16), c = piece % (p.head_size / 16);
+  const float k_div = p.k_scale ? p.k_scale[0] : 1.0f, v_div = p.v_scale ? p.v_scale[0] : 1.0f;
+  const uint16_t* ks = (const uint16_t*)p.key + (int64_t)t * p.key_stride_token + (int64_t)h * p.key_stride_head + c * 16;
+  const uint16_t* vs = (const uint16_t*)p.value + (int64_t)t * p.value_stride_token + (int64_t)h * p.value_stride_head + c * 16;
+  const cw_u32x4_t k0 = *(const cw_u32x4_t*)ks, k1 = *(const cw_u32x4_t*)(ks + 8), v0 = *(const cw_u32x4_t*)vs, v1 = *(const cw_u32x4_t*)(vs + 8);
+  uint8_t* kd = (uint8_t*)p.k_cache + page * p.k_stride_page + off * p.k_stride_slot + (int64_t)h * p.k_stride_head + c * 16;
+  uint8_t* vd = (uint8_t*)p.v_cache + page * p.v_stride_page + off * p.v_stride_slot + (int64_t)h * p.v_stride_head + c * 16;
+  *(cw_u32x4_t*)kd = quantise_fp8x16<ST, CT>(k0, k1, k_div);
+  *(cw_u32x4_t*)vd = quantise_fp8x16<ST, CT>(v0, v1, v_div);
+}
+
 template <typename ST>
 static int launch_src(const mi355_cache_params& p, hipStream_t stream) {
   CacheArgs a{p};
@@ -97,6 +120,27 @@ int launch_cache_write(const mi355_cache_params& p, hipStream_t stream) {
     CacheArgs a{p};
     hipLaunchKernelGGL(cache_write_vec16_kernel, dim3(p.num_tokens), dim3(256), 0, stream, a);
     return check_hip(hipGetLastError(), "cache_write_vec16 launch");
+  }
+  const bool fp8_cache = p.cache_dtype == MI355_FP8_E4M3 || p.cache_dtype == MI355_FP8_E5M2;
+  const bool fp8_vec_ok = two_byte && fp8_cache && p.head_size % 16 == 0 &&
+                          aligned16(p.key) && aligned16(p.value) && aligned16(p.k_cache) && aligned16(p.v_cache) &&
+                          p.key_stride_token % 8 == 0 && p.key_stride_head % 8 == 0 &&
+                          p.value_stride_token % 8 == 0 && p.value_stride_head % 8 == 0 &&
+                          p.k_stride_page % 16 == 0 && p.k_stride_slot % 16 == 0 && p.k_stride_head % 16 == 0 &&
+                          p.v_stride_page % 16 == 0 && p.v_stride_slot % 16 == 0 && p.v_stride_head % 16 == 0;
+  if (fp8_vec_ok) {
+    CacheArgs a{p};
+    const int64_t pieces = (int64_t)p.num_tokens * p.num_kv_heads * (p.head_size / 16);
+    const dim3 grid((unsigned)((pieces + 255) / 256)), block(256);
+    const bool e4 = p.cache_dtype == MI355_FP8_E4M3;
+    if (p.src_dtype == MI355_BF16) {
+      if (e4) hipLaunchKernelGGL((cache_write_fp8_vec_kernel<bf16_t, e4m3_t>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((cache_write_fp8_vec_kernel<bf16_t, e5m2_t>), grid, block, 0, stream, a);
+    } else {
+      if (e4) hipLaunchKernelGGL((cache_write_fp8_vec_kernel<f16_t, e4m3_t>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((cache_write_fp8_vec_kernel<f16_t, e5m2_t>), grid, block, 0, stream, a);
+    }
+    return check_hip(hipGetLastError(), "cache_write_fp8_vec launch");
   }
   switch (p.src_dtype) {
     case MI355_F32: return launch_src<f32_t>(p, stream);

@@ -100,30 +100,7 @@ __device__ __forceinline__ void widen_fp8x16(u32x4_t in, u32x4_t& lo, u32x4_t& h
   hi = u32x4_t{o[4], o[5], o[6], o[7]};
 }
 
-// 16 values of the query's 16-bit type (two 16-byte pieces) -> 16 fp8 values: the quantising store of
-// reshape_and_cache_flash, sat_fp8(x / scale) with the same software encoder (cache_write.hip), bit for bit
-template <typename T, typename KVT>
-__device__ __forceinline__ u32x4_t quantise_fp8x16(u32x4_t lo, u32x4_t hi, float scale) {
-  u32x4_t out;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    uint32_t word = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = 4 * w + e;                       // element 0 .. 15
-      const uint32_t src = idx < 8 ? lo[idx >> 1] : hi[(idx - 8) >> 1];
-      const uint16_t bits = (uint16_t)((idx & 1) ? (src >> 16) : (src & 0xffff));
-      float x;
-      if constexpr (__is_same(T, bf16_t)) x = bf16_to_f32(bits); else x = f16_to_f32(bits);
-      x /= scale;
-      uint8_t q;
-      if constexpr (__is_same(KVT, e4m3_t)) q = f32_to_e4m3_sat(x); else q = f32_to_e5m2_sat(x);
-      word |= (uint32_t)q << (8 * e);
-    }
-    out[w] = word;
-  }
-  return out;
-}
+// (the quantising store of the fused cache write: quantise_fp8x16, common.h)
 
 // max / sum over the four lanes {g, g+16, g+32, g+48}
 __device__ __forceinline__ float max_over_lane_groups(float v) {
