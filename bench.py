@@ -383,8 +383,8 @@ def main():
                            "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
                 "roofline": roofline("mfma", pf["w"]["flops"], MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12, pf["w"], pf, K, {
                     "algorithmic_flops_per_launch": pf["w"]["flops"],
-                    "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.1-2.35 GHz (in-kernel clock, "
-                            "tools/pw_clock.py, profiles/r02/pw_clock.log)"}),
+                    "note": "peak = nominal dense bf16 MFMA rate (2.4 GHz); under this kernel the chip holds ~2.1-2.3 GHz (in-kernel clock: 2.22 GHz "
+                            "median in the tile loop, tools/pw_clock.py, profiles/r03/pw_clock.log)"}),
             }
 
         def decode_leg(res, label, cfg):
