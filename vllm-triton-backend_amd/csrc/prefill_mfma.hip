@@ -1453,8 +1453,8 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, co
   return rc;
 }
 
-// Whether launch_prefill hands the call to prefill_pw_kernel (prefill_pw.hip): bf16, D = 128, plain, 16-bit cache, and
-// either >= 2048 keys or a key-split plan on the wide kernel. MI355_PREFILL=pw | d8 | d4 | v1 pins a kernel (measurements).
+// Whether launch_prefill hands the call to prefill_pw_kernel (prefill_pw.hip): bf16 or f16, D = 128, no soft-cap / ALiBi
+// (a sliding window is served), 16-bit cache, and either >= 2048 keys or a key-split plan on the wide kernel. MI355_PREFILL=pw | d8 | d4 | v1 pins a kernel (measurements).
 bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
   static const char* variant = getenv("MI355_PREFILL");
   const bool v1 = variant && variant[0] == 'v' && variant[1] == '1';

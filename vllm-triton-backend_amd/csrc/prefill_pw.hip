@@ -1,7 +1,9 @@
 // prefill_pw_kernel: the D = 128 prefill fast path. Four waves, 64 query rows each, one wave per SIMD.
 //
-// Replaces kernel_unified_attention_2d (LIB/kernels/triton_unified_attention.py:275-523) for the plain
-// (no soft-cap / ALiBi / window) 16-bit case; same semantics as prefill_mfma.hip's kernels.
+// Replaces kernel_unified_attention_2d (LIB/kernels/triton_unified_attention.py:275-523) for the 16-bit case
+// without soft-cap / ALiBi: bf16 or f16, with or without a sliding window (:474-479), causal or - for
+// prefill_flash_attention(causal=False) - not; same semantics as prefill_mfma.hip's kernels. An fp8 cache reaches it
+// through the dequantising pass of repack.hip.
 //
 // Why this shape. prefill_dma_kernel (eight waves of 32 rows, two per SIMD) issues 169 VALU + 106 SALU + 50 LDS
 // instructions per 32 MFMAs and keeps the matrix pipes 43 % busy. Here
@@ -25,21 +27,27 @@
 //     nor rescaling are computed per tile. What a running maximum protects against - P or a sum leaving the range
 //     of the format - is CHECKED once per row when the block is done (2^-64 <= l <= 2^100, O finite); a row that
 //     fails (scores beyond +-90 or so in log2 units: not attention as models produce it) is computed again by a
-//     slow, plain online-softmax routine in the same launch (pw_row_fallback). f16 (P <= 65504) cannot do this and
-//     stays on prefill_dma_kernel.
+//     slow, plain online-softmax routine in the same launch (pw_row_fallback).
+//     (Round 3, 16x16x32 form: the reference is PER ROW - minus the row's largest score over its first sixteen keys, taken
+//     once per item by sixteen matrix instructions (set_references) and fed to every score chain as its C operand - so a
+//     row's P stays near 1 whatever its scores' level; that is what lets f16 (P <= 65504) run here, with a margin of 2^6
+//     and tighter range checks, and what makes the fallback a matter of rows whose scores RISE by more than the format's
+//     range after their first sixteen keys.)
 //   * the tile loop has two forms: STEADY iterations (tile unmasked for the wave, the groups it fetches for the next
 //     tiles whole) carry no mask path and no tail handling and put their scalar address arithmetic behind the first
 //     MFMAs; general iterations do the rest (a Q block's last tiles, short sequences).
-//   * a workgroup walks SEVERAL work items when the batch is one sequence (about one workgroup per CU): the next
+//   * a workgroup walks SEVERAL work items (about one workgroup per CU; dealt statically for one sequence, by ticket
+//     counters in the caller's workspace for several): the next
 //     item's query rows and first K/V tiles are requested before the current item's output is normalised and stored,
 //     so that chain of round trips runs beside the epilogue instead of in front of an idle CU. Everything the per-item
 //     code needs is re-derived per item from opaque copies of the lane index and the kernarg pointer: the tile loop has
 //     no register to spare for values hoisted out of the item loop (tools/isa_audit.py must report no compiler
 //     accumulator-register or scratch use).
 //
-//   * TWO instantiations. The text above describes the 32x32x16 one (M16 = false: MFMA orientation, in-register softmax
-//     layout and LDS swizzles of prefill_dma_kernel, prefill_mfma.hip). The product is M16 = true: both contractions on
-//     v_mfma_f32_16x16x32_bf16 - the chip runs this kernel at its power limit and holds a higher clock under that shape -
+//   * FIVE instantiations <T, M16, SW>. The text above describes the 32x32x16 one (<bf16, false, false>: MFMA orientation,
+//     in-register softmax layout and LDS swizzles of prefill_dma_kernel, prefill_mfma.hip; kept for A/B). The product is
+//     M16 = true, for bf16 and f16, each with (SW) and without the sliding-window mask: both contractions on
+//     v_mfma_f32_16x16x32_{bf16,f16} - the chip runs this kernel at its power limit and holds a higher clock under that shape -
 //     with what its doubled matrix-instruction count asks for: the row sums on the matrix pipe (l += 1.P^T), the
 //     exponentials dealt ONE per 16-cycle gap from the moment a sub-block's first score tile is done, LDS-DMA split over
 //     two segments, a V swizzle that matches its transposed reads. One wave per SIMD pays ~4 cycles of issue for every
