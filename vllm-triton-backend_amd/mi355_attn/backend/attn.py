@@ -88,71 +88,54 @@ class MI355AttentionMetadataBuilder(AttentionMetadataBuilder[MI355AttentionMetad
         attn_metadata.seq_lens.fill_(1)
         return attn_metadata
 
+    # ---- the three host-side pieces of a step's metadata ---------------------------------------------------------
+    def _length_stats(self, n_seqs: int):
+        """(max, mean) of the step's key lengths and the mean query length, from the runner's numpy mirrors: host
+        integers only, the kernels' split plans are functions of them (no device read-back)."""
+        lens = self.runner.seq_lens_np[:n_seqs]
+        return int(lens.max()), int(lens.mean()), int(self.runner.query_start_loc_np[n_seqs] / n_seqs)
+
+    def _stage_slot_mapping(self, n_tokens: int) -> torch.Tensor:
+        """This step's slots to the device; every row behind them becomes -1, which the cache write - separate or fused
+        into the decode launch - skips (a captured graph is replayed with padded rows; reference: triton_attn.py:149-151)."""
+        table = self.block_table
+        table.slot_mapping[:n_tokens].copy_(table.slot_mapping_cpu[:n_tokens], non_blocking=True)
+        table.slot_mapping[n_tokens:].fill_(-1)
+        return table.slot_mapping[:n_tokens]
+
+    def _local_window_metadata(self, n_seqs: int, pages: torch.Tensor):
+        """Chunked-local (iRoPE) layers attend inside fixed windows: vLLM's helper rewrites the batch into one virtual
+        sequence per (request, window), and the kernels run on that batch unchanged (reference: triton_attn.py:157-190)."""
+        chunk = getattr(self.runner, "attention_chunk_size", None)
+        if chunk is None:
+            return None
+        if make_local_attention_virtual_batches is None:
+            raise NotImplementedError("local (chunked) attention needs vLLM's make_local_attention_virtual_batches")
+        q_lens, q_starts, k_lens, virtual_pages = make_local_attention_virtual_batches(
+            chunk, self.runner.query_start_loc_np[: n_seqs + 1], self.runner.seq_lens_np[:n_seqs], pages, self.block_size)
+        count = max(len(k_lens), 1)
+        to_dev = lambda a: torch.from_numpy(a).to(self.runner.device, non_blocking=True)  # noqa: E731
+        return MI355AttentionMetadata.LocalAttentionMetadata(
+            local_query_start_loc=to_dev(q_starts), local_seqused_k=to_dev(k_lens), local_block_table=virtual_pages,
+            local_max_query_len=int(q_lens.max()), local_max_seq_len=int(k_lens.max()),
+            local_avg_query_len=int(q_lens.sum() / count), local_avg_seq_len=int(k_lens.sum() / count),
+            local_scheduler_metadata=None)
+
     def build(self, common_prefix_len: int, common_attn_metadata: CommonAttentionMetadata) -> MI355AttentionMetadata:
-        num_reqs = common_attn_metadata.num_reqs
-        num_actual_tokens = common_attn_metadata.num_actual_tokens
-        max_query_len = common_attn_metadata.max_query_len
-
-        max_seq_len = int(self.runner.seq_lens_np[:num_reqs].max())
-        query_start_loc = common_attn_metadata.query_start_loc
-        seq_lens = common_attn_metadata.seq_lens
-        block_table = self.block_table
-        block_table_tensor = block_table.get_device_tensor()[:num_reqs]
-
-        avg_seq_len = int(self.runner.seq_lens_np[:num_reqs].mean())
-        avg_query_len = int(self.runner.query_start_loc_np[num_reqs] / num_reqs)
-
-        block_table.slot_mapping[:num_actual_tokens].copy_(block_table.slot_mapping_cpu[:num_actual_tokens], non_blocking=True)
-        # padding slots = -1: skipped by reshape_and_cache_flash (needed in full-graph mode, :149-151)
-        block_table.slot_mapping[num_actual_tokens:].fill_(-1)
-        slot_mapping = block_table.slot_mapping[:num_actual_tokens]
-
-        local_attn_metadata = None
-        if getattr(self.runner, "attention_chunk_size", None) is not None:
-            if make_local_attention_virtual_batches is None:
-                raise NotImplementedError("local (chunked) attention needs vLLM's make_local_attention_virtual_batches")
-            seqlens_q_local_np, virt_q_cu_seqlens_np, virt_k_seqlens_np, virt_block_table_tensor = make_local_attention_virtual_batches(
-                self.runner.attention_chunk_size,
-                self.runner.query_start_loc_np[: num_reqs + 1],
-                self.runner.seq_lens_np[:num_reqs],
-                block_table_tensor,
-                self.block_size,
-            )
-            n_virt = len(virt_k_seqlens_np)
-            local_attn_metadata = MI355AttentionMetadata.LocalAttentionMetadata(
-                local_query_start_loc=torch.from_numpy(virt_q_cu_seqlens_np).to(self.runner.device, non_blocking=True),
-                local_seqused_k=torch.from_numpy(virt_k_seqlens_np).to(self.runner.device, non_blocking=True),
-                local_block_table=virt_block_table_tensor,
-                local_max_query_len=int(seqlens_q_local_np.max()),
-                local_max_seq_len=int(virt_k_seqlens_np.max()),
-                local_avg_query_len=int(seqlens_q_local_np.sum() / max(n_virt, 1)),
-                local_avg_seq_len=int(virt_k_seqlens_np.sum() / max(n_virt, 1)),
-                local_scheduler_metadata=None,
-            )
-
-        # cascade attention is off for this backend (use_cascade_attention -> False, triton_attn.py:279-281): vLLM never
-        # passes a common prefix, and the cascade tensors of the metadata stay None
-        use_cascade = False
-        cu_prefix_query_lens = prefix_kv_lens = suffix_kv_lens = None
-
+        """One step's metadata (reference: TritonAttentionMetadataBuilder.build, triton_attn.py:130-227). Cascade attention
+        is off for this backend (use_cascade_attention -> False, :279-281): vLLM never passes a common prefix and the
+        cascade tensors stay None."""
+        cm = common_attn_metadata
+        n_seqs, n_tokens = cm.num_reqs, cm.num_actual_tokens
+        longest, mean_keys, mean_queries = self._length_stats(n_seqs)
+        pages = self.block_table.get_device_tensor()[:n_seqs]
         return MI355AttentionMetadata(
-            num_actual_tokens=num_actual_tokens,
-            max_query_len=max_query_len,
-            query_start_loc=query_start_loc,
-            max_seq_len=max_seq_len,
-            seq_lens=seq_lens,
-            block_table=block_table_tensor,
-            slot_mapping=slot_mapping,
-            use_cascade=use_cascade,
-            common_prefix_len=common_prefix_len,
-            cu_prefix_query_lens=cu_prefix_query_lens,
-            prefix_kv_lens=prefix_kv_lens,
-            suffix_kv_lens=suffix_kv_lens,
-            local_attn_metadata=local_attn_metadata,
-            prefix_scheduler_metadata=None,
-            avg_query_len=avg_query_len,
-            avg_seq_len=avg_seq_len,
-        )
+            num_actual_tokens=n_tokens, max_query_len=cm.max_query_len, query_start_loc=cm.query_start_loc,
+            max_seq_len=longest, seq_lens=cm.seq_lens, block_table=pages, slot_mapping=self._stage_slot_mapping(n_tokens),
+            use_cascade=False, common_prefix_len=common_prefix_len,
+            cu_prefix_query_lens=None, prefix_kv_lens=None, suffix_kv_lens=None,
+            local_attn_metadata=self._local_window_metadata(n_seqs, pages), prefix_scheduler_metadata=None,
+            avg_query_len=mean_queries, avg_seq_len=mean_keys)
 
     def can_run_in_cudagraph(self, common_attn_metadata: CommonAttentionMetadata) -> bool:
         return True  # static launch grids, caller-owned workspace, no host sync
