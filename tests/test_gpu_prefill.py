@@ -1,6 +1,7 @@
 """-m gpu: MFMA prefill kernel vs the CPU oracle on seeded inputs, plus properties at BASELINE C2 size."""
 
 import math
+import os
 
 import pytest
 import torch
@@ -382,6 +383,38 @@ def test_prefill_sliding_window_on_the_64_rows_per_wave_kernel(dtype, window):
     torch.testing.assert_close(lse.cpu(), ref_lse.float(), atol=2e-2, rtol=1e-3)
     out9, _ = gpu_util.run_unified(d, inp["scale"], window=window, force=9)
     torch.testing.assert_close(out.float(), out9.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("hq,hk", [(6, 2), (10, 2), (7, 1), (24, 2)])
+@pytest.mark.parametrize("window", [0, 333])
+def test_prefill_64_rows_per_wave_kernel_with_groups_that_are_no_power_of_two(hq, hk, window):
+    """Rows of a Q block are (token, head-in-group) pairs: the kernel turns a row index into its token with one 24-bit
+    multiply by ceil(2^16 / G) (exact for rows < 256, G <= 256; checked exhaustively on the host below). G = 3, 5, 7, 12:
+    Q blocks of 85, 51, 36 and 21 tokens - never a whole number of 64-key tiles - with and without a sliding window,
+    ragged lengths, a decode row in the batch."""
+    import gpu_util
+
+    for G in range(1, 257):
+        inv = (65536 + G - 1) // G
+        assert all(((x * inv) >> 16) == x // G for x in range(256)), G
+    query_lens, kv_lens = [500, 1, 2200, 37], [2250, 2100, 2200, 2137]
+    inp = orc.make_paged_inputs(77 + hq + window, query_lens, kv_lens, hq, hk, 128, 16, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], sliding_window=window, mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (window - 1, 0) if window else (-1, -1), d["block_table"], 0.0, None, None, None, None, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
+    if os.environ.get("MI355_PREFILL", "pw") == "pw":
+        assert kernel.startswith("prefill_mfma_pw_sw" if window else "prefill_mfma_pw"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(torch.bfloat16)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
 
 
 @pytest.mark.parametrize("gains", [(0.0, 4.0, -4.0), (0.0, 30.0, 0.0, -30.0), (0.0, 0.0, 100.0, -100.0)])
