@@ -361,6 +361,9 @@ def main():
                  tile=(64, 64), representable_in=bf)
     unified_case(ua, "long_chunk_gqa4_d128_f16rep_fp32", seed=21, dtype=f32, query_lens=[256], kv_lens=[2304], hq=4, hk=1, d=128, page=16,
                  tile=(64, 64), representable_in=hf)
+    # ... and its sliding-window form (prefill_pw_kernel<.., SW>): a window of 300 keys = a few tiles, both masked ends inside the chunk
+    unified_case(ua, "long_chunk_sw300_gqa4_d128_bf16rep_fp32", seed=22, dtype=f32, query_lens=[256], kv_lens=[2304], hq=4, hk=1, d=128, page=16,
+                 tile=(64, 64), representable_in=bf, window=300)
 
     legacy_cases()
     cache_cases()

@@ -56,12 +56,14 @@ def test_64_rows_per_wave_prefill_kernel_vs_the_reference_2d_kernel(name):
     d = gpu_util.to_dev(t)
     out = torch.full_like(d["q"], float("nan"))
     ql = meta["query_lens"]
+    window = int(meta.get("window", 0))                      # (`long_chunk_sw*`: the sliding-window instantiation, reference :474-479)
     p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(ql), d["seqused_k"], max(meta["kv_lens"]), meta["scale"],
-                               (-1, -1), d["block_table"], 0.0, None, None, None, None, num_segments=1)
+                               (window - 1, 0) if window else (-1, -1), d["block_table"], 0.0, None, None, None, None, num_segments=1)
     launch(p, gpu_util.DEV)
     torch.cuda.synchronize()
     import os
     pinned = os.environ.get("MI355_PREFILL", "pw")          # (tests/test_gpu_variants.py pins other prefill kernels on this file)
-    assert _lib.last_kernel() == ("prefill_mfma_pw" if pinned == "pw" else "prefill_mfma"), _lib.last_kernel()
+    expect = ("prefill_mfma_pw_sw" if window else "prefill_mfma_pw") if pinned == "pw" else ("prefill_mfma_feat" if window else "prefill_mfma")
+    assert _lib.last_kernel() == expect, _lib.last_kernel()
     atol, rtol = golden_io.tolerance(t["q"].dtype)
     torch.testing.assert_close(out.float().cpu(), t["out"], atol=atol, rtol=rtol)
