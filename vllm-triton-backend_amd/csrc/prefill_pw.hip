@@ -1325,6 +1325,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k) :: "memory");
 #endif
     PW_SEG_STAMP(5);
+#ifdef MI355_PW_SEAM
+    if (t - cur.tile_lo < 2) st_sum[0] = st_last;      // (diagnostic: end of the item's second iteration, tools/pw_first_iterations.py)
+#endif
   };
 
   // ---- an item's output: O / l through this wave's parking rows, whole 256-byte rows out ------------------
@@ -1580,6 +1583,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           rec[0] = st_c1 - st_c0; rec[1] = st_r1 - st_r0; rec[2] = (unsigned long long)(tile_hi - tile_lo);
 #ifndef MI355_PW_SEAM
           for (int i = 1; i < 6; ++i) rec[2 + i] = st_sum[i];
+#else
+          rec[7] = (unsigned long long)(st_sum[0] - (unsigned)st_c0);
 #endif
           rec[8] = st_entry; rec[9] = st_r0; rec[10] = st_r1;
         }
