@@ -18,18 +18,35 @@ __device__ __forceinline__ int64_t slot_of(const mi355_cache_params& p, int t) {
   return p.slot_mapping ? p.slot_mapping[t] : (int64_t)p.slot_mapping_i32[t];
 }
 
-// same 16-bit type, contiguous head rows: copy 8 elements (16 B) per lane
+// same 16-bit type, contiguous head rows: copy 8 elements (16 B) per lane. The token's slot and its K/V rows are
+// independent loads: the rows are requested BEFORE the slot is looked at, so the kernel is two memory round trips
+// (loads, stores), not three - it is latency, not bandwidth, at the sizes of a serving step (a 500-token prefill step of the
+// e2e proxy: 19.6 -> 19.2 us per layer for cache write + attention).
+// Threads 0..127 take K chunks, 128..255 V chunks when a token's row has at most 128 chunks (Hk * D <= 1024).
 __global__ __launch_bounds__(256) void cache_write_vec16_kernel(const CacheArgs a) {
   const mi355_cache_params& p = a.p;
   const int t = blockIdx.x;
-  const int64_t slot = slot_of(p, t);
-  if (slot < 0) return;
-  const int64_t page = slot / p.page_size;
-  const int64_t off = slot % p.page_size;
   const int chunks_per_head = p.head_size / 8;
   const int n = p.num_kv_heads * chunks_per_head;
   const uint16_t* ks = (const uint16_t*)p.key + (int64_t)t * p.key_stride_token;
   const uint16_t* vs = (const uint16_t*)p.value + (int64_t)t * p.value_stride_token;
+  if (n <= 128) {
+    const int i = threadIdx.x & 127;
+    const bool is_v = threadIdx.x >= 128;
+    const int h = i / chunks_per_head, c = i % chunks_per_head;
+    uint4 x = uint4{0, 0, 0, 0};
+    if (i < n) x = is_v ? *(const uint4*)(vs + (int64_t)h * p.value_stride_head + c * 8) : *(const uint4*)(ks + (int64_t)h * p.key_stride_head + c * 8);
+    const int64_t slot = slot_of(p, t);
+    if (slot < 0 || i >= n) return;
+    const int64_t page = slot / p.page_size, off = slot % p.page_size;
+    if (is_v) *(uint4*)((uint16_t*)p.v_cache + page * p.v_stride_page + off * p.v_stride_slot + (int64_t)h * p.v_stride_head + c * 8) = x;
+    else *(uint4*)((uint16_t*)p.k_cache + page * p.k_stride_page + off * p.k_stride_slot + (int64_t)h * p.k_stride_head + c * 8) = x;
+    return;
+  }
+  const int64_t slot = slot_of(p, t);
+  if (slot < 0) return;
+  const int64_t page = slot / p.page_size;
+  const int64_t off = slot % p.page_size;
   uint16_t* kd = (uint16_t*)p.k_cache + page * p.k_stride_page + off * p.k_stride_slot;
   uint16_t* vd = (uint16_t*)p.v_cache + page * p.v_stride_page + off * p.v_stride_slot;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
