@@ -385,6 +385,75 @@ def test_prefill_sliding_window_on_the_64_rows_per_wave_kernel(dtype, window):
     torch.testing.assert_close(out.float(), out9.float(), atol=atol, rtol=rtol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("window", [0, 700])
+@pytest.mark.parametrize("cap", [30.0, 50.0, 2.0])
+def test_prefill_softcap_on_the_64_rows_per_wave_kernel(dtype, window, cap):
+    """Soft-cap (reference: apply_softcap :55-60, applied before the mask :467-482) in the SC instantiations: P = 2^(c - B /
+    (1 + 2^u)) from the raw score u, the row's reference taken after the cap, masked scores carried through as -inf.
+    Gemma-2's cap 50 and Grok-like 30, and a cap of 2 (every score deep in the tanh's shoulders); with and without a
+    sliding window; chunked prefill, a decode row in the batch; lse against float64."""
+    import gpu_util
+
+    query_lens, kv_lens = [700, 270, 1, 2100], [2300, 2100, 2500, 2100]
+    inp = orc.make_paged_inputs(91 + window + int(cap), query_lens, kv_lens, 8, 2, 128, 16, dtype)
+    inp["q"] = inp["q"] * 3.0          # scores up to ~+-40: the cap does something
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], sliding_window=window, softcap=cap, mode="2d", block_n=64)
+    _, ref_lse = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                          inp["scale"], sliding_window=window, softcap=cap, return_lse=True)
+    d = gpu_util.to_dev(inp)
+    lse = torch.full((inp["q"].shape[0], 8), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (window - 1, 0) if window else (-1, -1), d["block_table"], cap, None, None, None, None, lse=lse, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
+    if os.environ.get("MI355_PREFILL", "pw") == "pw":
+        assert kernel.startswith("prefill_mfma_pw_sw_sc" if window else "prefill_mfma_pw_sc"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    torch.testing.assert_close(lse.cpu(), ref_lse.float(), atol=2e-2, rtol=1e-3)
+    out9, _ = gpu_util.run_unified(d, inp["scale"], window=window, softcap=cap, force=9)
+    torch.testing.assert_close(out.float(), out9.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_prefill_softcap_rows_whose_first_keys_sit_at_the_other_end_of_the_cap(dtype):
+    """Soft-capped scores live in [-cap, cap], and the SC instantiation takes a row's reference from its first sixteen keys:
+    a row whose first keys all score about -cap and whose later keys score about +cap has P up to 2^(2 cap log2 e) = 2^173 at
+    cap 60 - outside the range check - and is computed again by the f32 routine (which applies the cap itself). Every row must
+    match the oracle whichever way it was computed."""
+    import gpu_util
+
+    cap, query_lens, kv_lens = 60.0, [700, 270, 1], [2300, 2100, 2500]
+    inp = _spiked_inputs(43, query_lens, kv_lens, 8, 2, (0.0, 25.0, -25.0, 3.0))
+    kc, bt = inp["k_cache"], inp["block_table"]
+    for s_i in range(len(kv_lens)):                  # the first 64 keys of every sequence point the other way
+        for pos in range(64):
+            kc[int(bt[s_i, pos // 16]), pos % 16] = -kc[int(bt[s_i, pos // 16]), pos % 16]
+    inp = {k: (v.to(dtype) if isinstance(v, torch.Tensor) and v.dtype == torch.bfloat16 else v) for k, v in inp.items()}
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], softcap=cap, mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], cap, None, None, None, None, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    if os.environ.get("MI355_PREFILL", "pw") == "pw":
+        assert _lib.last_kernel().startswith("prefill_mfma_pw_sc"), _lib.last_kernel()
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
 @pytest.mark.parametrize("hq,hk", [(6, 2), (10, 2), (7, 1), (24, 2)])
 @pytest.mark.parametrize("window", [0, 333])
 def test_prefill_64_rows_per_wave_kernel_with_groups_that_are_no_power_of_two(hq, hk, window):

@@ -122,6 +122,16 @@ __device__ __forceinline__ void a_exp2x2_ho(float r0, float r1, float x0, float 
   asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" :: "v"(r0), "v"(r1), "v"(x0), "v"(x1));
 }
 __device__ __forceinline__ void a_exp_ho(float r, float x) { asm volatile("v_exp_f32 %0, %1" :: "v"(r), "v"(x)); }
+// Soft-capped score -> P (SC instantiation; reference: apply_softcap, triton_unified_attention.py:55-60, before the mask :467-482).
+// x = u = s * 2 log2(e) / cap (the query rows are pre-scaled for it), so cap tanh(s / cap) log2(e) = A - B / (1 + 2^u) with
+// B = 2 A = 2 cap log2(e), and P = 2^(c - B / (1 + 2^u)) with the row's reference c (A drops out of the softmax; it comes back
+// in the lse). Six instructions in place of one, three of them transcendental; x is overwritten with u 2^-100 + c: c for
+// any finite score, -inf for a masked one (-inf), which carries the mask through to P = 2^-inf = 0. An independent
+// instruction or a wait state sits between each transcendental and the VALU instruction that reads its result.
+__device__ __forceinline__ void a_softcap_exp_ho(float r, float x, float c, float inv_b) {
+  asm volatile("v_exp_f32 %0, %1\n\tv_fmamk_f32 %1, %1, 0x0d800000, %2\n\tv_fma_f32 %0, %0, %3, %3\n\tv_rcp_f32 %0, %0\n\ts_nop 0\n\t"
+               "v_sub_f32 %0, %1, %0\n\tv_exp_f32 %0, %0" :: "v"(r), "v"(x), "v"(c), "v"(inv_b));
+}
 // Four scores of one lane (registers r = 0..3 of a 16x16 score tile = four consecutive keys) against a bound, hand-owned
 // like the forms above. HI: masked (-> ninf) where r > c; LO: where r < c. Three mask registers in rotation put two
 // instructions between every compare and the select that reads it (a VALU-written SGPR wants two wait states before a
@@ -271,6 +281,10 @@ template <typename T> struct pw_ops16;
     template <int KA, int QA> static __device__ __forceinline__ void qk_acc_ho(const wf32x4_t& s) {               \
       asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], %0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));  \
     }                                                                                                             \
+    /* a chain that starts from 0 (soft-cap: the raw score is needed, the reference enters after the cap) */        \
+    template <int KA, int QA> static __device__ __forceinline__ void qk_zero_ho(const wf32x4_t& s) {              \
+      asm volatile(MFMA " %0, a[%c1:%c2], a[%c3:%c4], 0" :: "v"(s), "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));   \
+    }                                                                                                             \
     /* row sums on the matrix pipe: l += 1 . P^T (A = sixteen rows of ones: every register of l holds the row's */ \
     /* whole sum) */                                                                                               \
     static __device__ __forceinline__ void lsum_ho(const wf32x4_t& l, const wu32x4_t& ones, const wu32x4_t& pf) { \
@@ -362,6 +376,7 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
   const uint32_t qw = *(const uint32_t*)((const uint16_t*)kp->p.q + (int64_t)token * kp->p.q_stride_token + (int64_t)hq * kp->p.q_stride_head + 2 * lane);
   const float q0 = pw_lo<T>(qw), q1 = pw_hi<T>(qw);
   const float scale2 = kp->p.scale * kPwLog2e;
+  const float cap = kp->p.softcap, cap2 = cap * kPwLog2e;
   const int page_mask = kp->p.page_size - 1;
   float m = -INFINITY, l = 0.0f, a0 = 0.0f, a1 = 0.0f;
   for (int j = key_lo; j < key_hi; ++j) {
@@ -369,7 +384,8 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
     const int64_t slot = j & page_mask;
     const uint32_t kw = *(const uint32_t*)(kbase + (page * kp->k_page_stride + slot * kp->k_slot_stride) * 2 + 4 * lane);
     const uint32_t vw = *(const uint32_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) * 2 + 4 * lane);
-    const float sc = wave_sum(q0 * pw_lo<T>(kw) + q1 * pw_hi<T>(kw)) * scale2;
+    float sc = wave_sum(q0 * pw_lo<T>(kw) + q1 * pw_hi<T>(kw)) * scale2;
+    if (cap > 0.0f) sc = cap2 - 2.0f * cap2 / (1.0f + __builtin_amdgcn_exp2f(sc * (2.0f / cap)));   // cap tanh(s / cap) in log2 units: cap2 (1 - 2 / (1 + e^(2 s / cap))), e^(2 s / cap) = 2^(2 sc / cap)
     const float mn = fmaxf(m, sc);
     const float alpha = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
     const uint32_t pr = pw_pack<T>(pj, pj);                 // P is rounded to V's type before P.V (:508), not for the sum
@@ -404,9 +420,10 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
 // SW (M16 only): sliding window. A Q block's tile range starts at the window of its first token (the reference's 2D kernel
 // only masks, :474-479; prefill_mfma_kernel tightens the same way), the tiles at the window's lower edge are general
 // iterations with the lower bound in their mask, and the steady stretch lies between the two masked ends.
-template <typename T, bool M16, bool SW>
+template <typename T, bool M16, bool SW, bool SC = false>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   static_assert(M16 || !SW, "the sliding window is built into the 16x16x32 instantiation only");
+  static_assert(M16 || !SC, "soft-cap is built into the 16x16x32 instantiation only");
   using ops = pw_ops<bf16_t>;                  // the 32x32x16 form exists for bf16 only (its fixed reference 0 needs bf16's exponent range)
   using ops16 = pw_ops16<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
@@ -824,7 +841,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
 
   // ---- O = 0 and Q' = Q * scale * log2(e), packed, in place in the accumulator registers the raw rows landed in ---
-  const float scale2 = p.scale * kPwLog2e;
+  // (SC: the scores come out as u = s * 2 log2(e) / cap, see a_softcap_exp_ho)
+  const float scale2 = SC ? p.scale * (2.0f * kPwLog2e) / p.softcap : p.scale * kPwLog2e;
   auto zero_o_and_convert_q = [&](const Item& I, bool zero_o) __attribute__((always_inline)) {
     if (zero_o) sfor<128>([&](auto IC) { acc_zero<kAO + decltype(IC)::value>(); });
     // the item's query rows have landed (and everything older: its first tiles, the previous item's output)
@@ -886,6 +904,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // below it rounds to zero - 2^-18 of the reference term). A fixed reference 0 (rounds 1-2) failed for any row whose
   // scores all sit far from zero; the first keys of a row are where attention sinks live.
   wf32x4_t R16[2][2];
+  // (SC: the chains start from 0 and R16[x][rt][0] is the reference c of a_softcap_exp_ho; 1 / B sits in a VGPR because one
+  // v_fma takes it as two operands)
+  float sc_inv_b = SC ? 1.0f / (2.0f * p.softcap * kPwLog2e) : 0.0f;
+  if constexpr (SC) asm volatile("" : "+v"(sc_inv_b));
   auto reset_state = [&]() __attribute__((always_inline)) {
     if constexpr (M16) {
 #pragma unroll
@@ -959,7 +981,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         float m = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
         m = fmaxf(m, lane_xor16(m));
         m = fmaxf(m, lane_xor32(m));
-        const float r = -(m + kRefMargin);
+        float r = -(m + kRefMargin);
+        // SC: m is the largest u; the reference is what the cap makes of it, c = B / (1 + 2^u) - margin (P = 2^(c - B / (1 + 2^u)))
+        if constexpr (SC) r = __builtin_amdgcn_rcpf((1.0f + __builtin_amdgcn_exp2f(m)) * sc_inv_b) - kRefMargin;
         R16[x][rt] = wf32x4_t{r, r, r, r};
         pw_launder(R16[x][rt]);
       }
@@ -1057,8 +1081,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto qk16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kt = g >> 3, ks = (g >> 1) & 3, rt = g & 1;
     constexpr int KA = kAK + 16 * kt + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
-    if constexpr (ks == 0) ops16::template qk_ref_ho<KA, QA>(S16[0][rt][kt], R16[x][rt]);
-    else ops16::template qk_acc_ho<KA, QA>(S16[0][rt][kt]);
+    if constexpr (ks == 0) {
+      if constexpr (SC) ops16::template qk_zero_ho<KA, QA>(S16[0][rt][kt]);          // the raw score: the reference enters after the cap
+      else ops16::template qk_ref_ho<KA, QA>(S16[0][rt][kt], R16[x][rt]);
+    } else ops16::template qk_acc_ho<KA, QA>(S16[0][rt][kt]);
   };
   // The mask of sub-block x, applied to the finished scores (sixteen accumulator set-ups per sub-block: a run-time branch
   // around each, as in the 32x32 form, costs a general iteration a third of its time). Runs right behind the segment
@@ -1117,8 +1143,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #ifdef PW_ABL_E
     return;
 #endif
-    if constexpr (op.kind == 0) a_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr]);
-    else if constexpr (op.kind == 1) a_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1]);
+    if constexpr (op.kind == 0) { if constexpr (SC) a_softcap_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr], R16[x][rt][0], sc_inv_b); else a_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr]); }
+    else if constexpr (op.kind == 1) { if constexpr (SC) a_softcap_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1], R16[x][rt][0], sc_inv_b); else a_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1]); }
     else if constexpr (op.kind == 2) ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[w % 3], er1[w % 3]);
   };
   // the stream's instructions in a P.V segment's gap g (36 gaps). Steady iterations: 22 went out during the S_x segment,
@@ -1336,6 +1362,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto epilogue = [&](const Item& I, auto hook) __attribute__((always_inline)) {
     const int G = sa.G;
     const uint32_t g_inv = (uint32_t)sa.g_inv;   // m / G == (m * g_inv) >> 16 for m < 256, G <= 256
+    const float sc_a = SC ? kp->p.softcap * kPwLog2e : 0.0f;     // soft-cap: the constant A = cap log2(e) that the softmax drops and the lse needs
     const int lane = lane_o, qr = lane_o & 31, half = lane_o >> 5;
     char* ost = smem + kLdsO + wave * (32 * kPwORS);
     const bool wide_store = __builtin_amdgcn_readfirstlane((int)((((uintptr_t)I.out_base & 15) == 0) && (sa.out_st % 8 == 0) && (sa.out_sh % 8 == 0))) != 0;
@@ -1373,7 +1400,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           int tok_local, hq;
           const bool row_ok = row_of(I, 2 * x + rt, tok_local, hq);
           if (I.lse_base && row_ok && g4o == 0)
-            I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? (__builtin_amdgcn_logf(l) - R16[x][rt][0]) * 0.6931471805599453f : -INFINITY;   // P = 2^(score + R)
+            I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? (__builtin_amdgcn_logf(l) - R16[x][rt][0] + sc_a) * 0.6931471805599453f : -INFINITY;   // P = 2^(score + R) (SC: 2^(capped score - A + R))
           const float inv = (row_ok && l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;   // (1 ulp: the output is rounded to 16 bits next)
           l2[rt] = l; ok2[rt] = row_ok;
           if (__builtin_expect(wide_store, 1)) {
@@ -1662,9 +1689,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 // ---------------------------------------------------------------------------------------------
 
 // Preconditions beyond prefill_supported(): bf16 or f16, head size 128, a cache of the query type, G <= 256; a sliding
-// window is served, soft-cap and ALiBi are not (they touch every score: prefill_mfma_kernel's FEAT instantiation).
+// window and soft-cap are served, ALiBi is not (prefill_mfma_kernel's FEAT instantiation).
 bool prefill_pw_applicable(const mi355_attn_params& p) {
-  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr;
+  const bool feat = p.alibi_slopes != nullptr;        // (soft-cap is served since round 3: the SC instantiations)
   const int G = p.num_q_heads / p.num_kv_heads;
   // (rows of a Q block are addressed as 32-bit byte offsets from the block's first row: strides below 2^22 elements)
   const int64_t lim = (int64_t)1 << 22;
@@ -1718,8 +1745,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // exponentials dealt one per gap it is ahead on every shape this kernel is chosen for (same box: 1 x 4096 +6.9 %,
   // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
   static const bool m16_env = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
-  const bool sw = p.sliding_window > 0;
-  const bool m16 = m16_env || sw || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, no window
+  const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f;
+  const bool m16 = m16_env || sw || sc || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, no window, no soft-cap
   auto go = [&](auto kernel, std::atomic<uint64_t>& opted) -> int {
     const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
     if (rc1 != MI355_OK) return rc1;
@@ -1727,7 +1754,13 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
     return MI355_OK;
   };
   int rc_l = MI355_OK;
-  if (m16 && sw) {
+  if (sc && sw) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, true, true>, o);
+  } else if (sc) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, false, true>, o);
+  } else if (m16 && sw) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, true>, o);
   } else if (m16) {
@@ -1739,7 +1772,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   }
   if (rc_l != MI355_OK) return rc_l;
   const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");
-  if (rc == MI355_OK) set_kernel_name(sw ? "prefill_mfma_pw_sw" : "prefill_mfma_pw");
+  if (rc == MI355_OK) set_kernel_name(sc ? (sw ? "prefill_mfma_pw_sw_sc" : "prefill_mfma_pw_sc") : sw ? "prefill_mfma_pw_sw" : "prefill_mfma_pw");
   return rc;
 }
 
