@@ -24,7 +24,7 @@ for leg in prefill decode decode_fp8 mixed prefill_b8; do
 done
 echo "== the 2D kernel's matrix: every prefill variant at 1 x 4096 / 16 x 4096, then kernel stats + MFMA busy of the variants on the 64-rows-per-wave kernel"
 bash $REPO/tools/sweeps/prefill_matrix.sh $OUT/prefill_matrix.log; cat $OUT/prefill_matrix.log
-for v in "f16:--dtype f16" "sw1024:--window 1024" "fp8:--kvdtype fp8" "f16_b16:--dtype f16 --batch 16" "sw1024_b16:--window 1024 --batch 16" "fp8_b16:--kvdtype fp8 --batch 16"; do
+for v in "f16:--dtype f16" "sw1024:--window 1024" "fp8:--kvdtype fp8" "sc30:--softcap 30" "f16_b16:--dtype f16 --batch 16" "sw1024_b16:--window 1024 --batch 16" "fp8_b16:--kvdtype fp8 --batch 16" "sc30_b16:--softcap 30 --batch 16"; do
   name=${v%%:*}; args=${v#*:}
   rm -rf $OUT/stats_v && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_v -- python3 $REPO/tools/bench_prefill.py --iters 5 $args > $OUT/variant_$name.log 2>&1
   f=$(find $OUT/stats_v -name "*kernel_stats.csv" | head -1)

@@ -13,6 +13,8 @@ for b in 1 16; do
   run --batch $b --kvdtype fp8
   run --batch $b --kvdtype fp8 --window 1024
   run --batch $b --softcap 30
+  run --batch $b --softcap 50 --window 1024
+  run --batch $b --softcap 30 --kvdtype fp8
   run --batch $b --d 64
   run --batch $b --d 256 --hq 16 --hk 8
   run --batch $b --d 96
@@ -21,4 +23,5 @@ run --batch 1 --seq 16384
 run --batch 1 --seq 16384 --dtype f16
 run --batch 1 --seq 16384 --window 4096
 run --batch 1 --seq 16384 --kvdtype fp8
+run --batch 1 --seq 16384 --softcap 50 --window 4096
 } > $out
