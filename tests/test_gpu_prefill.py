@@ -423,6 +423,47 @@ def test_prefill_softcap_on_the_64_rows_per_wave_kernel(dtype, window, cap):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk", [(8, 2), (6, 2), (16, 1)])
+def test_prefill_alibi_on_the_64_rows_per_wave_kernel(dtype, hq, hk):
+    """ALiBi (reference :481-482: S += slope * (key position - context length)) in the AL instantiation: the bias rides in the
+    score chains' C operand, relative to the row's own key, plus one multiply-add in front of the exponentials of key tiles
+    1..3. Slopes of the usual geometric form (the steepest makes keys 40 positions back negligible, the flattest reaches
+    across the whole context); chunked prefill, a decode row in the batch; lse (counted from the context's end, as the
+    reference's bias is) against float64; spiked rows through the f32 routine."""
+    import gpu_util
+
+    query_lens, kv_lens = [700, 270, 1, 2100], [2300, 2100, 2500, 2100]
+    inp = _spiked_inputs(57 + hq, query_lens, kv_lens, hq, hk, (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 40.0, -40.0))
+    inp = {k: (v.to(dtype) if isinstance(v, torch.Tensor) and v.dtype == torch.bfloat16 else v) for k, v in inp.items()}
+    slopes = torch.tensor([2.0 ** (-(i + 1) * 8.0 / hq) for i in range(hq)], dtype=torch.float32)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], alibi_slopes=slopes, mode="2d", block_n=64)
+    _, ref_lse = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                          inp["scale"], alibi_slopes=slopes, return_lse=True)
+    d = gpu_util.to_dev(inp)
+    sl = slopes.to(gpu_util.DEV)
+    lse = torch.full((inp["q"].shape[0], hq), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], 0.0, None, None, sl, None, lse=lse, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
+    if os.environ.get("MI355_PREFILL", "pw") == "pw":
+        assert kernel.startswith("prefill_mfma_pw_al"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    # (lse on the rows that are not spiked: at |score| ~ 300 log2 units the rounding of Q * scale * log2(e) to 16 bits
+    # moves a score by a few hundredths - invisible in the output, not in a logarithm compared at 2e-2)
+    plain = (torch.arange(inp["q"].shape[0]) % 8) < 6
+    torch.testing.assert_close(lse.cpu()[plain], ref_lse.float()[plain], atol=2e-2, rtol=1e-3)
+    torch.testing.assert_close(lse.cpu(), ref_lse.float(), atol=0.2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_prefill_softcap_rows_whose_first_keys_sit_at_the_other_end_of_the_cap(dtype):
     """Soft-capped scores live in [-cap, cap], and the SC instantiation takes a row's reference from its first sixteen keys:
     a row whose first keys all score about -cap and whose later keys score about +cap has P up to 2^(2 cap log2 e) = 2^173 at

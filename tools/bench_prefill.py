@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--window", type=int, default=0, help="sliding window (keys per query row), 0 = off; FLOPs count the visible keys only")
     ap.add_argument("--softcap", type=float, default=0.0)
+    ap.add_argument("--alibi", action="store_true", help="ALiBi slopes 2^(-8 (i + 1) / Hq)")
     ap.add_argument("--segments", type=int, default=0, help="num_segments of the call (1 = no key split)")
     ap.add_argument("--legacy", action="store_true", help="context_attention_fwd: v0 cache layout for the first --ctx keys, the rest from linear k/v")
     ap.add_argument("--ctx", type=int, default=0, help="context keys per sequence already in the cache (query length = seq - ctx)")
@@ -54,7 +55,8 @@ def main():
         W = args.window
         vis = sum(min(i + 1, W) for i in range(L))
         flops = 4 * args.d * args.hq * vis * B
-    p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), win, bt, args.softcap, ksc, ksc, None, None,
+    slopes = torch.tensor([2.0 ** (-(i + 1) * 8.0 / args.hq) for i in range(args.hq)], dtype=torch.float32, device=q.device) if args.alibi else None
+    p, keep = ua_mod.fill_attn_params(q, k, v, out, cu, L, sl, L, 1.0 / math.sqrt(args.d), win, bt, args.softcap, ksc, ksc, slopes, None,
                                       num_segments=args.segments)
     if args.ctx and not args.legacy:     # chunked prefill through unified_attention: the last seq - ctx tokens are the queries
         QL = L - args.ctx

@@ -14,6 +14,7 @@ for b in 1 16; do
   run --batch $b --kvdtype fp8 --window 1024
   run --batch $b --softcap 30
   run --batch $b --softcap 50 --window 1024
+  run --batch $b --alibi
   run --batch $b --softcap 30 --kvdtype fp8
   run --batch $b --d 64
   run --batch $b --d 256 --hq 16 --hk 8

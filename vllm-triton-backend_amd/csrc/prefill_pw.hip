@@ -122,6 +122,16 @@ __device__ __forceinline__ void a_exp2x2_ho(float r0, float r1, float x0, float 
   asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" :: "v"(r0), "v"(r1), "v"(x0), "v"(x1));
 }
 __device__ __forceinline__ void a_exp_ho(float r, float x) { asm volatile("v_exp_f32 %0, %1" :: "v"(r), "v"(x)); }
+// ALiBi (AL instantiation; reference :481-482, S += slope * (key position - context length)): the row's slope times the
+// key's position is linear in the key, so its tile- and register-dependent part rides in the chain's C operand (rebuilt
+// per tile, see alibi_c16) and only slope * 16 kt is left for key tiles 1..3 of a score tile: one v_fmamk in front of the
+// exponential (K = 16, 32, 48 as a literal).
+template <int KT> __device__ __forceinline__ void a_alibi_exp_ho(float r, float x, float slope2) {
+  static_assert(KT >= 1 && KT <= 3, "key tile 0 needs no step");
+  if constexpr (KT == 1) asm volatile("v_fmamk_f32 %0, %2, 0x41800000, %1\n\tv_exp_f32 %0, %0" :: "v"(r), "v"(x), "v"(slope2));
+  else if constexpr (KT == 2) asm volatile("v_fmamk_f32 %0, %2, 0x42000000, %1\n\tv_exp_f32 %0, %0" :: "v"(r), "v"(x), "v"(slope2));
+  else asm volatile("v_fmamk_f32 %0, %2, 0x42400000, %1\n\tv_exp_f32 %0, %0" :: "v"(r), "v"(x), "v"(slope2));
+}
 // Soft-capped score -> P (SC instantiation; reference: apply_softcap, triton_unified_attention.py:55-60, before the mask :467-482).
 // x = u = s * 2 log2(e) / cap (the query rows are pre-scaled for it), so cap tanh(s / cap) log2(e) = A - B / (1 + 2^u) with
 // B = 2 A = 2 cap log2(e), and P = 2^(c - B / (1 + 2^u)) with the row's reference c (A drops out of the softmax; it comes back
@@ -372,11 +382,12 @@ __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int n
 // reference is good for - and independent of everything the fast path keeps on chip: K/V straight from the cache.
 template <typename T, typename ArgPtr>
 __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, const char* kbase, const char* vbase,
-                                             int token, int hq, int key_lo, int key_hi, uint16_t* out_base, float* lse_base, int lane) {
+                                             int token, int hq, int key_lo, int key_hi, uint16_t* out_base, float* lse_base, int lane, int ctx_len) {
   const uint32_t qw = *(const uint32_t*)((const uint16_t*)kp->p.q + (int64_t)token * kp->p.q_stride_token + (int64_t)hq * kp->p.q_stride_head + 2 * lane);
   const float q0 = pw_lo<T>(qw), q1 = pw_hi<T>(qw);
   const float scale2 = kp->p.scale * kPwLog2e;
   const float cap = kp->p.softcap, cap2 = cap * kPwLog2e;
+  const float slope2 = kp->p.alibi_slopes ? kp->p.alibi_slopes[hq] * kPwLog2e : 0.0f;     // ALiBi: + slope * (key position - context length), :481-482
   const int page_mask = kp->p.page_size - 1;
   float m = -INFINITY, l = 0.0f, a0 = 0.0f, a1 = 0.0f;
   for (int j = key_lo; j < key_hi; ++j) {
@@ -386,6 +397,7 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
     const uint32_t vw = *(const uint32_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) * 2 + 4 * lane);
     float sc = wave_sum(q0 * pw_lo<T>(kw) + q1 * pw_hi<T>(kw)) * scale2;
     if (cap > 0.0f) sc = cap2 - 2.0f * cap2 / (1.0f + __builtin_amdgcn_exp2f(sc * (2.0f / cap)));   // cap tanh(s / cap) in log2 units: cap2 (1 - 2 / (1 + e^(2 s / cap))), e^(2 s / cap) = 2^(2 sc / cap)
+    sc += slope2 * (float)(j - ctx_len);
     const float mn = fmaxf(m, sc);
     const float alpha = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sc - mn);
     const uint32_t pr = pw_pack<T>(pj, pj);                 // P is rounded to V's type before P.V (:508), not for the sum
@@ -420,10 +432,11 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
 // SW (M16 only): sliding window. A Q block's tile range starts at the window of its first token (the reference's 2D kernel
 // only masks, :474-479; prefill_mfma_kernel tightens the same way), the tiles at the window's lower edge are general
 // iterations with the lower bound in their mask, and the steady stretch lies between the two masked ends.
-template <typename T, bool M16, bool SW, bool SC = false>
+template <typename T, bool M16, bool SW, bool SC = false, bool AL = false>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   static_assert(M16 || !SW, "the sliding window is built into the 16x16x32 instantiation only");
   static_assert(M16 || !SC, "soft-cap is built into the 16x16x32 instantiation only");
+  static_assert(!AL || (M16 && !SW && !SC), "ALiBi: the plain 16x16x32 instantiation only");
   using ops = pw_ops<bf16_t>;                  // the 32x32x16 form exists for bf16 only (its fixed reference 0 needs bf16's exponent range)
   using ops16 = pw_ops16<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
@@ -908,6 +921,23 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // v_fma takes it as two operands)
   float sc_inv_b = SC ? 1.0f / (2.0f * p.softcap * kPwLog2e) : 0.0f;
   if constexpr (SC) asm volatile("" : "+v"(sc_inv_b));
+  // ALiBi state (AL): al_sl[x][rt] = the row's slope in log2 units (a row's head never changes: loaded once), al_base[x][rt] =
+  // -m_ref - slope * (the row's own position), so that the bias of the row's own key is 0 and every visible key's bias is
+  // <= 0: P = 2^(s - m_ref + slope (j - i)) stays where the plain kernel's P is. R16 becomes the PER-TILE C operand:
+  // R16[x][rt][r] = al_base + slope * (the lane's first key of the tile + r), rebuilt before each score segment (alibi_c16).
+  float al_sl[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, al_base[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+  unsigned al_ref_bad = 0;            // bit 2 x + rt: the row's estimated maximum is beyond kPwRefMax (see the epilogue)
+  if constexpr (AL) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int m_row = wave * 64 + (2 * x + rt) * 16 + (lane & 15);
+        const int hq = head * a.group + m_row % a.group;
+        al_sl[x][rt] = (m_row < a.block_q * a.group) ? p.alibi_slopes[hq] * kPwLog2e : 0.0f;
+        pw_launder(al_sl[x][rt]);
+      }
+  }
   auto reset_state = [&]() __attribute__((always_inline)) {
     if constexpr (M16) {
 #pragma unroll
@@ -959,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // see (causal mask, sliding window) are left in: the reference only has to be in the neighbourhood of the row's
   // scores. f16 leaves kRefMargin powers of two of head room above the estimate.
   constexpr float kRefMargin = __is_same(T, f16_t) ? 6.0f : 0.0f;
-  auto set_references = [&]() __attribute__((always_inline)) {
+  auto set_references = [&](const Item& I) __attribute__((always_inline)) {
     // (temporaries: score registers [rt][x] - nothing of a tile is in them yet; ordinary operands here, so the compiler
     // sees them defined again)
     sfor<2>([&](auto X) __attribute__((always_inline)) {
@@ -984,6 +1014,14 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         float r = -(m + kRefMargin);
         // SC: m is the largest u; the reference is what the cap makes of it, c = B / (1 + 2^u) - margin (P = 2^(c - B / (1 + 2^u)))
         if constexpr (SC) r = __builtin_amdgcn_rcpf((1.0f + __builtin_amdgcn_exp2f(m)) * sc_inv_b) - kRefMargin;
+        if constexpr (AL) {        // the bias is taken relative to the row's own key (see al_base); R16 is rebuilt per tile
+          int m_row = wave * 64 + (2 * x + rt) * 16 + (lane_o & 15);
+          asm volatile("" : "+v"(m_row));
+          al_base[x][rt] = r - al_sl[x][rt] * (float)(I.ctx_len + I.tok0 + div_g(m_row));
+          pw_launder(al_base[x][rt]);
+          if (x == 0 && rt == 0) al_ref_bad = 0;
+          al_ref_bad |= (fabsf(r) <= kPwRefMax) ? 0u : (1u << (2 * x + rt));
+        }
         R16[x][rt] = wf32x4_t{r, r, r, r};
         pw_launder(R16[x][rt]);
       }
@@ -1078,6 +1116,20 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   // ---- the same pieces on the 16x16x32 shape (M16) ----------------------------------------------------------
   // MFMA g (0..31) of S_x: key tile g >> 3, k-step (g >> 1) & 3, row tile g & 1
+  // AL: the C operand of sub-block x's score chains for tile t: reference + slope * (position of this lane's key r of key
+  // tile 0 - the row's own position); key tiles 1..3 add slope * 16 kt in front of their exponentials (a_alibi_exp_ho).
+  auto alibi_c16 = [&](auto X, int t) __attribute__((always_inline)) {
+    constexpr int x = decltype(X)::value;
+    int k0 = t * kPwTile + 4 * g4;
+    asm volatile("" : "+v"(k0));
+    const float k0f = (float)k0;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float sl = al_sl[x][rt], b = __builtin_fmaf(sl, k0f, al_base[x][rt]);
+      R16[x][rt] = wf32x4_t{b, b + sl, __builtin_fmaf(sl, 2.0f, b), __builtin_fmaf(sl, 3.0f, b)};
+    }
+    asm volatile("s_nop 1" : "+v"(R16[x][0]), "+v"(R16[x][1]));      // (VALU-written C operands: two wait states before the matrix instruction)
+  };
   auto qk16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kt = g >> 3, ks = (g >> 1) & 3, rt = g & 1;
     constexpr int KA = kAK + 16 * kt + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
@@ -1143,8 +1195,15 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #ifdef PW_ABL_E
     return;
 #endif
-    if constexpr (op.kind == 0) { if constexpr (SC) a_softcap_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr], R16[x][rt][0], sc_inv_b); else a_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr]); }
-    else if constexpr (op.kind == 1) { if constexpr (SC) a_softcap_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1], R16[x][rt][0], sc_inv_b); else a_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1]); }
+    if constexpr (op.kind == 0) {
+      if constexpr (SC) a_softcap_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr], R16[x][rt][0], sc_inv_b);
+      else if constexpr (AL && kt > 0) a_alibi_exp_ho<(kt > 0 ? kt : 1)>(er0[w % 3], S16[0][rt][kt][2 * pr], al_sl[x][rt]);
+      else a_exp_ho(er0[w % 3], S16[0][rt][kt][2 * pr]);
+    } else if constexpr (op.kind == 1) {
+      if constexpr (SC) a_softcap_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1], R16[x][rt][0], sc_inv_b);
+      else if constexpr (AL && kt > 0) a_alibi_exp_ho<(kt > 0 ? kt : 1)>(er1[w % 3], S16[0][rt][kt][2 * pr + 1], al_sl[x][rt]);
+      else a_exp_ho(er1[w % 3], S16[0][rt][kt][2 * pr + 1]);
+    }
     else if constexpr (op.kind == 2) ops16::pack_ho(pwv16[x][rt][kt >> 1][2 * (kt & 1) + pr], er0[w % 3], er1[w % 3]);
   };
   // the stream's instructions in a P.V segment's gap g (36 gaps). Steady iterations: 22 went out during the S_x segment,
@@ -1237,6 +1296,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       // done) through segment 2, B's from gap 10 of segment 3 through segment 4; the LDS-DMA in gaps 2 .. 9 of segment 1;
       // V(t) fragment f (read by instructions 2 f, 2 f + 1 of segment 2) re-loaded in the odd gaps from 2 f + 3 on; K(t+1)
       // fragments 0 .. 3 in segment 3, the others in the gaps segment 4's stream leaves free.
+      if constexpr (AL) alibi_c16(ic<0>{}, t);
       sfor<32>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         qk16(ic<0>{}, GC);
@@ -1269,6 +1329,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         if constexpr (g >= 3 && g < 32 && (g & 1) == 1) vread16(ic<(g >= 3 && g < 32) ? ((g - 3) / 2) : 0>{}, ic<VR>{});
       });
       PW_SEG_STAMP(2);
+      if constexpr (AL) alibi_c16(ic<1>{}, t);
       sfor<32>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         qk16(ic<1>{}, GC);
@@ -1400,7 +1461,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           int tok_local, hq;
           const bool row_ok = row_of(I, 2 * x + rt, tok_local, hq);
           if (I.lse_base && row_ok && g4o == 0)
-            I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? (__builtin_amdgcn_logf(l) - R16[x][rt][0] + sc_a) * 0.6931471805599453f : -INFINITY;   // P = 2^(score + R) (SC: 2^(capped score - A + R))
+            I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? (__builtin_amdgcn_logf(l) - (AL ? al_base[x][rt] + al_sl[x][rt] * (float)I.ctx_len : R16[x][rt][0]) + sc_a) * 0.6931471805599453f : -INFINITY;   // P = 2^(score + R) (SC: 2^(capped score - A + R); AL: the bias as the reference counts it, from the context's end)
           const float inv = (row_ok && l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;   // (1 ulp: the output is rounded to 16 bits next)
           l2[rt] = l; ok2[rt] = row_ok;
           if (__builtin_expect(wide_store, 1)) {
@@ -1442,7 +1503,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           bad16[x][rt] = has_keys && !(l2[rt] >= (__is_same(T, f16_t) ? kPwSumLoF16 : kPwSumLo) && l2[rt] <= kPwSumHi && (rt ? am1 : am0) < INFINITY);   // (an f16 P that overflowed is an inf in the sum)
           // scores of a magnitude at which the 2^-9 relative rounding of Q' = Q * scale * log2(e) to 16 bits moves the
           // DIFFERENCES between keys by tenths (thousands of log2 units: nothing a model produces): the f32 routine as well
-          bad16[x][rt] = bad16[x][rt] || (has_keys && !(fabsf(R16[x][rt][0]) <= kPwRefMax));
+          bad16[x][rt] = bad16[x][rt] || (has_keys && (AL ? ((al_ref_bad >> (2 * x + rt)) & 1u) != 0 : !(fabsf(R16[x][rt][0]) <= kPwRefMax)));
 #ifdef PW_FORCE_FALLBACK
           bad16[x][rt] = has_keys;
 #endif
@@ -1523,7 +1584,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         const int tok = I.tok0 + div_g(m);
         const int key_hi = min(min(I.ctx_len + tok, I.seq_len - 1) + 1, I.tile_hi * kPwTile);
         const int key_lo_row = (SW && sa.window > 0) ? max(key_lo, I.ctx_len + tok - sa.window + 1) : key_lo;
-        pw_row_fallback<T>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo_row, key_hi, I.out_base, I.lse_base, lane);
+        pw_row_fallback<T>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo_row, key_hi, I.out_base, I.lse_base, lane, I.ctx_len);
       }
     }
   };
@@ -1538,7 +1599,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       if constexpr (M16) sfor<16>([&](auto NC) __attribute__((always_inline)) { kread16(NC, ic<0>{}); });
       else sfor<16>([&](auto NC) __attribute__((always_inline)) { kread(NC, ic<0>{}); });
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slot 0 is re-filled (K(tile_lo + 3)) in the first iteration
-      if constexpr (M16) set_references();
+      if constexpr (M16) set_references(cur);
       int t = tile_lo;
 #ifdef MI355_PW_STAMP
       // diagnostic build only (tools/pw_clock.py): shader cycles and 100 MHz ticks around the tile loop
@@ -1689,9 +1750,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 // ---------------------------------------------------------------------------------------------
 
 // Preconditions beyond prefill_supported(): bf16 or f16, head size 128, a cache of the query type, G <= 256; a sliding
-// window and soft-cap are served, ALiBi is not (prefill_mfma_kernel's FEAT instantiation).
+// window and soft-cap are served, and ALiBi without either (with them: prefill_mfma_kernel's FEAT instantiation).
 bool prefill_pw_applicable(const mi355_attn_params& p) {
-  const bool feat = p.alibi_slopes != nullptr;        // (soft-cap is served since round 3: the SC instantiations)
+  // (soft-cap and ALiBi are served since round 3 - the SC and AL instantiations - but ALiBi only by itself)
+  const bool feat = p.alibi_slopes != nullptr && (p.softcap > 0.0f || p.sliding_window > 0);
   const int G = p.num_q_heads / p.num_kv_heads;
   // (rows of a Q block are addressed as 32-bit byte offsets from the block's first row: strides below 2^22 elements)
   const int64_t lim = (int64_t)1 << 22;
@@ -1745,8 +1807,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // exponentials dealt one per gap it is ahead on every shape this kernel is chosen for (same box: 1 x 4096 +6.9 %,
   // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
   static const bool m16_env = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
-  const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f;
-  const bool m16 = m16_env || sw || sc || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, no window, no soft-cap
+  const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f, al = p.alibi_slopes != nullptr;
+  const bool m16 = m16_env || sw || sc || al || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, no window, no soft-cap, no ALiBi
   auto go = [&](auto kernel, std::atomic<uint64_t>& opted) -> int {
     const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
     if (rc1 != MI355_OK) return rc1;
@@ -1754,7 +1816,10 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
     return MI355_OK;
   };
   int rc_l = MI355_OK;
-  if (sc && sw) {
+  if (al) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, false, false, true>, o);
+  } else if (sc && sw) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, true, true>, o);
   } else if (sc) {
@@ -1772,7 +1837,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   }
   if (rc_l != MI355_OK) return rc_l;
   const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");
-  if (rc == MI355_OK) set_kernel_name(sc ? (sw ? "prefill_mfma_pw_sw_sc" : "prefill_mfma_pw_sc") : sw ? "prefill_mfma_pw_sw" : "prefill_mfma_pw");
+  if (rc == MI355_OK) set_kernel_name(al ? "prefill_mfma_pw_al" : sc ? (sw ? "prefill_mfma_pw_sw_sc" : "prefill_mfma_pw_sc") : sw ? "prefill_mfma_pw_sw" : "prefill_mfma_pw");
   return rc;
 }
 
