@@ -141,9 +141,11 @@ def test_workspace_bytes_of_the_prefill_paths(lib):
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters
     p.q_dtype = p.kv_dtype = lib.dtype_code(torch.float16)           # f16: the same kernel (round 3), the same counters
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters
-    p.alibi_slopes = addr                                             # ALiBi stays on the 8-wave kernel: no scratch at all
+    p.alibi_slopes = addr                                             # ALiBi alone: the same kernel's AL instantiation
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) == counters
+    p.softcap = 30.0                                                  # ALiBi with soft-cap: the register-staged kernel, no scratch at all
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0
-    p.alibi_slopes = 0
+    p.alibi_slopes, p.softcap = 0, 0.0
     p.q_dtype = p.kv_dtype = lib.dtype_code(torch.bfloat16)
     # a 512-token chunk against 8192 keys: (512/32 + 1) * 8 = 136 workgroups -> 4 key splits of partial out (bf16) + lse (f32)
     p.num_tokens, p.max_seqlen_q, p.max_seqlen_k = 512, 512, 8192
