@@ -1461,7 +1461,11 @@ bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
   if (!prefill_supported(p) || !prefill_pw_applicable(p) || v1 || (variant && variant[0] != 'p')) return false;
   const bool pinned = variant && variant[0] == 'p';
   if (p.non_causal) return !ks || ks->wide;           // the one matrix-core kernel without the causal diagonal built in
-  const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= 2048;
+  // (soft-cap and ALiBi: from 512 keys on - the alternative is the register-staged kernel's feature instantiation, which the
+  // SC / AL instantiations beat at every short shape measured: 1 x 1024 42 / 31 us against 58, 8 x 512 55 / 44 against 66,
+  // 1 x 1536 58 / 40 against 86)
+  const int min_keys = (p.softcap > 0.0f || p.alibi_slopes) ? 512 : 2048;
+  const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= min_keys;
   return pinned ? (!ks || ks->wide) : use_pw;
 }
 
