@@ -553,6 +553,37 @@ def test_prefill_f16_rows_whose_scores_sit_far_from_zero(gains):
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("feature", ["softcap", "alibi"])
+def test_long_featured_prefill_over_an_fp8_cache(feature):
+    """Soft-cap or ALiBi over an fp8 flash-layout cache: the dequantising pass, then the feature's instantiation of the
+    64-rows-per-wave kernel on the 16-bit scratch (`repack+prefill_mfma_pw_sc` / `_al`)."""
+    import gpu_util
+
+    query_lens, kv_lens = [2100, 1500, 1], [2100, 2600, 2500]
+    ks, vs = 0.0237, 0.041
+    dtype, hq = torch.bfloat16, 8
+    inp = orc.make_paged_inputs(73, query_lens, kv_lens, hq, 2, 128, 16, dtype, kv_dtype=torch.float8_e4m3fn, kv_scale=ks)
+    slopes = torch.tensor([2.0 ** (-(i + 1) * 8.0 / hq) for i in range(hq)], dtype=torch.float32) if feature == "alibi" else None
+    cap = 30.0 if feature == "softcap" else 0.0
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], softcap=cap, alibi_slopes=slopes, k_scale=ks, v_scale=vs, mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    kst, vst = torch.tensor([ks], device=gpu_util.DEV), torch.tensor([vs], device=gpu_util.DEV)
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], cap, kst, vst, None if slopes is None else slopes.to(gpu_util.DEV), None, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
+    if os.environ.get("MI355_PREFILL", "pw") == "pw":
+        assert kernel.startswith("repack+prefill_mfma_pw_sc+decode" if feature == "softcap" else "repack+prefill_mfma_pw_al+decode"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype, torch.float8_e4m3fn)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
 @pytest.mark.parametrize("dtype,kv_dtype", [(torch.bfloat16, torch.float8_e4m3fn), (torch.float16, torch.float8_e5m2)])
 @pytest.mark.parametrize("window", [0, 700])
 def test_long_prefill_over_an_fp8_cache_runs_on_the_64_rows_per_wave_kernel(dtype, kv_dtype, window):
