@@ -553,6 +553,82 @@ def test_prefill_f16_rows_whose_scores_sit_far_from_zero(gains):
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk", [(8, 2), (6, 2), (16, 1)])
+def test_prefill_head_size_64_on_the_64_rows_per_wave_kernel(dtype, hq, hk):
+    """Head size 64 on the same kernel: the geometry of head size 128 with half-empty LDS rows - two k-steps per score chain,
+    four 16-column output tiles, the absent matrix instructions' slots left empty. Ragged chunked prefill, a decode row,
+    groups of 4 / 3 / 16 query heads, rows with larger scores, lse against float64. (The f32 routine with half its lanes
+    idle: test_prefill_head_size_64_rows_through_the_f32_routine.)"""
+    import gpu_util
+
+    query_lens, kv_lens = [700, 270, 1, 2100], [2300, 2100, 2500, 2100]
+    inp = orc.make_paged_inputs(61 + hq, query_lens, kv_lens, hq, hk, 64, 16, dtype)
+    q = inp["q"].float()
+    q[5::16] *= 6.0                        # every sixteenth row: scores 6 x larger
+    inp["q"] = q.to(dtype)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    _, ref_lse = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                          inp["scale"], return_lse=True)
+    d = gpu_util.to_dev(inp)
+    lse = torch.full((inp["q"].shape[0], hq), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], 0.0, None, None, None, None, lse=lse, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
+    if os.environ.get("MI355_PREFILL", "pw") == "pw":
+        assert kernel.startswith("prefill_mfma_pw"), kernel
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    plain = (torch.arange(inp["q"].shape[0]) % 16) != 5
+    torch.testing.assert_close(lse.cpu()[plain], ref_lse.float()[plain], atol=2e-2, rtol=1e-3)
+
+
+def test_prefill_head_size_64_rows_through_the_f32_routine():
+    """Head size 64, rows whose scores leave the range of their reference: keys = one direction per KV head plus noise, but the
+    first 64 keys of every sequence point the other way; rows that are +-60 x that direction have references taken at one end
+    and scores at the other (2^+-250), and are computed again by the f32 routine, whose upper 32 lanes have no head dimension."""
+    import gpu_util
+
+    query_lens, kv_lens, hq, hk = [700, 270, 1], [2300, 2100, 2500], 8, 2
+    inp = orc.make_paged_inputs(97, query_lens, kv_lens, hq, hk, 64, 16, torch.bfloat16)
+    g = torch.Generator().manual_seed(98)
+    u = torch.rand(hk, 64, generator=g) * 2 - 1
+    kc = (u[None, None] + (torch.rand(inp["k_cache"].shape, generator=g) * 2 - 1) * 0.1)
+    bt = inp["block_table"]
+    for s_i in range(len(kv_lens)):
+        for pos in range(64):
+            kc[int(bt[s_i, pos // 16]), pos % 16] *= -1.0
+    inp["k_cache"] = kc.to(torch.bfloat16)
+    q = inp["q"].float()
+    for r in range(q.shape[0]):
+        gain = (0.0, 60.0, 0.0, -60.0)[r % 4]
+        if gain != 0.0:
+            for h in range(hq):
+                q[r, h] = gain * u[h // (hq // hk)]
+    inp["q"] = q.to(torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], 0.0, None, None, None, None, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    if os.environ.get("MI355_PREFILL", "pw") == "pw":
+        assert _lib.last_kernel().startswith("prefill_mfma_pw"), _lib.last_kernel()
+    assert not torch.isnan(out).any()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("feature", ["softcap", "alibi"])
 def test_long_featured_prefill_over_an_fp8_cache(feature):
     """Soft-cap or ALiBi over an fp8 flash-layout cache: the dequantising pass, then the feature's instantiation of the

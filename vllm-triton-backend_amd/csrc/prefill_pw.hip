@@ -383,8 +383,10 @@ __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int n
 template <typename T, typename ArgPtr>
 __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, const char* kbase, const char* vbase,
                                              int token, int hq, int key_lo, int key_hi, uint16_t* out_base, float* lse_base, int lane, int ctx_len) {
-  const uint32_t qw = *(const uint32_t*)((const uint16_t*)kp->p.q + (int64_t)token * kp->p.q_stride_token + (int64_t)hq * kp->p.q_stride_head + 2 * lane);
-  const float q0 = pw_lo<T>(qw), q1 = pw_hi<T>(qw);
+  const bool act = 2 * lane < kp->p.head_size;            // (head size 64: half the lanes; the others add 0 to every score and store nothing)
+  const int dl = act ? 2 * lane : 0;
+  const uint32_t qw = *(const uint32_t*)((const uint16_t*)kp->p.q + (int64_t)token * kp->p.q_stride_token + (int64_t)hq * kp->p.q_stride_head + dl);
+  const float q0 = act ? pw_lo<T>(qw) : 0.0f, q1 = act ? pw_hi<T>(qw) : 0.0f;
   const float scale2 = kp->p.scale * kPwLog2e;
   const float cap = kp->p.softcap, cap2 = cap * kPwLog2e;
   const float slope2 = kp->p.alibi_slopes ? kp->p.alibi_slopes[hq] * kPwLog2e : 0.0f;     // ALiBi: + slope * (key position - context length), :481-482
@@ -393,8 +395,8 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
   for (int j = key_lo; j < key_hi; ++j) {
     const int64_t page = bt[j >> kp->page_shift];
     const int64_t slot = j & page_mask;
-    const uint32_t kw = *(const uint32_t*)(kbase + (page * kp->k_page_stride + slot * kp->k_slot_stride) * 2 + 4 * lane);
-    const uint32_t vw = *(const uint32_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) * 2 + 4 * lane);
+    const uint32_t kw = *(const uint32_t*)(kbase + (page * kp->k_page_stride + slot * kp->k_slot_stride) * 2 + 2 * dl);
+    const uint32_t vw = *(const uint32_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) * 2 + 2 * dl);
     float sc = wave_sum(q0 * pw_lo<T>(kw) + q1 * pw_hi<T>(kw)) * scale2;
     if (cap > 0.0f) sc = cap2 - 2.0f * cap2 / (1.0f + __builtin_amdgcn_exp2f(sc * (2.0f / cap)));   // cap tanh(s / cap) in log2 units: cap2 (1 - 2 / (1 + e^(2 s / cap))), e^(2 s / cap) = 2^(2 sc / cap)
     sc += slope2 * (float)(j - ctx_len);
@@ -407,7 +409,7 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
     m = mn;
   }
   const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-  *(uint32_t*)(out_base + (int64_t)token * kp->p.out_stride_token + (int64_t)hq * kp->p.out_stride_head + 2 * lane) = pw_pack<T>(a0 * inv, a1 * inv);
+  if (act) *(uint32_t*)(out_base + (int64_t)token * kp->p.out_stride_token + (int64_t)hq * kp->p.out_stride_head + dl) = pw_pack<T>(a0 * inv, a1 * inv);
   if (lse_base && lane == 0)
     lse_base[(int64_t)token * kp->p.lse_stride_token + hq] = l > 0.0f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
 }
@@ -432,11 +434,17 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
 // SW (M16 only): sliding window. A Q block's tile range starts at the window of its first token (the reference's 2D kernel
 // only masks, :474-479; prefill_mfma_kernel tightens the same way), the tiles at the window's lower edge are general
 // iterations with the lower bound in their mask, and the steady stretch lies between the two masked ends.
-template <typename T, bool M16, bool SW, bool SC = false, bool AL = false>
+template <typename T, bool M16, bool SW, bool SC = false, bool AL = false, int D = 128>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   static_assert(M16 || !SW, "the sliding window is built into the 16x16x32 instantiation only");
   static_assert(M16 || !SC, "soft-cap is built into the 16x16x32 instantiation only");
   static_assert(!AL || (M16 && !SW && !SC), "ALiBi: the plain 16x16x32 instantiation only");
+  // D = 64: the SAME geometry with half-empty rows - a key row still owns a 256-byte LDS row and sixteen chunk positions,
+  // of which the swizzle fills eight with the row's eight 16-byte chunks (the other eight lanes of a row's LDS-DMA re-read
+  // those chunks: same addresses, coalesced, never read back); k-steps 2 and 3 of every score chain, output tiles 4..7
+  // and their fragment reads simply do not exist. Every instruction table, ring and seam stays as it is.
+  static_assert(D == 128 || (D == 64 && M16 && !SW && !SC && !AL), "head size 64: the plain 16x16x32 instantiation only");
+  constexpr int kKS = D / 32, kDB = D / 16, kCM = D / 8 - 1;      // k-steps of a score chain, 16-column output tiles, chunk mask of a row
   using ops = pw_ops<bf16_t>;                  // the 32x32x16 form exists for bf16 only (its fixed reference 0 needs bf16's exponent range)
   using ops16 = pw_ops16<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
@@ -709,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         int tok_local, hq;
         row_of(I, rt4, tok_local, hq);
         const uint32_t off = (uint32_t)(((min(tok_local, I.q_len - 1) - I.tok0) * sa.q_st + (hq - head * sa.G) * sa.q_sh + 8 * (lane_o >> 4)) * 2);
-        sfor<4>([&](auto KS) { constexpr int ks = decltype(KS)::value; pw_gload16_acc<kAQ + 16 * rt4 + 4 * ks, 64 * ks>(off, qb); });
+        sfor<kKS>([&](auto KS) { constexpr int ks = decltype(KS)::value; pw_gload16_acc<kAQ + 16 * rt4 + 4 * ks, 64 * ks>(off, qb); });
       });
     } else if (part <= 0)
     sfor<2>([&](auto SB) {
@@ -734,7 +742,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     asm volatile("" : "+v"(lo));
     const int r4 = lo >> 4, c16 = lo & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + ((c16 ^ R) << 4)); }
+    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + (((c16 ^ R) & kCM) << 4)); }
   };
   auto set_v_offsets = [&](int maxr) {
     int lo = lane;
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     // V's chunk swizzle follows the transposed read of the instantiation: half a wave of it covers rows 0..3 x four chunks
     // (32x32x16 form: f = 4 (R & 3) | (R >> 2) & 3 keeps the rows apart) or rows 0..7 x two chunks (16x16x32 form: f = 2 (R & 7);
     // the other form's f there puts rows r and r + 4 on the same banks: 34 % of LDS-active cycles were conflicts)
-    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; const int f = M16 ? 2 * (R & 7) : (((R & 3) << 2) | ((R >> 2) & 3)); voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + ((c16 ^ f) << 4)); }
+    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; const int f = M16 ? 2 * (R & 7) : (((R & 3) << 2) | ((R >> 2) & 3)); voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + (((c16 ^ f) & kCM) << 4)); }
   };
   set_k_offsets(15);
   set_v_offsets(15);
@@ -869,7 +877,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         // (M16: registers kAQ + 32 x + 16 rt + 4 ks are Q'[x][rt][ks])
         constexpr int sb = decltype(SB)::value, rt = decltype(RT)::value, n = M16 ? 16 : 32;
         const float sc = row_lim(I, M16 ? 2 * sb + rt : sb) >= 0 ? scale2 : 0.0f;
-        sfor<n>([&](auto E) {
+        sfor<(M16 ? 4 * kKS : n)>([&](auto E) {
           constexpr int idx = kAQ + 32 * sb + n * rt + decltype(E)::value;
           const uint32_t v = acc_read_u32<idx>();
           acc_write<idx>(pw_pack<T>(pw_lo<T>(v) * sc, pw_hi<T>(v) * sc));
@@ -995,7 +1003,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     sfor<2>([&](auto X) __attribute__((always_inline)) {
       sfor<2>([&](auto RT) __attribute__((always_inline)) {
         constexpr int x = decltype(X)::value, rt = decltype(RT)::value;
-        sfor<4>([&](auto KS) __attribute__((always_inline)) {
+        sfor<kKS>([&](auto KS) __attribute__((always_inline)) {
           constexpr int ks = decltype(KS)::value, KA = kAK + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
           if constexpr (ks == 0) ops16::template qk_zero<KA, QA>(S16[0][rt][x]); else ops16::template qk_acc<KA, QA>(S16[0][rt][x]);
         });
@@ -1133,7 +1141,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto qk16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kt = g >> 3, ks = (g >> 1) & 3, rt = g & 1;
     constexpr int KA = kAK + 16 * kt + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
-    if constexpr (ks == 0) {
+    if constexpr (ks >= kKS) return;              // (D = 64: a chain has two k-steps; the slot stays in the schedule, empty)
+    else if constexpr (ks == 0) {
       if constexpr (SC) ops16::template qk_zero_ho<KA, QA>(S16[0][rt][kt]);          // the raw score: the reference enters after the cap
       else ops16::template qk_ref_ho<KA, QA>(S16[0][rt][kt], R16[x][rt]);
     } else ops16::template qk_acc_ho<KA, QA>(S16[0][rt][kt]);
@@ -1180,7 +1189,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // MFMA g (0..31) of O_x += V^T.P_x^T: d tile g >> 2, 32-key block (g >> 1) & 1, row tile g & 1
   auto pv16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, db = (g >> 2) & 7, c = (g >> 1) & 1, rt = g & 1;
-    if constexpr (g < 32) ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]);
+    if constexpr (g < 32) { if constexpr (db < kDB) ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]); }      // (D = 64: output tiles 0 .. 3)
     else ops16::lsum_ho(L16[x][rt], ones16, pwv16[x][rt][c]);        // g = 32 .. 35: the row sums of this tile
   };
   // Instruction q (0..47) of sub-block x's exponential / pack stream. A 16-cycle matrix instruction leaves this wave ~7
@@ -1225,6 +1234,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #ifdef PW_ABL_LDS
     return;
 #endif
+    if constexpr (db >= kDB) return;
     const wu32x2_t v0 = lds_tr_b64<off>(v_rd16[db]);
     const wu32x2_t v1 = lds_tr_b64<off + 16 * ROWB>(v_rd16[db]);
     vfr16[db][c] = wu32x4_t{v0[0], v0[1], v1[0], v1[1]};
@@ -1234,6 +1244,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #ifdef PW_ABL_LDS
     return;
 #endif
+    if constexpr (ks >= kKS) return;
     lds_to_acc_b128<kAK + 16 * kt + 4 * ks, decltype(SLOT)::value + kt * 16 * ROWB>(k_rd16[ks]);
   };
 
@@ -1446,7 +1457,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         // one row tile's 32 output registers: scaled, packed, to `store(db, words)`
         auto tile_out = [&](auto RT, float inv, auto store) __attribute__((always_inline)) {
           constexpr int rt = decltype(RT)::value;
-          sfor<8>([&](auto DB) __attribute__((always_inline)) {
+          sfor<kDB>([&](auto DB) __attribute__((always_inline)) {
             constexpr int db = decltype(DB)::value, base = kAO + 64 * x + 32 * rt + 4 * db;
             const float o0 = acc_read<base>(), o1 = acc_read<base + 1>(), o2 = acc_read<base + 2>(), o3 = acc_read<base + 3>();
             pw_amax3(amax2[rt], o0, o1);
@@ -1486,12 +1497,13 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
             tq = __umul24(m, g_inv) >> 16;
             return __umul24(tq, st_b) + __umul24(m - __umul24(tq, (uint32_t)G), sh_b) + (uint32_t)och * 16u;   // (full-rate 24-bit multiplies: strides are below 2^22 elements)
           };
+          const bool och_ok = D == 128 || och <= kCM;          // (D = 64: a row is eight chunks, half the lanes have nothing to store)
           if (__builtin_expect(whole_block, 1)) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
+            for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); if (och_ok) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); if (tq < tok_left) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
+            for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); if (och_ok && tq < tok_left) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
           }
         }
         // the two row tiles' magnitude checks, after the stores are on their way (four cross-lane steps in one go)
@@ -1759,7 +1771,8 @@ bool prefill_pw_applicable(const mi355_attn_params& p) {
   const int64_t lim = (int64_t)1 << 22;
   const bool strides_ok = p.q_stride_token >= 0 && p.q_stride_token < lim && p.q_stride_head >= 0 && p.q_stride_head < lim &&
                           p.out_stride_token >= 0 && p.out_stride_token < lim && p.out_stride_head >= 0 && p.out_stride_head < lim;
-  return !feat && strides_ok && p.head_size == 128 && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && p.kv_dtype == p.q_dtype;
+  const bool d_ok = p.head_size == 128 || (p.head_size == 64 && p.softcap == 0.0f && !p.alibi_slopes && p.sliding_window <= 0);   // (D = 64: plain)
+  return !feat && strides_ok && d_ok && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && p.kv_dtype == p.q_dtype;
 }
 
 template <typename T>
@@ -1808,7 +1821,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
   static const bool m16_env = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
   const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f, al = p.alibi_slopes != nullptr;
-  const bool m16 = m16_env || sw || sc || al || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, no window, no soft-cap, no ALiBi
+  const bool d64 = p.head_size == 64;
+  const bool m16 = m16_env || sw || sc || al || d64 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi
   auto go = [&](auto kernel, std::atomic<uint64_t>& opted) -> int {
     const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
     if (rc1 != MI355_OK) return rc1;
@@ -1816,7 +1830,10 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
     return MI355_OK;
   };
   int rc_l = MI355_OK;
-  if (al) {
+  if (d64) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, false, false, false, 64>, o);
+  } else if (al) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, false, false, true>, o);
   } else if (sc && sw) {
