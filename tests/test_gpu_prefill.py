@@ -555,15 +555,16 @@ def test_prefill_f16_rows_whose_scores_sit_far_from_zero(gains):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hq,hk", [(8, 2), (6, 2), (16, 1)])
-def test_prefill_head_size_64_on_the_64_rows_per_wave_kernel(dtype, hq, hk):
-    """Head size 64 on the same kernel: the geometry of head size 128 with half-empty LDS rows - two k-steps per score chain,
-    four 16-column output tiles, the absent matrix instructions' slots left empty. Ragged chunked prefill, a decode row,
+@pytest.mark.parametrize("hd", [64, 96])
+def test_prefill_head_size_64_on_the_64_rows_per_wave_kernel(dtype, hq, hk, hd):
+    """Head sizes 64 and 96 on the same kernel: the geometry of head size 128 with partly empty LDS rows - two / three k-steps
+    per score chain, four / six 16-column output tiles, the absent matrix instructions' slots left empty. Ragged chunked prefill, a decode row,
     groups of 4 / 3 / 16 query heads, rows with larger scores, lse against float64. (The f32 routine with half its lanes
     idle: test_prefill_head_size_64_rows_through_the_f32_routine.)"""
     import gpu_util
 
     query_lens, kv_lens = [700, 270, 1, 2100], [2300, 2100, 2500, 2100]
-    inp = orc.make_paged_inputs(61 + hq, query_lens, kv_lens, hq, hk, 64, 16, dtype)
+    inp = orc.make_paged_inputs(61 + hq + hd, query_lens, kv_lens, hq, hk, hd, 16, dtype)
     q = inp["q"].float()
     q[5::16] *= 6.0                        # every sixteenth row: scores 6 x larger
     inp["q"] = q.to(dtype)
@@ -629,16 +630,16 @@ def test_prefill_head_size_64_rows_through_the_f32_routine():
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("feature", ["softcap", "alibi"])
+@pytest.mark.parametrize("feature", ["softcap", "alibi", "d64"])
 def test_long_featured_prefill_over_an_fp8_cache(feature):
-    """Soft-cap or ALiBi over an fp8 flash-layout cache: the dequantising pass, then the feature's instantiation of the
-    64-rows-per-wave kernel on the 16-bit scratch (`repack+prefill_mfma_pw_sc` / `_al`)."""
+    """Soft-cap, ALiBi or head size 64 over an fp8 flash-layout cache: the dequantising pass, then the matching instantiation of
+    the 64-rows-per-wave kernel on the 16-bit scratch (`repack+prefill_mfma_pw_sc` / `_al` / `_pw`)."""
     import gpu_util
 
     query_lens, kv_lens = [2100, 1500, 1], [2100, 2600, 2500]
     ks, vs = 0.0237, 0.041
     dtype, hq = torch.bfloat16, 8
-    inp = orc.make_paged_inputs(73, query_lens, kv_lens, hq, 2, 128, 16, dtype, kv_dtype=torch.float8_e4m3fn, kv_scale=ks)
+    inp = orc.make_paged_inputs(73, query_lens, kv_lens, hq, 2, 64 if feature == "d64" else 128, 16, dtype, kv_dtype=torch.float8_e4m3fn, kv_scale=ks)
     slopes = torch.tensor([2.0 ** (-(i + 1) * 8.0 / hq) for i in range(hq)], dtype=torch.float32) if feature == "alibi" else None
     cap = 30.0 if feature == "softcap" else 0.0
     ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
@@ -654,7 +655,7 @@ def test_long_featured_prefill_over_an_fp8_cache(feature):
     torch.cuda.synchronize()
     kernel = _lib.last_kernel()
     if os.environ.get("MI355_PREFILL", "pw") == "pw":
-        assert kernel.startswith("repack+prefill_mfma_pw_sc+decode" if feature == "softcap" else "repack+prefill_mfma_pw_al+decode"), kernel
+        assert kernel.startswith({"softcap": "repack+prefill_mfma_pw_sc+decode", "alibi": "repack+prefill_mfma_pw_al+decode", "d64": "repack+prefill_mfma_pw+decode"}[feature]), kernel
     assert not torch.isnan(out).any()
     atol, rtol = golden_io.tolerance(dtype, torch.float8_e4m3fn)
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)

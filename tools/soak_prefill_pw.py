@@ -27,7 +27,10 @@ def case(rng):
     hk = rng.choice([1, 2, 4])
     g = rng.choice([1, 2, 3, 4, 5, 8, 12, 16])
     feat = rng.choice(["plain", "window", "softcap", "softcap+window", "alibi", "plain"])
-    return dict(q_lens=q_lens, kv_lens=kv_lens, hq=hk * g, hk=hk, page=rng.choice([16, 16, 32, 64]), dtype=rng.choice([torch.bfloat16, torch.float16]),
+    d = rng.choice([128, 128, 128, 64, 96])
+    if d != 128:
+        feat = "plain"                     # (head sizes 64 / 96 are on the 64-rows-per-wave kernel without features)
+    return dict(d=d, q_lens=q_lens, kv_lens=kv_lens, hq=hk * g, hk=hk, page=rng.choice([16, 16, 32, 64]), dtype=rng.choice([torch.bfloat16, torch.float16]),
                 window=rng.choice([9, 64, 300, 1000]) if "window" in feat else 0, softcap=rng.choice([20.0, 50.0]) if "softcap" in feat else 0.0,
                 alibi=feat == "alibi", kv_dtype=rng.choice([None, None, None, torch.float8_e4m3fn]))
 
@@ -40,11 +43,11 @@ def main():
         rng = random.Random(77000 + cid)
         c = case(rng)
         kw = dict(kv_dtype=c["kv_dtype"], kv_scale=0.5) if c["kv_dtype"] is not None else {}
-        inp = orc.make_paged_inputs(5000 + cid, c["q_lens"], c["kv_lens"], c["hq"], c["hk"], 128, c["page"], c["dtype"], **kw)
+        inp = orc.make_paged_inputs(5000 + cid, c["q_lens"], c["kv_lens"], c["hq"], c["hk"], c["d"], c["page"], c["dtype"], **kw)
         t = gpu_util.to_dev(inp)
         if c["alibi"]:
             t["alibi_slopes"] = torch.tensor([2.0 ** (-(i % 8 + 1)) for i in range(c["hq"])], dtype=torch.float32, device=gpu_util.DEV)
-        scale = 1.0 / math.sqrt(128)
+        scale = 1.0 / math.sqrt(c["d"])
         kvs = 0.5 if c["kv_dtype"] is not None else None
         n_tok = t["q"].shape[0]
         ref_lse = torch.full((n_tok, c["hq"]), float("nan"), dtype=torch.float32, device=gpu_util.DEV)

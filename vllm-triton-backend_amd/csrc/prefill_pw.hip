@@ -439,12 +439,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   static_assert(M16 || !SW, "the sliding window is built into the 16x16x32 instantiation only");
   static_assert(M16 || !SC, "soft-cap is built into the 16x16x32 instantiation only");
   static_assert(!AL || (M16 && !SW && !SC), "ALiBi: the plain 16x16x32 instantiation only");
-  // D = 64: the SAME geometry with half-empty rows - a key row still owns a 256-byte LDS row and sixteen chunk positions,
-  // of which the swizzle fills eight with the row's eight 16-byte chunks (the other eight lanes of a row's LDS-DMA re-read
-  // those chunks: same addresses, coalesced, never read back); k-steps 2 and 3 of every score chain, output tiles 4..7
-  // and their fragment reads simply do not exist. Every instruction table, ring and seam stays as it is.
-  static_assert(D == 128 || (D == 64 && M16 && !SW && !SC && !AL), "head size 64: the plain 16x16x32 instantiation only");
-  constexpr int kKS = D / 32, kDB = D / 16, kCM = D / 8 - 1;      // k-steps of a score chain, 16-column output tiles, chunk mask of a row
+  // D = 64 / 96: the SAME geometry with partly empty rows - a key row still owns a 256-byte LDS row and sixteen chunk
+  // positions, of which the swizzle fills eight / twelve with the row's 16-byte chunks (the other lanes of a row's LDS-DMA
+  // re-read its last chunk: same address, coalesced, never read back); the last k-steps of every score chain, the last
+  // output tiles and their fragment reads simply do not exist. Every instruction table, ring and seam stays as it is.
+  static_assert(D == 128 || ((D == 64 || D == 96) && M16 && !SW && !SC && !AL), "head sizes 64 and 96: the plain 16x16x32 instantiation only");
+  constexpr int kKS = D / 32, kDB = D / 16, kCM = D / 8 - 1;      // k-steps of a score chain, 16-column output tiles, a row's last chunk
   using ops = pw_ops<bf16_t>;                  // the 32x32x16 form exists for bf16 only (its fixed reference 0 needs bf16's exponent range)
   using ops16 = pw_ops16<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     asm volatile("" : "+v"(lo));
     const int r4 = lo >> 4, c16 = lo & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + (((c16 ^ R) & kCM) << 4)); }
+    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + (min(c16 ^ R, kCM) << 4)); }
   };
   auto set_v_offsets = [&](int maxr) {
     int lo = lane;
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     // V's chunk swizzle follows the transposed read of the instantiation: half a wave of it covers rows 0..3 x four chunks
     // (32x32x16 form: f = 4 (R & 3) | (R >> 2) & 3 keeps the rows apart) or rows 0..7 x two chunks (16x16x32 form: f = 2 (R & 7);
     // the other form's f there puts rows r and r + 4 on the same banks: 34 % of LDS-active cycles were conflicts)
-    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; const int f = M16 ? 2 * (R & 7) : (((R & 3) << 2) | ((R >> 2) & 3)); voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + (((c16 ^ f) & kCM) << 4)); }
+    for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; const int f = M16 ? 2 * (R & 7) : (((R & 3) << 2) | ((R >> 2) & 3)); voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + (min(c16 ^ f, kCM) << 4)); }
   };
   set_k_offsets(15);
   set_v_offsets(15);
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   auto qk16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, kt = g >> 3, ks = (g >> 1) & 3, rt = g & 1;
     constexpr int KA = kAK + 16 * kt + 4 * ks, QA = kAQ + 32 * x + 16 * rt + 4 * ks;
-    if constexpr (ks >= kKS) return;              // (D = 64: a chain has two k-steps; the slot stays in the schedule, empty)
+    if constexpr (ks >= kKS) return;              // (D = 64 / 96: a chain has two / three k-steps; the slot stays in the schedule, empty)
     else if constexpr (ks == 0) {
       if constexpr (SC) ops16::template qk_zero_ho<KA, QA>(S16[0][rt][kt]);          // the raw score: the reference enters after the cap
       else ops16::template qk_ref_ho<KA, QA>(S16[0][rt][kt], R16[x][rt]);
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // MFMA g (0..31) of O_x += V^T.P_x^T: d tile g >> 2, 32-key block (g >> 1) & 1, row tile g & 1
   auto pv16 = [&](auto X, auto GC) __attribute__((always_inline)) {
     constexpr int x = decltype(X)::value, g = decltype(GC)::value, db = (g >> 2) & 7, c = (g >> 1) & 1, rt = g & 1;
-    if constexpr (g < 32) { if constexpr (db < kDB) ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]); }      // (D = 64: output tiles 0 .. 3)
+    if constexpr (g < 32) { if constexpr (db < kDB) ops16::template pv<kAO + 64 * x + 32 * rt + 4 * db>(vfr16[db][c], pwv16[x][rt][c]); }      // (D = 64 / 96: output tiles 0 .. 3 / 0 .. 5)
     else ops16::lsum_ho(L16[x][rt], ones16, pwv16[x][rt][c]);        // g = 32 .. 35: the row sums of this tile
   };
   // Instruction q (0..47) of sub-block x's exponential / pack stream. A 16-cycle matrix instruction leaves this wave ~7
@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
             tq = __umul24(m, g_inv) >> 16;
             return __umul24(tq, st_b) + __umul24(m - __umul24(tq, (uint32_t)G), sh_b) + (uint32_t)och * 16u;   // (full-rate 24-bit multiplies: strides are below 2^22 elements)
           };
-          const bool och_ok = D == 128 || och <= kCM;          // (D = 64: a row is eight chunks, half the lanes have nothing to store)
+          const bool och_ok = D == 128 || och <= kCM;          // (D = 64 / 96: a row is eight / twelve chunks, the other lanes have nothing to store)
           if (__builtin_expect(whole_block, 1)) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { uint32_t tq; const uint32_t off = row_off(j, tq); if (och_ok) __builtin_nontemporal_store(rows[j], (grow_t)(out0 + off)); }
@@ -1771,7 +1771,7 @@ bool prefill_pw_applicable(const mi355_attn_params& p) {
   const int64_t lim = (int64_t)1 << 22;
   const bool strides_ok = p.q_stride_token >= 0 && p.q_stride_token < lim && p.q_stride_head >= 0 && p.q_stride_head < lim &&
                           p.out_stride_token >= 0 && p.out_stride_token < lim && p.out_stride_head >= 0 && p.out_stride_head < lim;
-  const bool d_ok = p.head_size == 128 || (p.head_size == 64 && p.softcap == 0.0f && !p.alibi_slopes && p.sliding_window <= 0);   // (D = 64: plain)
+  const bool d_ok = p.head_size == 128 || ((p.head_size == 64 || p.head_size == 96) && p.softcap == 0.0f && !p.alibi_slopes && p.sliding_window <= 0);   // (D = 64 / 96: plain)
   return !feat && strides_ok && d_ok && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && p.kv_dtype == p.q_dtype;
 }
 
@@ -1821,8 +1821,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
   static const bool m16_env = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
   const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f, al = p.alibi_slopes != nullptr;
-  const bool d64 = p.head_size == 64;
-  const bool m16 = m16_env || sw || sc || al || d64 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi
+  const bool d64 = p.head_size == 64, d96 = p.head_size == 96;
+  const bool m16 = m16_env || sw || sc || al || d64 || d96 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi
   auto go = [&](auto kernel, std::atomic<uint64_t>& opted) -> int {
     const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
     if (rc1 != MI355_OK) return rc1;
@@ -1833,6 +1833,9 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   if (d64) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, false, false, false, 64>, o);
+  } else if (d96) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, false, false, false, 96>, o);
   } else if (al) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, false, false, true>, o);
