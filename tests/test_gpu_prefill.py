@@ -555,8 +555,8 @@ def test_prefill_f16_rows_whose_scores_sit_far_from_zero(gains):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hq,hk", [(8, 2), (6, 2), (16, 1)])
-@pytest.mark.parametrize("hd", [64, 96])
-def test_prefill_head_size_64_on_the_64_rows_per_wave_kernel(dtype, hq, hk, hd):
+@pytest.mark.parametrize("hd,window", [(64, 0), (96, 0), (96, 600)])
+def test_prefill_head_size_64_on_the_64_rows_per_wave_kernel(dtype, hq, hk, hd, window):
     """Head sizes 64 and 96 on the same kernel: the geometry of head size 128 with partly empty LDS rows - two / three k-steps
     per score chain, four / six 16-column output tiles, the absent matrix instructions' slots left empty. Ragged chunked prefill, a decode row,
     groups of 4 / 3 / 16 query heads, rows with larger scores, lse against float64. (The f32 routine with half its lanes
@@ -564,26 +564,26 @@ def test_prefill_head_size_64_on_the_64_rows_per_wave_kernel(dtype, hq, hk, hd):
     import gpu_util
 
     query_lens, kv_lens = [700, 270, 1, 2100], [2300, 2100, 2500, 2100]
-    inp = orc.make_paged_inputs(61 + hq + hd, query_lens, kv_lens, hq, hk, hd, 16, dtype)
+    inp = orc.make_paged_inputs(61 + hq + hd + window, query_lens, kv_lens, hq, hk, hd, 16, dtype)
     q = inp["q"].float()
     q[5::16] *= 6.0                        # every sixteenth row: scores 6 x larger
     inp["q"] = q.to(dtype)
     ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
-                                       inp["scale"], mode="2d", block_n=64)
+                                       inp["scale"], sliding_window=window, mode="2d", block_n=64)
     _, ref_lse = orc.dense_attention_fp64(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
-                                          inp["scale"], return_lse=True)
+                                          inp["scale"], sliding_window=window, return_lse=True)
     d = gpu_util.to_dev(inp)
     lse = torch.full((inp["q"].shape[0], hq), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
     from mi355_attn import _lib
     from mi355_attn.kernels.unified import fill_attn_params, launch
     out = torch.full_like(d["q"], float("nan"))
     p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
-                               (-1, -1), d["block_table"], 0.0, None, None, None, None, lse=lse, num_segments=1)
+                               (window - 1, 0) if window else (-1, -1), d["block_table"], 0.0, None, None, None, None, lse=lse, num_segments=1)
     launch(p, gpu_util.DEV)
     torch.cuda.synchronize()
     kernel = _lib.last_kernel()
     if os.environ.get("MI355_PREFILL", "pw") == "pw":
-        assert kernel.startswith("prefill_mfma_pw"), kernel
+        assert kernel.startswith("prefill_mfma_pw_sw" if window else "prefill_mfma_pw"), kernel
     assert not torch.isnan(out).any()
     atol, rtol = golden_io.tolerance(dtype)
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // positions, of which the swizzle fills eight / twelve with the row's 16-byte chunks (the other lanes of a row's LDS-DMA
   // re-read its last chunk: same address, coalesced, never read back); the last k-steps of every score chain, the last
   // output tiles and their fragment reads simply do not exist. Every instruction table, ring and seam stays as it is.
-  static_assert(D == 128 || ((D == 64 || D == 96) && M16 && !SW && !SC && !AL), "head sizes 64 and 96: the plain 16x16x32 instantiation only");
+  static_assert(D == 128 || ((D == 64 || D == 96) && M16 && !SC && !AL && (!SW || D == 96)), "head sizes 64 and 96: the plain 16x16x32 instantiation (96: or with a sliding window)");
   constexpr int kKS = D / 32, kDB = D / 16, kCM = D / 8 - 1;      // k-steps of a score chain, 16-column output tiles, a row's last chunk
   using ops = pw_ops<bf16_t>;                  // the 32x32x16 form exists for bf16 only (its fixed reference 0 needs bf16's exponent range)
   using ops16 = pw_ops16<T>;
@@ -1771,7 +1771,8 @@ bool prefill_pw_applicable(const mi355_attn_params& p) {
   const int64_t lim = (int64_t)1 << 22;
   const bool strides_ok = p.q_stride_token >= 0 && p.q_stride_token < lim && p.q_stride_head >= 0 && p.q_stride_head < lim &&
                           p.out_stride_token >= 0 && p.out_stride_token < lim && p.out_stride_head >= 0 && p.out_stride_head < lim;
-  const bool d_ok = p.head_size == 128 || ((p.head_size == 64 || p.head_size == 96) && p.softcap == 0.0f && !p.alibi_slopes && p.sliding_window <= 0);   // (D = 64 / 96: plain)
+  // (D = 64 / 96: plain; 96 - Phi-3's head size - also with a sliding window)
+  const bool d_ok = p.head_size == 128 || ((p.head_size == 64 || p.head_size == 96) && p.softcap == 0.0f && !p.alibi_slopes && (p.sliding_window <= 0 || p.head_size == 96));
   return !feat && strides_ok && d_ok && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && p.kv_dtype == p.q_dtype;
 }
 
@@ -1833,6 +1834,9 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   if (d64) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, false, false, false, 64>, o);
+  } else if (d96 && sw) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, true, false, false, 96>, o);
   } else if (d96) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, false, false, false, 96>, o);
