@@ -1464,7 +1464,9 @@ bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
   // (soft-cap and ALiBi: from 512 keys on - the alternative is the register-staged kernel's feature instantiation, which the
   // SC / AL instantiations beat at every short shape measured: 1 x 1024 42 / 31 us against 58, 8 x 512 55 / 44 against 66,
   // 1 x 1536 58 / 40 against 86)
-  const int min_keys = (p.softcap > 0.0f || p.alibi_slopes) ? 512 : 2048;
+  // (head sizes 96 / 64: the alternative is the register-staged kernel too - 1 x 1024 24 against 30 us, 4 x 1024 45 against 60
+  // at 96; 1 x 1536 28 against 31 at 64)
+  const int min_keys = (p.softcap > 0.0f || p.alibi_slopes) ? 512 : p.head_size == 96 ? 1024 : p.head_size == 64 ? 1536 : 2048;
   const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= min_keys;
   return pinned ? (!ks || ks->wide) : use_pw;
 }
