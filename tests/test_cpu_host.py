@@ -412,21 +412,23 @@ def test_prefill_pw_kernel_keeps_the_compiler_out_of_the_accumulator_registers(t
                     src, "-o", str(out)], check=True, capture_output=True, timeout=900)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py"), str(out), "prefill_pw_kernel"], capture_output=True, text=True, check=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("compiler accvgpr/scratch outside asm:")]
-    # every instantiation: {bf16, f16} x 16x16x32 x ({plain, sliding window} x {plain, soft-cap} + ALiBi + head sizes 64 and 96, 96 also with a window) and the bf16 32x32x16 form (MI355_PW_M16=0)
-    assert len(line) == 17, r.stdout[-2000:]
+    # every instantiation: {bf16, f16} x 16x16x32 x ({plain, sliding window} x {plain, soft-cap} + ALiBi + head sizes 64, 80 and 96, 96 also with a window) and the bf16 32x32x16 form (MI355_PW_M16=0)
+    assert len(line) == 19, r.stdout[-2000:]
     assert all(l.split(":")[1].split()[0] == "0" for l in line), r.stdout[-2000:]
     # the steady tile iterations (the regions between two barriers that hold a tile's matrix instructions: 136 in the
     # 16x16x32 instantiations, 64 in the other): the hand-owned registers leave the compiler nothing to pad or copy there
     import ast
     names = [l for l in r.stdout.splitlines() if l.startswith("== ")]
     regions = [ast.literal_eval(l.split(":", 1)[1].strip()) for l in r.stdout.splitlines() if l.startswith("regions between barriers")]
-    assert len(regions) == len(names) == 17
+    assert len(regions) == len(names) == 19
     for name, regs in zip(names, regions):
         per_tile = 136 if "ELb1EL" in name.split("prefill_pw_kernel")[1][:24] else 64          # <T, M16 = true, SW, SC, AL, D>
         if "ELi64EEEv" in name:
             per_tile = 72                                                                       # head size 64: 2 x (16 + 16 + 4) matrix instructions
         if "ELi96EEEv" in name:
             per_tile = 104                                                                      # head size 96: 2 x (24 + 24 + 4)
+        if "ELi80EEEv" in name:
+            per_tile = 96                                                                       # head size 80: 2 x (24 + 20 + 4)
         steady = [x for x in regs if x[0] == per_tile]
         assert len(steady) >= 3, (name, regs)
         # compiler s_nops (was ~45 per tile); the ALiBi instantiation builds its per-tile C operands in compiler-visible code: a few more

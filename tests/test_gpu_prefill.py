@@ -555,7 +555,7 @@ def test_prefill_f16_rows_whose_scores_sit_far_from_zero(gains):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hq,hk", [(8, 2), (6, 2), (16, 1)])
-@pytest.mark.parametrize("hd,window", [(64, 0), (96, 0), (96, 600)])
+@pytest.mark.parametrize("hd,window", [(64, 0), (80, 0), (96, 0), (96, 600)])
 def test_prefill_head_size_64_on_the_64_rows_per_wave_kernel(dtype, hq, hk, hd, window):
     """Head sizes 64 and 96 on the same kernel: the geometry of head size 128 with partly empty LDS rows - two / three k-steps
     per score chain, four / six 16-column output tiles, the absent matrix instructions' slots left empty. Ragged chunked prefill, a decode row,

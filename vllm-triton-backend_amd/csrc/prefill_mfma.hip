@@ -1466,7 +1466,7 @@ bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
   // 1 x 1536 58 / 40 against 86)
   // (head sizes 96 / 64: the alternative is the register-staged kernel too - 1 x 1024 24 against 30 us, 4 x 1024 45 against 60
   // at 96; 1 x 1536 28 against 31 at 64)
-  const int min_keys = (p.softcap > 0.0f || p.alibi_slopes) ? 512 : p.head_size == 96 ? 1024 : p.head_size == 64 ? 1536 : 2048;
+  const int min_keys = (p.softcap > 0.0f || p.alibi_slopes) ? 512 : (p.head_size == 96 || p.head_size == 80) ? 1024 : p.head_size == 64 ? 1536 : 2048;
   const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= min_keys;
   return pinned ? (!ks || ks->wide) : use_pw;
 }

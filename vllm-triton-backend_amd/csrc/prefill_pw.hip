@@ -443,8 +443,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   // positions, of which the swizzle fills eight / twelve with the row's 16-byte chunks (the other lanes of a row's LDS-DMA
   // re-read its last chunk: same address, coalesced, never read back); the last k-steps of every score chain, the last
   // output tiles and their fragment reads simply do not exist. Every instruction table, ring and seam stays as it is.
-  static_assert(D == 128 || ((D == 64 || D == 96) && M16 && !SC && !AL && (!SW || D == 96)), "head sizes 64 and 96: the plain 16x16x32 instantiation (96: or with a sliding window)");
-  constexpr int kKS = D / 32, kDB = D / 16, kCM = D / 8 - 1;      // k-steps of a score chain, 16-column output tiles, a row's last chunk
+  static_assert(D == 128 || ((D == 64 || D == 80 || D == 96) && M16 && !SC && !AL && (!SW || D == 96)), "head sizes 64, 80 and 96: the plain 16x16x32 instantiation (96: or with a sliding window)");
+  // k-steps of a score chain (D = 80: the third covers 16 of its 32 columns - lane groups 0 and 1 of the query rows' fragment,
+  // the other two hold zeros and meet re-read, finite key chunks), 16-column output tiles, a row's last chunk
+  constexpr int kTailG = (D % 32) / 8, kKS = D / 32 + (kTailG ? 1 : 0), kDB = D / 16, kCM = D / 8 - 1;
   using ops = pw_ops<bf16_t>;                  // the 32x32x16 form exists for bf16 only (its fixed reference 0 needs bf16's exponent range)
   using ops16 = pw_ops16<T>;
   constexpr int ROWB = 256;                    // bytes per key row (D = 128), 16 chunks of 16 B
@@ -717,7 +719,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         int tok_local, hq;
         row_of(I, rt4, tok_local, hq);
         const uint32_t off = (uint32_t)(((min(tok_local, I.q_len - 1) - I.tok0) * sa.q_st + (hq - head * sa.G) * sa.q_sh + 8 * (lane_o >> 4)) * 2);
-        sfor<kKS>([&](auto KS) { constexpr int ks = decltype(KS)::value; pw_gload16_acc<kAQ + 16 * rt4 + 4 * ks, 64 * ks>(off, qb); });
+        // (a partial last k-step: the lane groups past the row's end re-read its last piece; their registers are zeroed on conversion)
+        const uint32_t off_tail = kTailG ? off - 16u * (uint32_t)max((lane_o >> 4) - (kTailG - 1), 0) : off;
+        sfor<kKS>([&](auto KS) { constexpr int ks = decltype(KS)::value; pw_gload16_acc<kAQ + 16 * rt4 + 4 * ks, 64 * ks>((kTailG && ks == kKS - 1) ? off_tail : off, qb); });
       });
     } else if (part <= 0)
     sfor<2>([&](auto SB) {
@@ -877,10 +881,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         // (M16: registers kAQ + 32 x + 16 rt + 4 ks are Q'[x][rt][ks])
         constexpr int sb = decltype(SB)::value, rt = decltype(RT)::value, n = M16 ? 16 : 32;
         const float sc = row_lim(I, M16 ? 2 * sb + rt : sb) >= 0 ? scale2 : 0.0f;
+        const float sc_tail = (kTailG && (lane_o >> 4) >= kTailG) ? 0.0f : sc;          // (D = 80: columns 80 .. 95 of the third k-step do not exist)
         sfor<(M16 ? 4 * kKS : n)>([&](auto E) {
           constexpr int idx = kAQ + 32 * sb + n * rt + decltype(E)::value;
           const uint32_t v = acc_read_u32<idx>();
-          acc_write<idx>(pw_pack<T>(pw_lo<T>(v) * sc, pw_hi<T>(v) * sc));
+          const float sce = (M16 && kTailG && decltype(E)::value / 4 == kKS - 1) ? sc_tail : sc;
+          acc_write<idx>(pw_pack<T>(pw_lo<T>(v) * sce, pw_hi<T>(v) * sce));
         });
       });
     });
@@ -1772,7 +1778,7 @@ bool prefill_pw_applicable(const mi355_attn_params& p) {
   const bool strides_ok = p.q_stride_token >= 0 && p.q_stride_token < lim && p.q_stride_head >= 0 && p.q_stride_head < lim &&
                           p.out_stride_token >= 0 && p.out_stride_token < lim && p.out_stride_head >= 0 && p.out_stride_head < lim;
   // (D = 64 / 96: plain; 96 - Phi-3's head size - also with a sliding window)
-  const bool d_ok = p.head_size == 128 || ((p.head_size == 64 || p.head_size == 96) && p.softcap == 0.0f && !p.alibi_slopes && (p.sliding_window <= 0 || p.head_size == 96));
+  const bool d_ok = p.head_size == 128 || ((p.head_size == 64 || p.head_size == 80 || p.head_size == 96) && p.softcap == 0.0f && !p.alibi_slopes && (p.sliding_window <= 0 || p.head_size == 96));
   return !feat && strides_ok && d_ok && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && p.kv_dtype == p.q_dtype;
 }
 
@@ -1822,8 +1828,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
   static const bool m16_env = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
   const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f, al = p.alibi_slopes != nullptr;
-  const bool d64 = p.head_size == 64, d96 = p.head_size == 96;
-  const bool m16 = m16_env || sw || sc || al || d64 || d96 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi
+  const bool d64 = p.head_size == 64, d96 = p.head_size == 96, d80 = p.head_size == 80;
+  const bool m16 = m16_env || sw || sc || al || d64 || d96 || d80 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi
   auto go = [&](auto kernel, std::atomic<uint64_t>& opted) -> int {
     const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
     if (rc1 != MI355_OK) return rc1;
@@ -1834,6 +1840,9 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   if (d64) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, false, false, false, 64>, o);
+  } else if (d80) {
+    static std::atomic<uint64_t> o{0};
+    rc_l = go(prefill_pw_kernel<T, true, false, false, false, 80>, o);
   } else if (d96 && sw) {
     static std::atomic<uint64_t> o{0};
     rc_l = go(prefill_pw_kernel<T, true, true, false, false, 96>, o);

@@ -300,7 +300,7 @@ static bool fp8_prefill_through_scratch(const mi355_attn_params& p) {
   if (off || !is_fp8(p.kv_dtype) || p.k_new || p.max_seqlen_q <= 1 || p.max_seqlen_k < 2048) return false;
   // (soft-cap, and ALiBi by itself: the 64-rows-per-wave kernel's SC / AL instantiations serve them)
   if (p.alibi_slopes && (p.softcap > 0.0f || p.sliding_window > 0)) return false;
-  if (!(p.head_size == 128 || ((p.head_size == 64 || p.head_size == 96) && !p.alibi_slopes && p.softcap == 0.0f && (p.sliding_window <= 0 || p.head_size == 96)))) return false;   // (what prefill_pw_applicable serves)
+  if (!(p.head_size == 128 || ((p.head_size == 64 || p.head_size == 80 || p.head_size == 96) && !p.alibi_slopes && p.softcap == 0.0f && (p.sliding_window <= 0 || p.head_size == 96)))) return false;   // (what prefill_pw_applicable serves)
   const int64_t G = p.num_q_heads / p.num_kv_heads;
   return (int64_t)p.num_tokens * G >= (int64_t)4096 * p.num_seqs;
 }
