@@ -17,6 +17,7 @@ for b in 1 16; do
   run --batch $b --alibi
   run --batch $b --softcap 30 --kvdtype fp8
   run --batch $b --d 64
+  run --batch $b --d 80
   run --batch $b --d 256 --hq 16 --hk 8
   run --batch $b --d 96
 done
