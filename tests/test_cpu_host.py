@@ -406,11 +406,19 @@ def test_prefill_pw_kernel_keeps_the_compiler_out_of_the_accumulator_registers(t
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "vllm-triton-backend_amd", "csrc", "prefill_pw.hip")
-    out = tmp_path / "prefill_pw.s"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
-                    src, "-o", str(out)], check=True, capture_output=True, timeout=900)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py"), str(out), "prefill_pw_kernel"], capture_output=True, text=True, check=True)
+    # the kernel's instantiations are built in three translation units of the one source (see "host side" in prefill_pw.hip)
+    outs, procs = [], []
+    for tu in ("prefill_pw", "prefill_pw_feat", "prefill_pw_heads"):
+        outs.append(tmp_path / (tu + ".s"))
+        procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                                       os.path.join(ROOT, "vllm-triton-backend_amd", "csrc", tu + ".hip"), "-o", str(outs[-1])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for pr in procs:
+        log, _ = pr.communicate(timeout=900)
+        assert pr.returncode == 0, log.decode()[-3000:]
+    stdout = ""
+    for o in outs:
+        stdout += subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_audit.py"), str(o), "prefill_pw_kernel"], capture_output=True, text=True, check=True).stdout
+    r = type("R", (), {"stdout": stdout})
     line = [l for l in r.stdout.splitlines() if l.startswith("compiler accvgpr/scratch outside asm:")]
     # every instantiation: {bf16, f16} x 16x16x32 x ({plain, sliding window} x {plain, soft-cap} + ALiBi + head sizes 64, 80 and 96, 96 also with a window) and the bf16 32x32x16 form (MI355_PW_M16=0)
     assert len(line) == 19, r.stdout[-2000:]
@@ -435,8 +443,9 @@ def test_prefill_pw_kernel_keeps_the_compiler_out_of_the_accumulator_registers(t
         pads = 10 if "ELb0ELb0ELb1ELi128EEEv" in name else 4      # <.., SW = 0, SC = 0, AL = 1, D = 128>
         assert sum(1 for x in steady if x[1] <= pads) >= 3, (name, regs)
         assert sum(1 for x in steady if x[2] == 0) >= 2, (name, regs)          # compiler register copies
-    text = out.read_text()
-    assert "ScratchSize: 0" in text.split("prefill_pw_kernel")[-1] or ".private_segment_fixed_size: 0" in text
+    for o in outs:
+        text = o.read_text()
+        assert "ScratchSize: 0" in text.split("prefill_pw_kernel")[-1] or ".private_segment_fixed_size: 0" in text
 
 
 def test_head_size_256_prefill_keeps_the_compiler_out_of_its_accumulator_registers(tmp_path):

@@ -1774,6 +1774,48 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// The kernel's nineteen instantiations are built in THREE translation units of this one source (hipcc spends ~12 s on
+// each): prefill_pw.hip itself (PW_TU 0: the plain and sliding-window kernels of both dtypes, the 32x32x16 form, and all
+// host code), prefill_pw_feat.hip (PW_TU 1: soft-cap, ALiBi) and prefill_pw_heads.hip (PW_TU 2: head sizes 64 / 80 / 96),
+// which define PW_TU and include this file.
+#ifndef PW_TU
+#define PW_TU 0
+#endif
+
+template <typename K>
+static int pw_go(K kernel, const PwArgs& a, int num_kv_heads, hipStream_t stream, std::atomic<uint64_t>& opted) {
+  const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
+  if (rc1 != MI355_OK) return rc1;
+  hipLaunchKernelGGL(kernel, dim3(a.slots * num_kv_heads), dim3(256), (size_t)kPwLds, stream, a);
+  return MI355_OK;
+}
+template <typename T> int launch_pw_feat(const PwArgs& a, int num_kv_heads, bool sw, bool sc, bool al, hipStream_t stream);      // prefill_pw_feat.hip
+template <typename T> int launch_pw_heads(const PwArgs& a, int num_kv_heads, int head_size, bool sw, hipStream_t stream);       // prefill_pw_heads.hip
+
+#if PW_TU == 1
+template <typename T> int launch_pw_feat(const PwArgs& a, int num_kv_heads, bool sw, bool sc, bool al, hipStream_t stream) {
+  static std::atomic<uint64_t> o_al{0}, o_scw{0}, o_sc{0};
+  if (al) return pw_go(prefill_pw_kernel<T, true, false, false, true>, a, num_kv_heads, stream, o_al);
+  if (sc && sw) return pw_go(prefill_pw_kernel<T, true, true, true>, a, num_kv_heads, stream, o_scw);
+  return pw_go(prefill_pw_kernel<T, true, false, true>, a, num_kv_heads, stream, o_sc);
+}
+template int launch_pw_feat<bf16_t>(const PwArgs&, int, bool, bool, bool, hipStream_t);
+template int launch_pw_feat<f16_t>(const PwArgs&, int, bool, bool, bool, hipStream_t);
+#endif
+
+#if PW_TU == 2
+template <typename T> int launch_pw_heads(const PwArgs& a, int num_kv_heads, int head_size, bool sw, hipStream_t stream) {
+  static std::atomic<uint64_t> o64{0}, o80{0}, o96{0}, o96w{0};
+  if (head_size == 64) return pw_go(prefill_pw_kernel<T, true, false, false, false, 64>, a, num_kv_heads, stream, o64);
+  if (head_size == 80) return pw_go(prefill_pw_kernel<T, true, false, false, false, 80>, a, num_kv_heads, stream, o80);
+  if (sw) return pw_go(prefill_pw_kernel<T, true, true, false, false, 96>, a, num_kv_heads, stream, o96w);
+  return pw_go(prefill_pw_kernel<T, true, false, false, false, 96>, a, num_kv_heads, stream, o96);
+}
+template int launch_pw_heads<bf16_t>(const PwArgs&, int, int, bool, hipStream_t);
+template int launch_pw_heads<f16_t>(const PwArgs&, int, int, bool, hipStream_t);
+#endif
+
+#if PW_TU == 0
 
 // Preconditions beyond prefill_supported(): bf16 or f16, head size 128, a cache of the query type, G <= 256; a sliding
 // window and soft-cap are served, and ALiBi without either (with them: prefill_mfma_kernel's FEAT instantiation).
@@ -1838,43 +1880,20 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f, al = p.alibi_slopes != nullptr;
   const bool d64 = p.head_size == 64, d96 = p.head_size == 96, d80 = p.head_size == 80;
   const bool m16 = m16_env || sw || sc || al || d64 || d96 || d80 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi
-  auto go = [&](auto kernel, std::atomic<uint64_t>& opted) -> int {
-    const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
-    if (rc1 != MI355_OK) return rc1;
-    hipLaunchKernelGGL(kernel, dim3(a.slots * p.num_kv_heads), dim3(256), lds, stream, a);
-    return MI355_OK;
-  };
   int rc_l = MI355_OK;
-  if (d64) {
-    static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, false, false, false, 64>, o);
-  } else if (d80) {
-    static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, false, false, false, 80>, o);
-  } else if (d96 && sw) {
-    static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, true, false, false, 96>, o);
-  } else if (d96) {
-    static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, false, false, false, 96>, o);
-  } else if (al) {
-    static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, false, false, true>, o);
-  } else if (sc && sw) {
-    static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, true, true>, o);
-  } else if (sc) {
-    static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, false, true>, o);
+  if (d64 || d80 || d96) {
+    rc_l = launch_pw_heads<T>(a, p.num_kv_heads, p.head_size, sw, stream);
+  } else if (al || sc) {
+    rc_l = launch_pw_feat<T>(a, p.num_kv_heads, sw, sc, al, stream);
   } else if (m16 && sw) {
     static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, true>, o);
+    rc_l = pw_go(prefill_pw_kernel<T, true, true>, a, p.num_kv_heads, stream, o);
   } else if (m16) {
     static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, true, false>, o);
+    rc_l = pw_go(prefill_pw_kernel<T, true, false>, a, p.num_kv_heads, stream, o);
   } else if constexpr (__is_same(T, bf16_t)) {
     static std::atomic<uint64_t> o{0};
-    rc_l = go(prefill_pw_kernel<T, false, false>, o);
+    rc_l = pw_go(prefill_pw_kernel<T, false, false>, a, p.num_kv_heads, stream, o);
   }
   if (rc_l != MI355_OK) return rc_l;
   const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");
@@ -1886,5 +1905,6 @@ int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_sp
   if (p.q_dtype == MI355_F16) return launch_pw_t<f16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream);
   return launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream);
 }
+#endif   // PW_TU == 0
 
 }  // namespace mi355
