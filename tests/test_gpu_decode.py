@@ -27,6 +27,7 @@ def _check(inp, dtype, *, force, window=0, softcap=0.0, alibi=None, expect=None,
     atol, rtol = golden_io.tolerance(dtype, kv_dtype)
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    return kernel
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -328,3 +329,69 @@ def test_mixed_batch_splits_into_prefill_and_decode_launches():
     out2, kernel2 = gpu_util.run_unified(d, inp["scale"], force=2)
     assert kernel2.startswith("prefill_mfma") and "+" not in kernel2, kernel2
     torch.testing.assert_close(out2.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+# ---- multi-token decode steps on the PACK kernels (16 / G query tokens of a sequence share a wave's matrix columns) ----------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hk", [(32, 8), (8, 8), (16, 2), (6, 2), (64, 8), (10, 2)])
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_multi_token_decode_steps_share_one_key_stream(dtype, hq, hk, d):
+    """Speculative-decoding / MTP verification batches (a few query tokens per sequence, causal among themselves, over a
+    long context) run on the decode kernel with several tokens per work unit; every row must match the oracle - the
+    per-column key limits, ragged chunks (query lengths that are not multiples of the chunk), sequences of one token
+    and contexts of zero keys included."""
+    q_lens = [4, 1, 3, 2, 4, 4, 2, 1]
+    kv_lens = [700, 45, 3, 2, 4, 1030, 65, 1]            # contexts of 696, 44, 0, 0, 0, 1026, 63, 0 keys
+    inp = orc.make_paged_inputs(21, q_lens, kv_lens, hq, hk, d, 16, dtype)
+    # (selected explicitly: the dispatch itself packs only what ONE work unit per sequence holds, see the test below)
+    assert "pack" in _check(inp, dtype, force=3, expect="decode_s")
+
+
+@pytest.mark.parametrize("q_len", [2, 5, 8, 16])
+@pytest.mark.parametrize("segments", [1, 2, 7, 40])
+def test_multi_token_decode_split_counts_and_chunks_agree(q_len, segments):
+    """More tokens than one chunk holds (two work units per sequence and more - forced onto the decode path) and every
+    merge route: no split, the in-kernel merge, the merge launch."""
+    import gpu_util
+    from mi355_attn.kernels import unified as ua_mod
+
+    q_lens = [q_len, max(1, q_len - 1), q_len, 1]
+    kv_lens = [1500 + q_len, 33 + q_len, 257, 300]
+    inp = orc.make_paged_inputs(22 + q_len, q_lens, kv_lens, 32, 8, 128, 16, torch.bfloat16)
+    d = gpu_util.to_dev(inp)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], mode="3d")
+    out = torch.full_like(d["q"], float("nan"))
+    lse = torch.full((d["q"].shape[0], 32), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    p, keep = ua_mod.fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(q_lens), d["seqused_k"], max(kv_lens),
+                                      inp["scale"], (-1, -1), d["block_table"], 0.0, None, None, None, 3, num_segments=segments, lse=lse)
+    ua_mod.launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    from mi355_attn import _lib
+    assert "pack" in _lib.last_kernel()
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    assert torch.isfinite(lse).all()
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+def test_multi_token_decode_fp8_cache(kv_dtype):
+    q_lens, kv_lens = [4, 2, 3, 1], [900, 130, 3, 64]
+    inp = orc.make_paged_inputs(31, q_lens, kv_lens, 32, 8, 128, 16, torch.bfloat16, kv_dtype=kv_dtype, kv_scale=0.5)
+    kernel = _check(inp, torch.bfloat16, force=None, expect="decode_s", kv_dtype=kv_dtype, kv_scale=0.5)
+    assert "pack" in kernel and "fp8" in kernel
+
+
+def test_multi_token_decode_dispatch():
+    """The dispatch packs a batch whose longest query fits one work unit (16 / G tokens, rounded down to a power of two);
+    windows / soft-cap / ALiBi, more than 8 query heads per KV head and longer queries stay on their former paths."""
+    for hq, hk, q_lens in [(32, 8, [4, 1, 3]), (16, 2, [2, 2, 1]), (8, 8, [16, 9]), (6, 2, [4, 4])]:
+        inp = orc.make_paged_inputs(35, q_lens, [300 + q for q in q_lens], hq, hk, 128, 16, torch.bfloat16)
+        assert "pack" in _check(inp, torch.bfloat16, force=None), (hq, hk, q_lens)
+    inp = orc.make_paged_inputs(36, [3, 2], [300, 200], 16, 2, 128, 16, torch.bfloat16)      # G = 8: two tokens per unit
+    assert "pack" not in _check(inp, torch.bfloat16, force=None)
+    inp = orc.make_paged_inputs(32, [4, 4], [300, 200], 8, 2, 128, 16, torch.bfloat16)
+    assert "pack" not in _check(inp, torch.bfloat16, force=None, window=64)
+    inp = orc.make_paged_inputs(33, [2, 2], [300, 200], 32, 2, 128, 16, torch.bfloat16)
+    assert "pack" not in _check(inp, torch.bfloat16, force=None)
+    inp = orc.make_paged_inputs(34, [40, 33], [300, 200], 32, 8, 128, 16, torch.bfloat16)
+    assert "pack" not in _check(inp, torch.bfloat16, force=None)

@@ -93,6 +93,10 @@ static Path choose(const mi355_attn_params& p) {
   if (sel == MI355_SELECT_3D) return dec_ok ? Path::Decode : Path::Generic;
   if (sel == MI355_SELECT_2D) return pre_ok ? Path::Prefill : Path::Generic;
   if (p.max_seqlen_q <= 1 && dec_ok) return Path::Decode;
+  // multi-token decode steps (speculative decoding / MTP verification): a few query tokens per sequence share one
+  // stream of the sequence's K/V in the decode kernel's matrix columns. More tokens than one work unit holds would
+  // stream it once per unit (64 x 8 tokens x 8192 keys, 4 per unit: 838 us against the prefill kernel's 438).
+  if (dec_ok && decode_pack_shift(p) && p.max_seqlen_q <= (1 << decode_pack_shift(p))) return Path::Decode;
   // mixed batch: prefill rows on the MFMA Q-block kernel, query_len == 1 rows on the split-KV kernel
   // (what the reference's legacy glue does with two kernels, chunked_prefill_paged_decode:28-117;
   // its unified 2D kernel instead pads every decode row to a BLOCK_M-row Q block)

@@ -72,6 +72,9 @@ struct DecodeArgs {
   int by_seq;      // 1: work items enumerate sequences (only_decodes), 0: query tokens
   int d_valid;     // the real head size; columns d_valid .. D-1 of the kernel's head size are padding
   int unit_is_seq; // 1: every sequence has exactly one query token (max_seqlen_q == 1), so unit == token == sequence
+  int pack_tokens; // PACK kernels: query tokens of one sequence per work unit (a power of two <= 16 / G), else 0
+  int pack_shift;  // log2(pack_tokens)
+  int pack_cps;    // chunks (work units) per sequence: cdiv(max_seqlen_q, pack_tokens)
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated on the host
   uint32_t k_dx_stride, v_d_stride;   // legacy v0 layout only: K [page][Hk][D/8][slot][8], V [page][Hk][D][slot]
 };
@@ -159,9 +162,20 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
 // tile is one contiguous block there and its 16-byte pieces are exactly what the kernel wants: a K piece is 8
 // consecutive d of one key (parked like a flash-layout piece, only the global offset differs), a V piece is 8
 // consecutive keys of one d - V is parked d-major and the P.V operand is read with two plain 8-byte reads, no transpose.
-template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD, bool V0>
+// PACK: multi-token decode steps (speculative decoding / MTP verification: a few query tokens per sequence over a long
+// context). The 16 matrix columns of a wave hold the G query heads of pack_tokens = 16 / G (rounded down to a power of
+// two) CONSECUTIVE query tokens of one sequence instead of the G heads of one token: the sequence's K/V is streamed
+// once per pack_tokens tokens, and only the last tiles differ between the columns (column of token i sees keys up to
+// ctx_len + i: a per-lane key limit in the tail tiles' mask). Work units are (sequence, chunk of pack_tokens tokens),
+// cdiv(max_seqlen_q, pack_tokens) per sequence - ONE in the dispatched case, so that unit == sequence and the launch
+// has no empty units (the reference's Q-block enumeration, triton_unified_attention.py:32-52 with sequence i's blocks
+// starting at cu_seqlens_q[i] / BLOCK_Q + i, leaves every other unit empty on a batch of equal query lengths: with
+// the workgroups dealt round-robin to the XCDs half of them then stood idle, 64 x 4 tokens x 8192 keys 559 us against
+// 380); partials and outputs are addressed per column (token, head).
+template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD, bool V0, bool PACK = false>
 __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const DecodeArgs a) {
   static_assert(!V0 || (__is_same(T, KVT) && !PAD), "the v0 layout path serves same-type 16-bit caches of a built head size");
+  static_assert(!PACK || (!FEAT && !PAD && !V0), "packed query tokens: plain attention on a flash-layout cache of a built head size");
   constexpr bool FP8 = !__is_same(T, KVT);
   // tiles in flight HBM -> VGPR per wave: an fp8 tile is half the bytes of a 16-bit one, so two of
   // them are kept in flight to put the same number of bytes on the wire per CU
@@ -200,12 +214,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const int hq0 = head * a.group + 16 * qg;   // first query head of this wave
   const int G = min(16, a.group - 16 * qg);   // query heads of this wave
   const int g = lane & 15, grp = lane >> 4;
-  const bool g_ok = g < G;
-  const int hq = hq0 + g;
+  const int tq = PACK ? g / G : 0;            // PACK: column g = (token tq of the unit's chunk, query head g % G)
+  const int hcol = g - tq * G;
+  bool g_ok = PACK ? tq < a.pack_tokens : g < G;
+  const int hq = hq0 + hcol;
 
   // ---- Q fragments: B operand of S^T = K.Q^T: lane (g, grp) holds Q[g][32c + 8grp .. +7] --------
   s16x8_t qf[KSTEPS];
-  auto load_q = [&](int tok) {   // issued as early as the token is known: rides the same round trip as the lookups
+  auto load_q = [&](int tok) {   // issued as early as the token is known: rides the same round trip as the lookups (PACK: a per-lane token)
     const uint16_t* qp = (const uint16_t*)p.q + (int64_t)tok * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * grp;
 #pragma unroll
     for (int c = 0; c < KSTEPS; ++c) {
@@ -248,6 +264,22 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     ri.ctx_len = seq_len - 1;
     ri.n_keys = max(0, seq_len);
     ri.valid = true;
+  } else if constexpr (PACK) {
+    ri.seq = a.pack_cps == 1 ? unit : unit / a.pack_cps;
+    if (ri.seq >= p.num_seqs) return;
+    const int q_start = p.cu_seqlens_q[ri.seq];
+    ri.q_len = p.cu_seqlens_q[ri.seq + 1] - q_start;
+    ri.q_pos = (unit - ri.seq * a.pack_cps) << a.pack_shift;                       // first token of the chunk
+    if (ri.q_pos >= ri.q_len) return;                                              // (a sequence shorter than max_seqlen_q)
+    const int seq_len = p.seqused_k[ri.seq];
+    const int rows = min(a.pack_tokens, ri.q_len - ri.q_pos);
+    ri.ctx_len = seq_len - ri.q_len;
+    ri.token = q_start + ri.q_pos;
+    ri.n_keys = max(0, min(ri.ctx_len + ri.q_pos + rows, seq_len));               // the chunk's last token sees the most
+    ri.first_key = 0;
+    ri.valid = true;
+    g_ok = g_ok && tq < rows;
+    load_q(ri.token + (g_ok ? tq : 0));
   } else {
     ri = row_info(p, a.by_seq, unit);
     if (!ri.valid) return;
@@ -255,7 +287,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     if (p.write_new_kv && (p.slot_mapping || p.slot_mapping_i32))
       slot_sign = p.slot_mapping ? ((const int32_t*)(p.slot_mapping + ri.token))[1] : p.slot_mapping_i32[ri.token];
   }
-  const int token = ri.token, n_keys = ri.n_keys, first_key = ri.first_key, ctx_len = ri.ctx_len;
+  const int token = PACK ? ri.token + (g_ok ? tq : 0) : ri.token;   // PACK: this lane's column's token
+  const int n_keys = ri.n_keys, first_key = ri.first_key, ctx_len = ri.ctx_len;
+  // PACK: keys this lane's column sees / the fewest any column sees (tiles below it need no mask)
+  const int n_keys_col = PACK ? max(0, min(ctx_len + ri.q_pos + tq + 1, n_keys)) : n_keys;
+  const int n_keys_min = PACK ? max(0, min(ctx_len + ri.q_pos + 1, n_keys)) : n_keys;
 
   const int tile_lo = first_key / kTileKeys;
   const int tile_hi = (n_keys + kTileKeys - 1) / kTileKeys;
@@ -395,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
       for (int i = 0; i < NLD; ++i) kcur[h][i] = KR[h][i];
     const bool tail = (tile * kTileKeys + kTileKeys > n_keys);
-    if constexpr (!V0 && !FEAT) {
+    if constexpr (!V0 && !FEAT && !PACK) {
       // Fused cache write (write_new_kv): the wave whose split ends at the sequence's last tile owns the key of the
       // token being decoded. Its row of K and V comes from k_new / v_new instead of from the cache - quantised the way
       // reshape_and_cache_flash would have stored it - is written to its page, and takes part in this tile like any
@@ -482,7 +518,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
       for (int r = 0; r < 4; ++r) sv[h * 4 + r] = s[h][r];
     const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
-    const bool need_mask = tail || (FEAT && tile * kTileKeys < first_key);
+    const bool need_mask = (PACK ? tile * kTileKeys + kTileKeys > n_keys_min : tail) || (FEAT && tile * kTileKeys < first_key);
     if (plain && !need_mask) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) sv[j] *= scale2;
@@ -490,7 +526,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int key = tile * kTileKeys + (j >> 2) * 16 + grp * 4 + (j & 3);
-        sv[j] = key < n_keys ? sv[j] * scale2 : -INFINITY;
+        sv[j] = key < n_keys_col ? sv[j] * scale2 : -INFINITY;
       }
     } else {
 #pragma unroll
@@ -580,14 +616,20 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   constexpr int SLOT = D + kSlotPad;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ws_slots, 0, (int)a.ws_slot_bytes_total, 0x00020000);
   // slot rows are indexed by work unit: the query token, or the sequence when only decode rows are served
-  const uint32_t slot_g0 = (uint32_t)(((uint32_t)unit * p.num_q_heads + hq0) * a.num_splits);   // slot of (g = 0, split 0)
+  // (PACK: by query token, column by column)
+  const uint32_t slot_g0 = (uint32_t)(((uint32_t)(PACK ? ri.token : unit) * p.num_q_heads + hq0) * a.num_splits);   // slot of (g = 0, split 0)
+  auto slot_of_col = [&](int c) -> uint32_t {
+    if constexpr (PACK) { const int t = c / G; return slot_g0 + (uint32_t)((t * p.num_q_heads + (c - t * G)) * a.num_splits); }
+    return slot_g0 + (uint32_t)(c * a.num_splits);
+  };
   if (g_ok) {
-    const uint32_t so = ((slot_g0 + g * a.num_splits + split) * SLOT) * 4u;
+    const uint32_t so = ((slot_of_col(g) + split) * SLOT) * 4u;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o_acc[b]), rsrc, so + (16 * b + 4 * grp) * 4, 0, 16);
     if (grp == 0)
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(uint32_t, m_run), __builtin_bit_cast(uint32_t, l_tot)}, rsrc, so + D * 4, 0, 16);
+      // (PACK: a split whose tiles lie past a column's last key leaves that column an empty partial)
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(uint32_t, (PACK && !(l_tot > 0.0f)) ? -INFINITY : m_run), __builtin_bit_cast(uint32_t, l_tot)}, rsrc, so + D * 4, 0, 16);
   }
   if (!a.fused_merge) return;
 
@@ -606,10 +648,13 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   // of a split's loads in flight at once, and the NS partial merges meet through xor shuffles.
   // (m, l are two 4-byte loads: hipcc 7.2 narrows a raw_buffer_load_b64 whose halves are used apart
   // to ONE dword and hands the same register out for both.)
-  const int Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // G rounded up to a power of two
+  const int C = PACK ? G << a.pack_shift : G;                                 // columns in use
+  const int Gp = C <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(C - 1)));   // ... rounded up to a power of two
   const int NS = 16 / Gp;
   const int gm = g & (Gp - 1), sub = g / Gp;
-  const bool gm_ok = gm < G;
+  const int tqm = PACK ? gm / G : 0;                                          // column gm = (token tqm of the chunk, head gm % G)
+  const bool gm_ok = PACK ? (gm < C && tqm < min(a.pack_tokens, ri.q_len - ri.q_pos)) : gm < G;
+  const int tokm = ri.token + tqm, hqm = hq0 + gm - tqm * G;
   float m_acc = -INFINITY, l_acc = 0.0f;
   f32x4_t acc[DBLK];
 #pragma unroll
@@ -628,7 +673,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     // so the serial chain is ceil(active / (NS*U)) trips. A split past `active` is given an offset
     // beyond the descriptor's range (the load returns 0) and the weight of an empty partial.
     constexpr int U = D >= 128 ? 2 : 4;
-    const uint32_t s0 = ((slot_g0 + gm * a.num_splits) * SLOT) * 4u;
+    const uint32_t s0 = (slot_of_col(gm) * SLOT) * 4u;
     for (int base = sub; base < active; base += NS * U) {
       float m_in[U], l_in[U];
       f32x4_t v_in[U][DBLK];
@@ -657,9 +702,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   }
   if (gm_ok && sub == 0) {
     if (p.lse && grp == 0)
-      p.lse[(int64_t)token * p.lse_stride_token + hq0 + gm] = l_acc > 0.0f ? (m_acc + __builtin_amdgcn_logf(l_acc)) * kLn2 : -INFINITY;
+      p.lse[(int64_t)tokm * p.lse_stride_token + hqm] = l_acc > 0.0f ? (m_acc + __builtin_amdgcn_logf(l_acc)) * kLn2 : -INFINITY;
     const float inv = l_acc > 0.0f ? v_scale / l_acc : 0.0f;              // "0 if the overall sum is 0" (:828)
-    const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)(hq0 + gm) * p.out_stride_head;
+    const int64_t o = (int64_t)tokm * p.out_stride_token + (int64_t)hqm * p.out_stride_head;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
       if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
@@ -686,8 +731,12 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
 
   const mi355_attn_params& p = a.p;
   const int hq = blockIdx.y, tid = threadIdx.x;
-  const RowInfo ri = row_info(p, a.by_seq, blockIdx.x);
+  RowInfo ri = row_info(p, a.by_seq, blockIdx.x);
   if (!ri.valid) return;
+  if (a.pack_tokens) {   // the token's partials were written by its chunk's waves, whose splits follow the chunk's last token
+    const int q0 = (ri.q_pos >> a.pack_shift) << a.pack_shift;
+    ri.n_keys = max(0, min(ri.ctx_len + min(q0 + a.pack_tokens, ri.q_len), ri.ctx_len + ri.q_len));
+  }
   const int tile_lo = ri.first_key / kTileKeys;
   const int tile_hi = (ri.n_keys + kTileKeys - 1) / kTileKeys;
   const int n_tiles = max(0, tile_hi - tile_lo);
@@ -796,7 +845,29 @@ struct SplitPlan { int num_splits, tiles_per_split; };
 // streaming the head's K/V (neighbouring waves: the second reader hits in L2).
 static int query_head_groups(const mi355_attn_params& p) { return (p.num_q_heads / p.num_kv_heads + 15) / 16; }
 
-static long decode_units(const mi355_attn_params& p) { return p.only_decodes ? p.num_seqs : p.num_tokens; }
+// Multi-token decode steps on the PACK kernels: log2 of the query tokens one work unit holds (0 = not packed). Plain
+// attention (no window / soft-cap / ALiBi), flash layout, a built head size, at most 8 query heads per KV head.
+// MI355_DECODE_PACK=0 switches it off (A/B).
+int decode_pack_shift(const mi355_attn_params& p) {
+  if (p.max_seqlen_q <= 1 || p.num_tokens <= p.num_seqs || p.only_decodes || p.skip_decodes || p.write_new_kv) return 0;
+  if (p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0) return 0;
+  if (!layout_is_flash(p) || p.head_size != padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype))) return 0;
+  const int G = p.num_q_heads / p.num_kv_heads;
+  if (G > 8) return 0;
+  const char* e = getenv("MI355_DECODE_PACK");
+  if (e && e[0] == '0') return 0;
+  return G == 1 ? 4 : G == 2 ? 3 : G <= 4 ? 2 : 1;
+}
+
+static int pack_chunks_per_seq(const mi355_attn_params& p, int ps) { return (p.max_seqlen_q + (1 << ps) - 1) >> ps; }
+// work units: sequences (only_decodes), query tokens, or - packed - chunks of query tokens
+static long decode_units(const mi355_attn_params& p) {
+  const int ps = decode_pack_shift(p);
+  if (ps) return (long)p.num_seqs * pack_chunks_per_seq(p, ps);
+  return p.only_decodes ? p.num_seqs : p.num_tokens;
+}
+// rows of split partials: one per work unit and query head; packed units keep them by query token
+static long partial_rows(const mi355_attn_params& p) { return decode_pack_shift(p) ? p.num_tokens : decode_units(p); }
 
 // Capture-stable split policy: depends only on host-known sizes (units, Hk, max_seqlen_k).
 static SplitPlan plan_splits(const mi355_attn_params& p) {
@@ -811,6 +882,8 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
     // of the num_tokens - num_seqs tokens beyond one per sequence. C4: 64 sequences, 32 of them decode rows; sized for
     // all 64 the launch ran 2 waves per CU at 3.7 TB/s, profiles/r02/bench_kernel_stats_mixed.csv)
     long units = decode_units(p);
+    // (packed chunks: sequences shorter than max_seqlen_q leave units empty; this many are filled at least)
+    if (const int ps = decode_pack_shift(p)) units = std::min(units, std::max((long)p.num_seqs, ((long)p.num_tokens + (1 << ps) - 1) >> ps));
     if (p.only_decodes && p.max_seqlen_q > 1 && p.num_tokens > p.num_seqs) {
       const long prefills = ((long)p.num_tokens - p.num_seqs + p.max_seqlen_q - 2) / (p.max_seqlen_q - 1);
       units = std::max(1L, std::min(units - 1, units - prefills));
@@ -849,11 +922,11 @@ size_t decode_workspace_bytes(const mi355_attn_params& p) {
   if (!decode_supported(p)) return 0;
   const int splits = plan_splits(p).num_splits;
   if (splits == 1) return 0;
-  const size_t slots = (size_t)decode_units(p) * p.num_q_heads * splits;
+  const size_t slots = (size_t)partial_rows(p) * p.num_q_heads * splits;
   return counters_bytes(p) + slots * (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) + kSlotPad) * sizeof(float);
 }
 
-template <typename T, typename KVT, int D, bool FEAT, bool PAD, bool V0>
+template <typename T, typename KVT, int D, bool FEAT, bool PAD, bool V0, bool PACK = false>
 static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   constexpr int WAVES = 4;
   constexpr bool FP8 = !__is_same(T, KVT);
@@ -868,6 +941,9 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.by_seq = p.only_decodes ? 1 : 0;
   a.d_valid = p.head_size;
   a.unit_is_seq = (!p.only_decodes && p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) ? 1 : 0;
+  a.pack_shift = PACK ? decode_pack_shift(p) : 0;
+  a.pack_tokens = PACK ? 1 << a.pack_shift : 0;
+  a.pack_cps = PACK ? pack_chunks_per_seq(p, a.pack_shift) : 0;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
   a.v_page_stride = (uint32_t)p.v_stride_page; a.v_slot_stride = (uint32_t)p.v_stride_slot;
   a.k_dx_stride = (uint32_t)p.k_stride_dx; a.v_d_stride = (uint32_t)p.v_stride_d;
@@ -876,7 +952,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.ws_slot_bytes_total = 0;
   a.fused_merge = 0;
   if (sp.num_splits > 1) {
-    const size_t slots = (size_t)decode_units(p) * p.num_q_heads * sp.num_splits;
+    const size_t slots = (size_t)partial_rows(p) * p.num_q_heads * sp.num_splits;
     const size_t slot_bytes = slots * (D + kSlotPad) * sizeof(float);
     const size_t need = counters_bytes(p) + slot_bytes;
     if (!ws || ws_bytes < need) {
@@ -894,7 +970,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     // in-kernel merge only where the last arriver reads its partials in ONE round trip (NS lanes x U
     // loads in flight, see the kernel's epilogue); more splits than that merge faster in a launch of
     // their own, which is one round trip at any split count
-    const int G = std::min(a.group, 16), Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));
+    const int G = std::min(a.group, 16) << a.pack_shift, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // columns in use
     const int one_trip = (16 / Gp) * (D >= 128 ? 2 : 4);
     a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip) ? 0 : 1;
   }
@@ -903,11 +979,11 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   const long items = units * sp.num_splits * p.num_kv_heads * a.qgroups;
   const int grid = (int)((items + WAVES - 1) / WAVES);
   const size_t lds = (size_t)WAVES * (16 * (D * 2 + 32) + (V0 ? D * 80 : 32 * (D * 2 + 32)));
-  hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD, V0>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+  hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD, V0, PACK>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
   if (rc != MI355_OK) return rc;
   if (sp.num_splits > 1 && !a.fused_merge) {
-    const dim3 rgrid((unsigned)units, p.num_q_heads);
+    const dim3 rgrid((unsigned)partial_rows(p), p.num_q_heads);
     if (sp.num_splits <= 32) hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 32>), rgrid, dim3(256), 0, stream, a);
     else if (sp.num_splits <= 64) hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 64>), rgrid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 128>), rgrid, dim3(256), 0, stream, a);
@@ -915,6 +991,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   }
   if (rc == MI355_OK)
     set_kernel_name(V0 ? (sp.num_splits > 1 ? "decode_splitkv_v0" : "decode_single_v0")
+                       : PACK ? (sp.num_splits > 1 ? (FP8 ? "decode_splitkv_pack_fp8" : "decode_splitkv_pack") : (FP8 ? "decode_single_pack_fp8" : "decode_single_pack"))
                        : sp.num_splits > 1 ? (FP8 ? "decode_splitkv_fp8" : "decode_splitkv") : (FP8 ? "decode_single_fp8" : "decode_single"));
   return rc;
 }
@@ -926,6 +1003,7 @@ static int launch_decode_f(const mi355_attn_params& p, void* ws, size_t ws_bytes
     if (!layout_is_flash(p))   // decode_supported admitted it: the legacy v0 layout
       return feat ? launch_decode_t<T, KVT, D, true, false, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, true>(p, ws, ws_bytes, stream);
   }
+  if (!feat && decode_pack_shift(p)) return launch_decode_t<T, KVT, D, false, false, false, true>(p, ws, ws_bytes, stream);
   if (p.head_size != D)
     return feat ? launch_decode_t<T, KVT, D, true, true, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, true, false>(p, ws, ws_bytes, stream);
   return feat ? launch_decode_t<T, KVT, D, true, false, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, false>(p, ws, ws_bytes, stream);
