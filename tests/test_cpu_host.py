@@ -490,7 +490,7 @@ def test_fp8_decode_loop_keeps_its_two_register_sets_apart(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                     src, "-o", str(out)], check=True, capture_output=True, timeout=900)
     text = out.read_text()
-    name = "_ZN5mi35521decode_splitkv_kernelINS_6bf16_tENS_6e4m3_tELi128ELi4ELb0ELb0ELb0ELb0EEEvNS_10DecodeArgsE"
+    name = "_ZN5mi35521decode_splitkv_kernelINS_6bf16_tENS_6e4m3_tELi128ELi4ELb0ELb0ELb0ELi0EEEvNS_10DecodeArgsE"
     body = text[text.index(name + ":"):]
     body = body[:body.index(".Lfunc_end")]
     ops = [l.split()[0] for l in body.splitlines() if l.strip() and l.strip()[0] not in ";." and not l.strip().endswith(":")]

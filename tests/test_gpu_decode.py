@@ -333,7 +333,7 @@ def test_mixed_batch_splits_into_prefill_and_decode_launches():
 
 # ---- multi-token decode steps on the PACK kernels (16 / G query tokens of a sequence share a wave's matrix columns) ----------
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("hq,hk", [(32, 8), (8, 8), (16, 2), (6, 2), (64, 8), (10, 2)])
+@pytest.mark.parametrize("hq,hk", [(32, 8), (8, 8), (16, 2), (6, 2), (64, 8), (10, 2), (32, 2), (24, 2)])
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_multi_token_decode_steps_share_one_key_stream(dtype, hq, hk, d):
     """Speculative-decoding / MTP verification batches (a few query tokens per sequence, causal among themselves, over a
@@ -344,7 +344,10 @@ def test_multi_token_decode_steps_share_one_key_stream(dtype, hq, hk, d):
     kv_lens = [700, 45, 3, 2, 4, 1030, 65, 1]            # contexts of 696, 44, 0, 0, 0, 1026, 63, 0 keys
     inp = orc.make_paged_inputs(21, q_lens, kv_lens, hq, hk, d, 16, dtype)
     # (selected explicitly: the dispatch itself packs only what ONE work unit per sequence holds, see the test below)
-    assert "pack" in _check(inp, dtype, force=3, expect="decode_s")
+    kernel = _check(inp, dtype, force=3, expect="decode_s")
+    g = hq // hk
+    want = "pack2" if (g > 4 and d <= 128) else "pack" if g <= 8 else "decode_splitkv"      # 4 tokens: one column group up to G = 4, two up to head size 128
+    assert want in kernel and (want != "pack" or "pack2" not in kernel), kernel
 
 
 @pytest.mark.parametrize("q_len", [2, 5, 8, 16])
@@ -384,14 +387,18 @@ def test_multi_token_decode_fp8_cache(kv_dtype):
 def test_multi_token_decode_dispatch():
     """The dispatch packs a batch whose longest query fits one work unit (16 / G tokens, rounded down to a power of two);
     windows / soft-cap / ALiBi, more than 8 query heads per KV head and longer queries stay on their former paths."""
-    for hq, hk, q_lens in [(32, 8, [4, 1, 3]), (16, 2, [2, 2, 1]), (8, 8, [16, 9]), (6, 2, [4, 4])]:
+    for hq, hk, q_lens, want in [(32, 8, [4, 1, 3], "pack"), (16, 2, [2, 2, 1], "pack"), (8, 8, [16, 9], "pack"), (6, 2, [4, 4], "pack"),
+                                 (16, 2, [3, 2], "pack2"), (32, 8, [8, 5, 1], "pack2"), (32, 2, [2, 2], "pack2"), (8, 8, [32, 17], "pack2")]:
         inp = orc.make_paged_inputs(35, q_lens, [300 + q for q in q_lens], hq, hk, 128, 16, torch.bfloat16)
-        assert "pack" in _check(inp, torch.bfloat16, force=None), (hq, hk, q_lens)
-    inp = orc.make_paged_inputs(36, [3, 2], [300, 200], 16, 2, 128, 16, torch.bfloat16)      # G = 8: two tokens per unit
+        kernel = _check(inp, torch.bfloat16, force=None)
+        assert want in kernel and (want != "pack" or "pack2" not in kernel), (hq, hk, q_lens, kernel)
+    inp = orc.make_paged_inputs(36, [5, 2], [300, 200], 16, 2, 128, 16, torch.bfloat16)      # G = 8: four tokens per unit at most
+    assert "pack" not in _check(inp, torch.bfloat16, force=None)
+    inp = orc.make_paged_inputs(37, [4, 4], [300, 200], 16, 2, 256, 16, torch.bfloat16)      # head size 256: one column group only
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
     inp = orc.make_paged_inputs(32, [4, 4], [300, 200], 8, 2, 128, 16, torch.bfloat16)
     assert "pack" not in _check(inp, torch.bfloat16, force=None, window=64)
-    inp = orc.make_paged_inputs(33, [2, 2], [300, 200], 32, 2, 128, 16, torch.bfloat16)
+    inp = orc.make_paged_inputs(33, [2, 2], [300, 200], 34, 2, 128, 16, torch.bfloat16)      # G = 17
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
     inp = orc.make_paged_inputs(34, [40, 33], [300, 200], 32, 8, 128, 16, torch.bfloat16)
     assert "pack" not in _check(inp, torch.bfloat16, force=None)

@@ -30,8 +30,11 @@ def c4_lens(batch=64, seqlen=4096, page=16):
     return q, [a + b for a, b in zip(q, ctx)]
 
 
+HQ, HK = 32, 8
+
+
 def run(qlens, kvlens, dev, iters=10):
-    Hq, Hk, D, page = 32, 8, 128, 16
+    Hq, Hk, D, page = HQ, HK, 128, 16
     S, T = len(qlens), sum(qlens)
     pps = [(n + page - 1) // page for n in kvlens]
     nb = sum(pps) + 8

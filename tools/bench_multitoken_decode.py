@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Multi-token decode steps (speculative decoding / MTP verification: a few query tokens per sequence over a long
 context): the packed decode kernels (several tokens of a sequence in one wave's matrix columns) against the former
-route (the prefill kernels), same process, same tensors. MI355_DECODE_PACK=0 is the library's A/B switch.
+route (the prefill kernels), same process, same tensors. MI355_DECODE_PACK is the library's A/B switch (0: off, 1: one column group only).
   python tools/bench_multitoken_decode.py [--hq 32 --hk 8]"""
 import argparse
 import os
@@ -19,17 +19,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", nargs="*", default=["64x4x8192", "64x2x8192", "64x8x8192", "16x4x32768", "128x4x2048", "8x4x512", "64x3x8192", "64x16x8192"])
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--hq", type=int, default=32)
+    ap.add_argument("--hk", type=int, default=8)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    print("# sequences x query tokens x keys (Hq 32 / Hk 8 / D 128, bf16): median us, K/V stream rate, kernel")
+    bench_mixed.HQ, bench_mixed.HK = a.hq, a.hk
+    print(f"# sequences x query tokens x keys (Hq {a.hq} / Hk {a.hk} / D 128, bf16): median us, K/V stream rate, kernel")
     for sh in a.shapes:
         b, ql, kv = (int(x) for x in sh.split("x"))
         row = []
-        for pack in ("0", "1"):
+        for pack in ("0", "2"):
             os.environ["MI355_DECODE_PACK"] = pack
             torch.manual_seed(0)
             t, fl, by, kern = bench_mixed.run([ql] * b, [kv] * b, dev, iters=a.iters)
-            row.append(f"{'packed' if pack == '1' else 'former'} {t * 1e6:8.1f} us {by / t / 1e12:5.2f} TB/s {kern}")
+            row.append(f"{'packed' if pack != '0' else 'former'} {t * 1e6:8.1f} us {by / t / 1e12:5.2f} TB/s {kern}")
         print(f"{sh:>14}: " + "   |   ".join(row), flush=True)
     os.environ.pop("MI355_DECODE_PACK", None)
 

@@ -172,10 +172,14 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
 // starting at cu_seqlens_q[i] / BLOCK_Q + i, leaves every other unit empty on a batch of equal query lengths: with
 // the workgroups dealt round-robin to the XCDs half of them then stood idle, 64 x 4 tokens x 8192 keys 559 us against
 // 380); partials and outputs are addressed per column (token, head).
-template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD, bool V0, bool PACK = false>
+// PACK = 2: TWO column groups per wave (32 columns: twice the tokens per unit, or G up to 16) - the K / V fragments a
+// lane reads from LDS feed two matrix instructions, the score / softmax work per tile doubles (head sizes up to 128).
+template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD, bool V0, int PACK = 0>
 __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const DecodeArgs a) {
   static_assert(!V0 || (__is_same(T, KVT) && !PAD), "the v0 layout path serves same-type 16-bit caches of a built head size");
   static_assert(!PACK || (!FEAT && !PAD && !V0), "packed query tokens: plain attention on a flash-layout cache of a built head size");
+  static_assert(PACK != 2 || D <= 128, "two column groups: O, Q and the K/V tiles in flight fit the register file up to head size 128");
+  constexpr int NCG = PACK == 2 ? 2 : 1;            // column groups (16 matrix columns each) per wave
   constexpr bool FP8 = !__is_same(T, KVT);
   // tiles in flight HBM -> VGPR per wave: an fp8 tile is half the bytes of a 16-bit one, so two of
   // them are kept in flight to put the same number of bytes on the wire per CU
@@ -214,20 +218,26 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const int hq0 = head * a.group + 16 * qg;   // first query head of this wave
   const int G = min(16, a.group - 16 * qg);   // query heads of this wave
   const int g = lane & 15, grp = lane >> 4;
-  const int tq = PACK ? g / G : 0;            // PACK: column g = (token tq of the unit's chunk, query head g % G)
-  const int hcol = g - tq * G;
-  bool g_ok = PACK ? tq < a.pack_tokens : g < G;
-  const int hq = hq0 + hcol;
+  // PACK: column c = 16 * cg + g = (token tq of the unit's chunk, query head c % G)
+  int tq[NCG], hq[NCG];
+  bool g_ok[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+    const int c = 16 * cg + g;
+    tq[cg] = PACK ? c / G : 0;
+    hq[cg] = hq0 + c - tq[cg] * G;
+    g_ok[cg] = PACK ? tq[cg] < a.pack_tokens : g < G;
+  }
 
   // ---- Q fragments: B operand of S^T = K.Q^T: lane (g, grp) holds Q[g][32c + 8grp .. +7] --------
-  s16x8_t qf[KSTEPS];
-  auto load_q = [&](int tok) {   // issued as early as the token is known: rides the same round trip as the lookups (PACK: a per-lane token)
-    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)tok * p.q_stride_token + (int64_t)hq * p.q_stride_head + 8 * grp;
+  s16x8_t qf[NCG][KSTEPS];
+  auto load_q = [&](int cg, int tok) {   // issued as early as the token is known: rides the same round trip as the lookups (PACK: a per-lane token)
+    const uint16_t* qp = (const uint16_t*)p.q + (int64_t)tok * p.q_stride_token + (int64_t)hq[cg] * p.q_stride_head + 8 * grp;
 #pragma unroll
     for (int c = 0; c < KSTEPS; ++c) {
       u32x4_t v = {0, 0, 0, 0};
-      if (g_ok && (!PAD || 32 * c + 8 * grp < a.d_valid)) v = *(const u32x4_t*)(qp + 32 * c);
-      qf[c] = __builtin_bit_cast(s16x8_t, v);
+      if (g_ok[cg] && (!PAD || 32 * c + 8 * grp < a.d_valid)) v = *(const u32x4_t*)(qp + 32 * c);
+      qf[cg][c] = __builtin_bit_cast(s16x8_t, v);
     }
   };
 
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const bool fast_head = !FEAT && a.unit_is_seq;
   if (fast_head) {
     if (unit >= p.num_seqs || p.skip_decodes) return;
-    load_q(unit);
+    load_q(0, unit);
     const int t0s = split * a.tiles_per_split;
     // (speculative: the entries are used only if this row's own split size puts the split where the host's did; any
     // index inside the row is safe to read)
@@ -278,19 +288,26 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     ri.n_keys = max(0, min(ri.ctx_len + ri.q_pos + rows, seq_len));               // the chunk's last token sees the most
     ri.first_key = 0;
     ri.valid = true;
-    g_ok = g_ok && tq < rows;
-    load_q(ri.token + (g_ok ? tq : 0));
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      g_ok[cg] = g_ok[cg] && tq[cg] < rows;
+      load_q(cg, ri.token + (g_ok[cg] ? tq[cg] : 0));
+    }
   } else {
     ri = row_info(p, a.by_seq, unit);
     if (!ri.valid) return;
-    load_q(ri.token);
+    load_q(0, ri.token);
     if (p.write_new_kv && (p.slot_mapping || p.slot_mapping_i32))
       slot_sign = p.slot_mapping ? ((const int32_t*)(p.slot_mapping + ri.token))[1] : p.slot_mapping_i32[ri.token];
   }
-  const int token = PACK ? ri.token + (g_ok ? tq : 0) : ri.token;   // PACK: this lane's column's token
   const int n_keys = ri.n_keys, first_key = ri.first_key, ctx_len = ri.ctx_len;
-  // PACK: keys this lane's column sees / the fewest any column sees (tiles below it need no mask)
-  const int n_keys_col = PACK ? max(0, min(ctx_len + ri.q_pos + tq + 1, n_keys)) : n_keys;
+  // PACK: this lane's columns' tokens, the keys they see / the fewest any column sees (tiles below it need no mask)
+  int token[NCG], n_keys_col[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+    token[cg] = PACK ? ri.token + (g_ok[cg] ? tq[cg] : 0) : ri.token;
+    n_keys_col[cg] = PACK ? max(0, min(ctx_len + ri.q_pos + tq[cg] + 1, n_keys)) : n_keys;
+  }
   const int n_keys_min = PACK ? max(0, min(ctx_len + ri.q_pos + 1, n_keys)) : n_keys;
 
   const int tile_lo = first_key / kTileKeys;
@@ -304,19 +321,21 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const int t1 = min(t0 + tps, tile_hi);
   const bool direct = a.num_splits == 1;
   if (t0 >= t1) {
-    if (split == 0 && g_ok) {  // no visible key at all (no split has a tile): the reference returns acc/L = 0/1 = 0
-      const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg)
+    if (split == 0 && g_ok[cg]) {  // no visible key at all (no split has a tile): the reference returns acc/L = 0/1 = 0
+      const int64_t o = (int64_t)token[cg] * p.out_stride_token + (int64_t)hq[cg] * p.out_stride_head;
 #pragma unroll
       for (int b = 0; b < DBLK; ++b)
         if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) = u32x2_t{0, 0};
-      if (p.lse && grp == 0) p.lse[(int64_t)token * p.lse_stride_token + hq] = -INFINITY;
+      if (p.lse && grp == 0) p.lse[(int64_t)token[cg] * p.lse_stride_token + hq[cg]] = -INFINITY;
     }
     return;
   }
 
   const float k_scale = (FP8 && p.k_scale) ? p.k_scale[0] : 1.0f;
   const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
-  const float slope = (FEAT && p.alibi_slopes && g_ok) ? p.alibi_slopes[hq] : 0.0f;
+  const float slope = (FEAT && p.alibi_slopes && g_ok[0]) ? p.alibi_slopes[hq[0]] : 0.0f;
   const float scale_nat = p.scale * k_scale;     // fp8: K is used un-scaled, its scale moves here
   const float scale2 = scale_nat * kLog2e;
   const int32_t* bt = p.block_table + (int64_t)ri.seq * p.block_table_stride;
@@ -401,10 +420,15 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     }
   };
 
-  float m_run = -INFINITY, l_run = 0.0f;
-  f32x4_t o_acc[DBLK];
+  float m_run[NCG], l_run[NCG];
+  f32x4_t o_acc[NCG][DBLK];
 #pragma unroll
-  for (int b = 0; b < DBLK; ++b) o_acc[b] = f32x4_t{0, 0, 0, 0};
+  for (int cg = 0; cg < NCG; ++cg) {
+    m_run[cg] = -INFINITY;
+    l_run[cg] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < DBLK; ++b) o_acc[cg][b] = f32x4_t{0, 0, 0, 0};
+  }
 
   if (fast_head && t0 == split * a.tiles_per_split) {
     // looked up with the sequence length, at the tile the host's split size predicted (the usual eager call: lengths
@@ -421,7 +445,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       if (t0 + u + 1 < t1) lookup_pages(t0 + u + 1);
     }
 #pragma unroll
-  for (int c = 0; c < KSTEPS; ++c) asm volatile("" : "+v"(qf[c]));   // retire the Q loads before the loop (see prefill kernel)
+  for (int c = 0; c < KSTEPS; ++c)
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) asm volatile("" : "+v"(qf[cg][c]));   // retire the Q loads before the loop (see prefill kernel)
 
   auto tile_body = [&](int tile, u32x4_t (&KR)[2][NLD], u32x4_t (&VR)[2][NLD]) __attribute__((always_inline)) {
     // ---- park the current tile's rows in LDS, then refill the registers with a later tile --------
@@ -444,8 +470,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
           for (int i = 0; i < NLD; ++i)
             if (h * 16 + ld_row[i] == r_last && !(PAD && ld_pad[i])) {
-              const uint16_t* kn = (const uint16_t*)p.k_new + (int64_t)token * p.new_stride_token + (int64_t)head * p.new_stride_head + ld_piece[i] * EPP;
-              const uint16_t* vn = (const uint16_t*)p.v_new + (int64_t)token * p.new_stride_token + (int64_t)head * p.new_stride_head + ld_piece[i] * EPP;
+              const uint16_t* kn = (const uint16_t*)p.k_new + (int64_t)token[0] * p.new_stride_token + (int64_t)head * p.new_stride_head + ld_piece[i] * EPP;
+              const uint16_t* vn = (const uint16_t*)p.v_new + (int64_t)token[0] * p.new_stride_token + (int64_t)head * p.new_stride_head + ld_piece[i] * EPP;
               u32x4_t kq, vq;
               if constexpr (FP8) {
                 kq = quantise_fp8x16<T, KVT>(*(const u32x4_t*)kn, *(const u32x4_t*)(kn + 8), k_scale);
@@ -497,28 +523,33 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     }
 
     // ---- S^T = K . Q^T, one 16-key group at a time through the K buffer --------------------------
-    f32x4_t s[2];
+    f32x4_t s[NCG][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) park(k_lds, ld_row[i], ld_piece[i], (PAD && ld_pad[i]) ? u32x4_t{0, 0, 0, 0} : kcur[h][i]);
-      f32x4_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) s[cg][h] = f32x4_t{0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < KSTEPS; ++c) {
         const u32x4_t kf = *(const u32x4_t*)(k_lds + g * RS + c * 64 + grp * 16);  // lane = key row g of the group
-        acc = mma<T>::run(__builtin_bit_cast(s16x8_t, kf), qf[c], acc);
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg) s[cg][h] = mma<T>::run(__builtin_bit_cast(s16x8_t, kf), qf[cg][c], s[cg][h]);
       }
-      s[h] = acc;
     }
 
     // ---- scores -> log2 domain, masks (reference order: scale, softcap, causal, window, +alibi) ---
+    float alpha[NCG];
+    s16x8_t pf[NCG];
+    const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
+    const bool need_mask = (PACK ? tile * kTileKeys + kTileKeys > n_keys_min : tail) || (FEAT && tile * kTileKeys < first_key);
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
     float sv[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sv[h * 4 + r] = s[h][r];
-    const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
-    const bool need_mask = (PACK ? tile * kTileKeys + kTileKeys > n_keys_min : tail) || (FEAT && tile * kTileKeys < first_key);
+      for (int r = 0; r < 4; ++r) sv[h * 4 + r] = s[cg][h][r];
     if (plain && !need_mask) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) sv[j] *= scale2;
@@ -526,7 +557,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int key = tile * kTileKeys + (j >> 2) * 16 + grp * 4 + (j & 3);
-        sv[j] = key < n_keys_col ? sv[j] * scale2 : -INFINITY;
+        sv[j] = key < n_keys_col[cg] ? sv[j] * scale2 : -INFINITY;
       }
     } else {
 #pragma unroll
@@ -541,24 +572,28 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     }
     float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     mx = max_over_lane_groups(mx);
-    float m_new = fmaxf(m_run, mx);
+    float m_new = fmaxf(m_run[cg], mx);
     if (!(m_new > -INFINITY)) m_new = 0.0f;   // fully masked so far (:486-489)
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    alpha[cg] = __builtin_amdgcn_exp2f(m_run[cg] - m_new);
     float pv[8], psum = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       pv[j] = __builtin_amdgcn_exp2f(sv[j] - m_new);
       psum += pv[j];
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    l_run[cg] = l_run[cg] * alpha[cg] + psum;
+    m_run[cg] = m_new;
     // P^T fragment (B operand): k-slot j -> key 4*grp + (j&3) of group (j>>2); rounded to the KV
     // dtype before P.V like the reference (:508)
-    const s16x8_t pf = __builtin_bit_cast(s16x8_t, u32x4_t{mma<T>::pack2(pv[0], pv[1]), mma<T>::pack2(pv[2], pv[3]),
-                                                           mma<T>::pack2(pv[4], pv[5]), mma<T>::pack2(pv[6], pv[7])});
+    pf[cg] = __builtin_bit_cast(s16x8_t, u32x4_t{mma<T>::pack2(pv[0], pv[1]), mma<T>::pack2(pv[2], pv[3]),
+                                                 mma<T>::pack2(pv[4], pv[5]), mma<T>::pack2(pv[6], pv[7])});
+    }
 
     // ---- O^T += V^T . P^T -----------------------------------------------------------------------
-    const bool rescale = !__all(alpha == 1.0f);
+    bool all_one = alpha[0] == 1.0f;
+#pragma unroll
+    for (int cg = 1; cg < NCG; ++cg) all_one = all_one && alpha[cg] == 1.0f;
+    const bool rescale = !__all(all_one);
 #pragma unroll
     for (int b = 0; b < DBLK; ++b) {
       // transposed read: lane 4q+pp of group grp addresses row 4*grp+q, columns 16b+4pp..+3 and
@@ -576,11 +611,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
         v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + 16 * RS));
       }
       const s16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (rescale) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o_acc[b][r] *= alpha;
+      for (int cg = 0; cg < NCG; ++cg) {
+        if (rescale) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o_acc[cg][b][r] *= alpha[cg];
+        }
+        o_acc[cg][b] = mma<T>::run(vf, pf[cg], o_acc[cg][b]);
       }
-      o_acc[b] = mma<T>::run(vf, pf, o_acc[b]);
     }
   };
 
@@ -598,17 +636,22 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
-  const float l_tot = sum_over_lane_groups(l_run);
-  if (direct) {
-    if (!g_ok) return;
-    if (p.lse && grp == 0)   // m_run is the row max of the scaled scores in the log2 domain
-      p.lse[(int64_t)token * p.lse_stride_token + hq] = l_tot > 0.0f ? (m_run + __builtin_amdgcn_logf(l_tot)) * kLn2 : -INFINITY;
-    const float inv = l_tot > 0.0f ? v_scale / l_tot : 0.0f;
-    const int64_t o = (int64_t)token * p.out_stride_token + (int64_t)hq * p.out_stride_head;
+  float l_tot[NCG];
 #pragma unroll
-    for (int b = 0; b < DBLK; ++b)
-      if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
-          u32x2_t{mma<T>::pack2(o_acc[b][0] * inv, o_acc[b][1] * inv), mma<T>::pack2(o_acc[b][2] * inv, o_acc[b][3] * inv)};
+  for (int cg = 0; cg < NCG; ++cg) l_tot[cg] = sum_over_lane_groups(l_run[cg]);
+  if (direct) {
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      if (!g_ok[cg]) continue;
+      if (p.lse && grp == 0)   // m_run is the row max of the scaled scores in the log2 domain
+        p.lse[(int64_t)token[cg] * p.lse_stride_token + hq[cg]] = l_tot[cg] > 0.0f ? (m_run[cg] + __builtin_amdgcn_logf(l_tot[cg])) * kLn2 : -INFINITY;
+      const float inv = l_tot[cg] > 0.0f ? v_scale / l_tot[cg] : 0.0f;
+      const int64_t o = (int64_t)token[cg] * p.out_stride_token + (int64_t)hq[cg] * p.out_stride_head;
+#pragma unroll
+      for (int b = 0; b < DBLK; ++b)
+        if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
+            u32x2_t{mma<T>::pack2(o_acc[cg][b][0] * inv, o_acc[cg][b][1] * inv), mma<T>::pack2(o_acc[cg][b][2] * inv, o_acc[cg][b][3] * inv)};
+    }
     return;
   }
   // Partial -> workspace with WRITE-THROUGH (sc1) 16-byte stores: they are visible to every CU once
@@ -622,16 +665,18 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     if constexpr (PACK) { const int t = c / G; return slot_g0 + (uint32_t)((t * p.num_q_heads + (c - t * G)) * a.num_splits); }
     return slot_g0 + (uint32_t)(c * a.num_splits);
   };
-  if (g_ok) {
-    const uint32_t so = ((slot_of_col(g) + split) * SLOT) * 4u;
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg)
+  if (g_ok[cg]) {
+    const uint32_t so = ((slot_of_col(16 * cg + g) + split) * SLOT) * 4u;
 #pragma unroll
     for (int b = 0; b < DBLK; ++b)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o_acc[b]), rsrc, so + (16 * b + 4 * grp) * 4, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o_acc[cg][b]), rsrc, so + (16 * b + 4 * grp) * 4, 0, 16);
     if (grp == 0)
       // (PACK: a split whose tiles lie past a column's last key leaves that column an empty partial)
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(uint32_t, (PACK && !(l_tot > 0.0f)) ? -INFINITY : m_run), __builtin_bit_cast(uint32_t, l_tot)}, rsrc, so + D * 4, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(uint32_t, (PACK && !(l_tot[cg] > 0.0f)) ? -INFINITY : m_run[cg]), __builtin_bit_cast(uint32_t, l_tot[cg])}, rsrc, so + D * 4, 0, 16);
   }
-  if (!a.fused_merge) return;
+  if (NCG > 1 || !a.fused_merge) return;   // (two column groups: the host always takes the merge launch)
 
   // ---- in-kernel merge by the last-arriving split of this (unit, KV head) (reference: reduce_segments, :757-836)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains before it signals
@@ -845,18 +890,26 @@ struct SplitPlan { int num_splits, tiles_per_split; };
 // streaming the head's K/V (neighbouring waves: the second reader hits in L2).
 static int query_head_groups(const mi355_attn_params& p) { return (p.num_q_heads / p.num_kv_heads + 15) / 16; }
 
-// Multi-token decode steps on the PACK kernels: log2 of the query tokens one work unit holds (0 = not packed). Plain
-// attention (no window / soft-cap / ALiBi), flash layout, a built head size, at most 8 query heads per KV head.
-// MI355_DECODE_PACK=0 switches it off (A/B).
-int decode_pack_shift(const mi355_attn_params& p) {
+// Multi-token decode steps on the PACK kernels: plain attention (no window / soft-cap / ALiBi), flash layout, a built
+// head size. One column group (16 matrix columns) per wave holds 16 / G tokens (G <= 8), two hold 32 / G (G <= 16,
+// head sizes up to 128), both rounded down to a power of two; one group is taken when the longest query fits it.
+// MI355_DECODE_PACK=0 switches packing off, =1 keeps it to one column group (A/B).
+static int pow2_floor_shift(int x) { return x < 1 ? -1 : 31 - __builtin_clz((unsigned)x); }
+int decode_pack_groups(const mi355_attn_params& p) {
   if (p.max_seqlen_q <= 1 || p.num_tokens <= p.num_seqs || p.only_decodes || p.skip_decodes || p.write_new_kv) return 0;
   if (p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0) return 0;
   if (!layout_is_flash(p) || p.head_size != padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype))) return 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  if (G > 8) return 0;
   const char* e = getenv("MI355_DECODE_PACK");
   if (e && e[0] == '0') return 0;
-  return G == 1 ? 4 : G == 2 ? 3 : G <= 4 ? 2 : 1;
+  const bool one_ok = G <= 8, two_ok = G <= 16 && p.head_size <= 128 && !(e && e[0] == '1');
+  if (one_ok && (p.max_seqlen_q <= (1 << pow2_floor_shift(16 / G)) || !two_ok)) return 1;
+  return two_ok ? 2 : 0;
+}
+// log2 of the query tokens one work unit holds (0 = not packed)
+int decode_pack_shift(const mi355_attn_params& p) {
+  const int groups = decode_pack_groups(p);
+  return groups ? pow2_floor_shift(16 * groups / (p.num_q_heads / p.num_kv_heads)) : 0;
 }
 
 static int pack_chunks_per_seq(const mi355_attn_params& p, int ps) { return (p.max_seqlen_q + (1 << ps) - 1) >> ps; }
@@ -926,7 +979,7 @@ size_t decode_workspace_bytes(const mi355_attn_params& p) {
   return counters_bytes(p) + slots * (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) + kSlotPad) * sizeof(float);
 }
 
-template <typename T, typename KVT, int D, bool FEAT, bool PAD, bool V0, bool PACK = false>
+template <typename T, typename KVT, int D, bool FEAT, bool PAD, bool V0, int PACK = 0>
 static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   constexpr int WAVES = 4;
   constexpr bool FP8 = !__is_same(T, KVT);
@@ -972,12 +1025,13 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     // their own, which is one round trip at any split count
     const int G = std::min(a.group, 16) << a.pack_shift, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // columns in use
     const int one_trip = (16 / Gp) * (D >= 128 ? 2 : 4);
-    a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip) ? 0 : 1;
+    a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip || PACK == 2) ? 0 : 1;
   }
   const long units = decode_units(p);
   if (units == 0) return MI355_OK;
   const long items = units * sp.num_splits * p.num_kv_heads * a.qgroups;
   const int grid = (int)((items + WAVES - 1) / WAVES);
+  if (PACK && (a.group << a.pack_shift) > 16 * PACK) { set_error("decode: packed columns exceed the wave's"); return MI355_ERR_UNSUPPORTED; }
   const size_t lds = (size_t)WAVES * (16 * (D * 2 + 32) + (V0 ? D * 80 : 32 * (D * 2 + 32)));
   hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD, V0, PACK>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
@@ -991,7 +1045,8 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   }
   if (rc == MI355_OK)
     set_kernel_name(V0 ? (sp.num_splits > 1 ? "decode_splitkv_v0" : "decode_single_v0")
-                       : PACK ? (sp.num_splits > 1 ? (FP8 ? "decode_splitkv_pack_fp8" : "decode_splitkv_pack") : (FP8 ? "decode_single_pack_fp8" : "decode_single_pack"))
+                       : PACK == 1 ? (sp.num_splits > 1 ? (FP8 ? "decode_splitkv_pack_fp8" : "decode_splitkv_pack") : (FP8 ? "decode_single_pack_fp8" : "decode_single_pack"))
+                       : PACK == 2 ? (sp.num_splits > 1 ? (FP8 ? "decode_splitkv_pack2_fp8" : "decode_splitkv_pack2") : (FP8 ? "decode_single_pack2_fp8" : "decode_single_pack2"))
                        : sp.num_splits > 1 ? (FP8 ? "decode_splitkv_fp8" : "decode_splitkv") : (FP8 ? "decode_single_fp8" : "decode_single"));
   return rc;
 }
@@ -1003,7 +1058,9 @@ static int launch_decode_f(const mi355_attn_params& p, void* ws, size_t ws_bytes
     if (!layout_is_flash(p))   // decode_supported admitted it: the legacy v0 layout
       return feat ? launch_decode_t<T, KVT, D, true, false, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, true>(p, ws, ws_bytes, stream);
   }
-  if (!feat && decode_pack_shift(p)) return launch_decode_t<T, KVT, D, false, false, false, true>(p, ws, ws_bytes, stream);
+  if (!feat && decode_pack_groups(p) == 1) return launch_decode_t<T, KVT, D, false, false, false, 1>(p, ws, ws_bytes, stream);
+  if constexpr (D <= 128)
+    if (!feat && decode_pack_groups(p) == 2) return launch_decode_t<T, KVT, D, false, false, false, 2>(p, ws, ws_bytes, stream);
   if (p.head_size != D)
     return feat ? launch_decode_t<T, KVT, D, true, true, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, true, false>(p, ws, ws_bytes, stream);
   return feat ? launch_decode_t<T, KVT, D, true, false, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, false>(p, ws, ws_bytes, stream);
