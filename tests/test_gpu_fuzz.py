@@ -69,6 +69,53 @@ def test_fast_kernels_agree_with_the_generic_kernel(case_id):
     torch.testing.assert_close(lse, ref_lse, atol=5e-2, rtol=0, msg=lambda m: f"[{kernel}] lse {c}\n{m}")
 
 
+@pytest.mark.parametrize("case_id", range(120))
+def test_packed_multi_token_decode_agrees_with_the_generic_kernel(case_id):
+    """Multi-token decode steps (speculative decoding / MTP verification) on the PACK decode kernels: random query heads
+    per KV head (1 .. 16), head sizes, page sizes, dtypes, fp8 caches, query lengths up to what two column groups hold
+    (and beyond: then selected explicitly, several chunks per sequence), split counts through every merge route."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels import unified as ua_mod
+
+    rng = random.Random(7000 + case_id)
+    g = rng.choice([1, 2, 3, 4, 4, 5, 6, 8, 8, 12, 16])
+    hk = rng.choice([1, 2, 8])
+    d = rng.choice([64, 128, 128, 256])
+    max_q = rng.choice([2, 3, 4, 8, 11, 32])
+    n_seq = rng.randint(1, 7)
+    q_lens = [rng.randint(1, max_q) for _ in range(n_seq)]
+    q_lens[rng.randrange(n_seq)] = max_q
+    kv_lens = [ql + rng.choice([0, 0, 1, 14, 15, 16, 17, 31, 32, 33, 63, 255, 700, 1500, 4097]) for ql in q_lens]
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    kv_dtype = rng.choice([None, None, torch.float8_e4m3fn, torch.float8_e5m2])
+    page = rng.choice([16, 16, 32, 128])
+    segments = rng.choice([0, 0, 1, 2, 3, 8, 33])
+    kw = dict(kv_dtype=kv_dtype, kv_scale=0.5) if kv_dtype is not None else {}
+    inp = orc.make_paged_inputs(7000 + case_id, q_lens, kv_lens, hk * g, hk, d, page, dtype, **kw)
+    t = gpu_util.to_dev(inp)
+    scale = 1.0 / math.sqrt(d)
+    n_tok = t["q"].shape[0]
+    ref_lse = torch.full((n_tok, hk * g), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    ref, ref_kernel = gpu_util.run_unified(t, scale, kv_scale=0.5 if kv_dtype is not None else None, force=9, lse=ref_lse)
+    assert ref_kernel == "generic"
+    out = torch.full_like(t["q"], float("nan"))
+    lse = torch.full_like(ref_lse, float("nan"))
+    descale = torch.tensor([0.5], dtype=torch.float32, device=gpu_util.DEV) if kv_dtype is not None else None
+    p, keep = ua_mod.fill_attn_params(t["q"], t["k_cache"], t["v_cache"], out, t["cu_seqlens_q"], max(q_lens), t["seqused_k"], max(kv_lens),
+                                      scale, (-1, -1), t["block_table"], 0.0, descale, descale, None, 3, num_segments=segments, lse=lse)
+    ua_mod.launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    kernel = _lib.last_kernel()
+    packable = max(q_lens) > 1 and sum(q_lens) > n_seq and (g <= 8 or d <= 128)
+    assert ("pack" in kernel) == packable, (kernel, g, d, q_lens)
+    assert not torch.isnan(out).any(), (kernel, q_lens, kv_lens)
+    atol, rtol = golden_io.tolerance(dtype, kv_dtype)
+    case = dict(g=g, hk=hk, d=d, q_lens=q_lens, kv_lens=kv_lens, page=page, segments=segments, kv_dtype=kv_dtype)
+    torch.testing.assert_close(out.float(), ref.float(), atol=atol, rtol=rtol, msg=lambda m: f"[{kernel}] {case}\n{m}")
+    torch.testing.assert_close(lse, ref_lse, atol=5e-2, rtol=0, msg=lambda m: f"[{kernel}] lse {case}\n{m}")
+
+
 @pytest.mark.parametrize("q_lens,kv_lens", [([5, 0, 1, 0, 64], [70, 33, 45, 0, 64]), ([0, 1, 1], [16, 300, 1]), ([0, 200], [0, 777])])
 def test_sequences_without_query_tokens_are_skipped(q_lens, kv_lens):
     """A sequence may contribute no query token to a step (equal neighbours in cu_seqlens_q): nothing is computed for it and
