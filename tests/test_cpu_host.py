@@ -114,6 +114,28 @@ def test_workspace_bytes_is_host_arithmetic(lib):
     assert h.mi355_attn_workspace_bytes(C.byref(p)) == 0          # generic kernel needs none
 
 
+def test_workspace_bytes_of_a_multi_token_decode_step(lib):
+    """Speculative-decoding / MTP verification batches whose longest query fits the decode kernel's packed columns take
+    the decode kernel (host-known sizes only): partials per QUERY TOKEN and head, splits planned per sequence."""
+    h = lib.load()
+    buf = np.zeros(64, dtype=np.uint8)
+    addr = (buf.ctypes.data + 15) & ~15
+    counters, slot = 256 << 10, (128 + 32) * 4
+    p = _c3_like_params(lib, addr)                                  # Hq 32 / Hk 8 (G = 4)
+    p.num_tokens, p.num_seqs, p.max_seqlen_q, p.max_seqlen_k = 64, 64, 1, 8192
+    one = h.mi355_attn_workspace_bytes(C.byref(p))
+    splits = (one - counters) // (64 * 32 * slot)
+    for q_len in (2, 3, 4, 8):                                      # one column group holds 4 tokens, two hold 8
+        p.num_tokens, p.max_seqlen_q = 64 * q_len, q_len
+        n = h.mi355_attn_workspace_bytes(C.byref(p))
+        assert n == counters + 64 * q_len * 32 * splits * slot, (q_len, n)
+    p.num_tokens, p.max_seqlen_q = 64 * 9, 9                        # more than the columns hold: the prefill path (a uniform batch: no decode rows)
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) in (0, counters)
+    p.num_tokens, p.max_seqlen_q = 64 * 4, 4
+    p.sliding_window = 128                                          # the packed kernels are plain attention only
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) in (0, counters)
+
+
 def _c3_like_params(lib, addr):
     p = lib.AttnParams()
     for f in ("q", "out", "k_cache", "v_cache", "block_table", "cu_seqlens_q", "seqused_k"):

@@ -231,3 +231,51 @@ def test_capture_with_the_plain_torch_idiom_after_a_warm_up_on_another_stream():
         torch.cuda.synchronize()
         ref = orc.unified_attention_oracle(q2, inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"])
         torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+def test_multi_token_decode_graph_replays_other_lengths_and_draft_counts():
+    """A speculative-decoding verification step captured for B sequences x (1 + k) tokens at max_model_len: replays see
+    other context lengths AND sequences that carry fewer tokens than the capture's maximum (rejected drafts / padding:
+    cu_seqlens_q changes inside the same buffers, trailing token rows unused). Everything the packed decode launch is
+    sized from is host-known and fixed by the capture."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels import unified_attention
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page, B, Tq = 32, 8, 128, 16, 5, 4
+    cap_len = 32768
+    first = dict(q_lens=[Tq] * B, kv_lens=[3000, 40, 700, 4, 1290])
+    inp = orc.make_paged_inputs(51, first["q_lens"], first["kv_lens"], Hq, Hk, D, page, torch.bfloat16)
+    d = gpu_util.to_dev(inp)
+    out = torch.zeros_like(d["q"])
+
+    def step():
+        unified_attention(q=d["q"], k=d["k_cache"], v=d["v_cache"], out=out, cu_seqlens_q=d["cu_seqlens_q"], max_seqlen_q=Tq,
+                          seqused_k=d["seqused_k"], max_seqlen_k=cap_len, avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=inp["scale"],
+                          causal=True, window_size=(-1, -1), block_table=d["block_table"], softcap=0, q_descale=None, k_descale=None,
+                          v_descale=None)
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.synchronize()
+    assert "pack" in _lib.last_kernel()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        step()
+    for q_lens, kv_lens in ([[4, 4, 4, 4, 4], [3000, 40, 700, 4, 1290]], [[4, 1, 3, 2, 4], [2999, 1, 650, 2, 100]], [[1, 1, 1, 1, 1], [17, 3000, 5, 64, 1]],
+                            [[2, 4, 0, 4, 3], [33, 1200, 0, 500, 3]]):
+        cu = torch.zeros(B + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(torch.tensor(q_lens, dtype=torch.int32), 0)
+        d["cu_seqlens_q"].copy_(cu)
+        d["seqused_k"].copy_(torch.tensor(kv_lens, dtype=torch.int32))
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        T = int(cu[-1])
+        ref = orc.unified_attention_oracle(inp["q"][:T], inp["k_cache"], inp["v_cache"], cu, torch.tensor(kv_lens, dtype=torch.int32), inp["block_table"],
+                                           inp["scale"], mode="3d")
+        assert not torch.isnan(out[:T]).any(), q_lens
+        torch.testing.assert_close(out[:T].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+        assert torch.isnan(out[T:]).all()          # token rows past the batch stay untouched

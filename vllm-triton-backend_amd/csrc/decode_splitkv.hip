@@ -150,6 +150,7 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
   const int seq_len = p.seqused_k[r.seq];
   r.ctx_len = seq_len - r.q_len;
   r.q_pos = r.token - q_start;
+  if (r.q_pos >= r.q_len) return r;   // a token row past the batch's last sequence (padding of a captured graph): untouched, like the reference's (:307-327)
   r.n_keys = max(0, min(r.ctx_len + r.q_pos + 1, seq_len));   // causal
   if (p.sliding_window > 0) r.first_key = max(0, r.ctx_len + r.q_pos - p.sliding_window + 1);  // keep j with q_abs - j < window
   r.valid = true;
