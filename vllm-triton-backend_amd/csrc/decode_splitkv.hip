@@ -677,7 +677,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
       // (PACK: a split whose tiles lie past a column's last key leaves that column an empty partial)
       __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(uint32_t, (PACK && !(l_tot[cg] > 0.0f)) ? -INFINITY : m_run[cg]), __builtin_bit_cast(uint32_t, l_tot[cg])}, rsrc, so + D * 4, 0, 16);
   }
-  if (NCG > 1 || !a.fused_merge) return;   // (two column groups: the host always takes the merge launch)
+  if (!a.fused_merge) return;
 
   // ---- in-kernel merge by the last-arriving split of this (unit, KV head) (reference: reduce_segments, :757-836)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains before it signals
@@ -694,13 +694,17 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   // of a split's loads in flight at once, and the NS partial merges meet through xor shuffles.
   // (m, l are two 4-byte loads: hipcc 7.2 narrows a raw_buffer_load_b64 whose halves are used apart
   // to ONE dword and hands the same register out for both.)
-  const int C = PACK ? G << a.pack_shift : G;                                 // columns in use
-  const int Gp = C <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(C - 1)));   // ... rounded up to a power of two
+  // (two column groups: one after the other, every lane on its own column - NS = 1)
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+  const int C = PACK ? min(16, (G << a.pack_shift) - 16 * cg) : G;            // columns of this group in use
+  const int Gp = NCG > 1 ? 16 : C <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(C - 1)));   // ... rounded up to a power of two
   const int NS = 16 / Gp;
   const int gm = g & (Gp - 1), sub = g / Gp;
-  const int tqm = PACK ? gm / G : 0;                                          // column gm = (token tqm of the chunk, head gm % G)
+  const int cm = 16 * cg + gm;
+  const int tqm = PACK ? cm / G : 0;                                          // column cm = (token tqm of the chunk, head cm % G)
   const bool gm_ok = PACK ? (gm < C && tqm < min(a.pack_tokens, ri.q_len - ri.q_pos)) : gm < G;
-  const int tokm = ri.token + tqm, hqm = hq0 + gm - tqm * G;
+  const int tokm = ri.token + tqm, hqm = hq0 + cm - tqm * G;
   float m_acc = -INFINITY, l_acc = 0.0f;
   f32x4_t acc[DBLK];
 #pragma unroll
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     // so the serial chain is ceil(active / (NS*U)) trips. A split past `active` is given an offset
     // beyond the descriptor's range (the load returns 0) and the weight of an empty partial.
     constexpr int U = D >= 128 ? 2 : 4;
-    const uint32_t s0 = (slot_of_col(gm) * SLOT) * 4u;
+    const uint32_t s0 = (slot_of_col(cm) * SLOT) * 4u;
     for (int base = sub; base < active; base += NS * U) {
       float m_in[U], l_in[U];
       f32x4_t v_in[U][DBLK];
@@ -755,6 +759,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     for (int b = 0; b < DBLK; ++b)
       if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
           u32x2_t{mma<T>::pack2(acc[b][0] * inv, acc[b][1] * inv), mma<T>::pack2(acc[b][2] * inv, acc[b][3] * inv)};
+  }
   }
   if (lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counter zero for the next call
 }
@@ -1025,8 +1030,8 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     // loads in flight, see the kernel's epilogue); more splits than that merge faster in a launch of
     // their own, which is one round trip at any split count
     const int G = std::min(a.group, 16) << a.pack_shift, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // columns in use
-    const int one_trip = (16 / Gp) * (D >= 128 ? 2 : 4);
-    a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip || PACK == 2) ? 0 : 1;
+    const int one_trip = (PACK == 2 ? 1 : 16 / Gp) * (D >= 128 ? 2 : 4);
+    a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip) ? 0 : 1;
   }
   const long units = decode_units(p);
   if (units == 0) return MI355_OK;
