@@ -144,10 +144,12 @@ typedef struct mi355_attn_params {
   float softcap;               /* > 0 enables cap * tanh(s / cap) (:25-29,:914)                   */
   int32_t sliding_window;      /* 0 = off; else keep keys with query_pos - key_pos < window      */
                                /*   (= 1 + window_size[0], :915)                                  */
-  int32_t skip_decodes;        /* 1: leave rows of sequences with query_len == 1 untouched       */
-                               /*   (triton_prefix_prefill.py:83-84)                              */
-  int32_t only_decodes;        /* 1: process only sequences with query_len == 1                  */
-                               /*   (filter_by_query_len, triton_paged_decode_attention_2d.py:143-148) */
+  int32_t skip_decodes;        /* N >= 1: leave rows of sequences with query_len <= N untouched  */
+                               /*   (1: triton_prefix_prefill.py:83-84)                           */
+  int32_t only_decodes;        /* N >= 1: process only sequences with query_len <= N             */
+                               /*   (1: filter_by_query_len, triton_paged_decode_attention_2d.py:143-148; */
+                               /*   N > 1: multi-token decode rows - speculative decoding - of a  */
+                               /*   mixed batch, which the split-KV kernel takes N tokens a wave) */
   int32_t kernel_select;       /* mi355_kernel_select                                            */
   int32_t num_segments;        /* split-KV segment count of the decode path / key-split count of */
                                /*   a prefill (1 = every Q block walks its whole key range in    */

@@ -322,7 +322,8 @@ def test_mixed_batch_splits_into_prefill_and_decode_launches():
     d = gpu_util.to_dev(inp)
     out, kernel = gpu_util.run_unified(d, inp["scale"])
     # (the prefill half may be the key-split launch: few Q blocks, and the longest sequence of the batch has 2048 keys)
-    assert kernel.replace("_pw", "") in ("prefill_mfma+decode_splitkv", "prefill_mfma+decode_single", "prefill_mfma_ksplit+decode_splitkv"), kernel
+    # (the decode half: the packed instantiation - G = 4 here, rows of up to 4 query tokens are decode rows)
+    assert kernel.replace("_pw", "").replace("_pack", "") in ("prefill_mfma+decode_splitkv", "prefill_mfma+decode_single", "prefill_mfma_ksplit+decode_splitkv"), kernel
     assert not torch.isnan(out).any()
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
     # and the single-kernel 2D path gives the same answer
@@ -393,6 +394,8 @@ def test_multi_token_decode_dispatch():
         kernel = _check(inp, torch.bfloat16, force=None)
         assert want in kernel and (want != "pack" or "pack2" not in kernel), (hq, hk, q_lens, kernel)
     inp = orc.make_paged_inputs(36, [5, 2], [300, 200], 16, 2, 128, 16, torch.bfloat16)      # G = 8: four tokens per unit at most
+    assert _check(inp, torch.bfloat16, force=None).startswith("prefill")                     # (a mixed batch: the 2-token row is the decode launch's)
+    inp = orc.make_paged_inputs(36, [5, 5], [300, 200], 16, 2, 128, 16, torch.bfloat16)
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
     inp = orc.make_paged_inputs(37, [4, 4], [300, 200], 16, 2, 256, 16, torch.bfloat16)      # head size 256: one column group only
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
@@ -401,4 +404,32 @@ def test_multi_token_decode_dispatch():
     inp = orc.make_paged_inputs(33, [2, 2], [300, 200], 34, 2, 128, 16, torch.bfloat16)      # G = 17
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
     inp = orc.make_paged_inputs(34, [40, 33], [300, 200], 32, 8, 128, 16, torch.bfloat16)
+    assert _check(inp, torch.bfloat16, force=None).startswith("prefill")                      # (with a decode launch that finds no row of up to 4 tokens)
+    inp = orc.make_paged_inputs(34, [40, 40], [300, 200], 32, 8, 128, 16, torch.bfloat16)
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
+
+
+def test_mixed_batch_sends_multi_token_decode_rows_to_the_decode_launch():
+    """A step that mixes prefill chunks with speculative-decoding rows (1 + k tokens each): rows of up to 16 / G tokens
+    are the decode launch's (packed into a wave's matrix columns), longer ones the prefill launch's; every row is
+    computed exactly once (the output starts as NaN) and matches the oracle."""
+    import gpu_util
+    query_lens = [300, 4, 1, 3, 5, 2, 4, 64, 1]
+    kv_lens = [900, 640, 17, 2048, 333, 2, 4, 64, 513]
+    for hq, hk, thr in [(32, 8, 4), (16, 2, 2), (8, 8, 16)]:
+        inp = orc.make_paged_inputs(61, query_lens, kv_lens, hq, hk, 128, 16, torch.bfloat16)
+        ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                           inp["scale"], mode="2d", block_n=64)
+        d = gpu_util.to_dev(inp)
+        lse = torch.full((sum(query_lens), hq), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+        out, kernel = gpu_util.run_unified(d, inp["scale"], lse=lse)
+        assert "+decode" in kernel and "pack" in kernel, kernel
+        assert not torch.isnan(out).any() and torch.isfinite(lse).all(), (hq, hk)
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    # features keep the one-token split
+    inp = orc.make_paged_inputs(62, query_lens, kv_lens, 32, 8, 128, 16, torch.bfloat16)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], sliding_window=100, mode="2d", block_n=64)
+    out, kernel = gpu_util.run_unified(gpu_util.to_dev(inp), inp["scale"], window=100)
+    assert "pack" not in kernel, kernel
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)

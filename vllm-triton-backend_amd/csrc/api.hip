@@ -53,6 +53,7 @@ static int validate(const mi355_attn_params* p) {
     return MI355_ERR_BAD_ARG;
   }
   if (p->lse && p->lse_stride_token < p->num_q_heads) { set_error("lse_stride_token %lld is smaller than num_q_heads %d", (long long)p->lse_stride_token, p->num_q_heads); return MI355_ERR_BAD_ARG; }
+  if (p->skip_decodes < 0 || p->only_decodes < 0) { set_error("skip_decodes / only_decodes are query-length thresholds: not negative"); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
   if (p->non_causal && (p->sliding_window > 0 || p->alibi_slopes || p->write_new_kv)) {
     set_error("non_causal attention takes neither a sliding window nor ALiBi slopes nor a fused cache write");
@@ -115,8 +116,7 @@ static size_t plain_workspace_bytes(const mi355_attn_params& p) {
     case Path::Prefill: return prefill_workspace_bytes(p);
     case Path::PrefillPlusDecode: {          // the two run one after the other on the stream and share the bytes
       mi355_attn_params pp = p, pd = p;
-      pp.skip_decodes = 1;
-      pd.only_decodes = 1;
+      pp.skip_decodes = pd.only_decodes = decode_rows_max_q(p);
       const size_t a = prefill_workspace_bytes(pp), b = decode_workspace_bytes(pd);
       return a > b ? a : b;
     }
@@ -133,8 +133,7 @@ static int dispatch_plain(const mi355_attn_params& p, void* workspace, size_t wo
       return launch_prefill_ws(p, workspace, workspace_bytes, s);
     case Path::PrefillPlusDecode: {
       mi355_attn_params pp = p, pd = p;
-      pp.skip_decodes = 1;
-      pd.only_decodes = 1;
+      pp.skip_decodes = pd.only_decodes = decode_rows_max_q(p);    // (1, or what one packed decode unit holds: multi-token decode rows)
       rc = launch_prefill_ws(pp, workspace, workspace_bytes, s);
       static thread_local char prefill_name[64];
       snprintf(prefill_name, sizeof(prefill_name), "%s", g_kernel);

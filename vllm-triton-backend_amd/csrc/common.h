@@ -369,6 +369,7 @@ int launch_cache_write(const mi355_cache_params& p, hipStream_t stream);
 
 bool decode_supported(const mi355_attn_params& p);
 int decode_pack_groups(const mi355_attn_params& p);        // 0: not a packed multi-token decode step; 1 / 2: column groups (16 matrix columns each) per wave
+int decode_rows_max_q(const mi355_attn_params& p);         // mixed batch: sequences with up to this many query tokens are the decode launch's rows
 int decode_pack_shift(const mi355_attn_params& p);         // > 0: a multi-token decode step the PACK decode kernels take (log2 of the tokens per work unit)
 bool decode_write_fusable(const mi355_attn_params& p);     // decode step whose cache write can ride the attention launch
 size_t decode_workspace_bytes(const mi355_attn_params& p);

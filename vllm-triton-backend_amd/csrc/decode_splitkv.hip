@@ -145,8 +145,8 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
   const int q_start = p.cu_seqlens_q[r.seq];
   r.q_len = p.cu_seqlens_q[r.seq + 1] - q_start;
   if (by_seq && r.q_len != 1) return r;
-  if (p.skip_decodes && r.q_len == 1) return r;
-  if (p.only_decodes && r.q_len != 1) return r;
+  if (r.q_len <= p.skip_decodes) return r;
+  if (p.only_decodes && r.q_len > p.only_decodes) return r;
   const int seq_len = p.seqused_k[r.seq];
   r.ctx_len = seq_len - r.q_len;
   r.q_pos = r.token - q_start;
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     ri.q_len = p.cu_seqlens_q[ri.seq + 1] - q_start;
     ri.q_pos = (unit - ri.seq * a.pack_cps) << a.pack_shift;                       // first token of the chunk
     if (ri.q_pos >= ri.q_len) return;                                              // (a sequence shorter than max_seqlen_q)
+    if (p.only_decodes && ri.q_len > p.only_decodes) return;                       // (a mixed batch: the prefill launch's rows)
     const int seq_len = p.seqused_k[ri.seq];
     const int rows = min(a.pack_tokens, ri.q_len - ri.q_pos);
     ri.ctx_len = seq_len - ri.q_len;
@@ -660,8 +661,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   constexpr int SLOT = D + kSlotPad;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ws_slots, 0, (int)a.ws_slot_bytes_total, 0x00020000);
   // slot rows are indexed by work unit: the query token, or the sequence when only decode rows are served
-  // (PACK: by query token, column by column)
-  const uint32_t slot_g0 = (uint32_t)(((uint32_t)(PACK ? ri.token : unit) * p.num_q_heads + hq0) * a.num_splits);   // slot of (g = 0, split 0)
+  // (PACK: a row per (unit, token of the chunk), column by column)
+  const uint32_t slot_g0 = (uint32_t)(((uint32_t)(PACK ? unit << a.pack_shift : unit) * p.num_q_heads + hq0) * a.num_splits);   // slot of (g = 0, split 0)
   auto slot_of_col = [&](int c) -> uint32_t {
     if constexpr (PACK) { const int t = c / G; return slot_g0 + (uint32_t)((t * p.num_q_heads + (c - t * G)) * a.num_splits); }
     return slot_g0 + (uint32_t)(c * a.num_splits);
@@ -782,11 +783,24 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
 
   const mi355_attn_params& p = a.p;
   const int hq = blockIdx.y, tid = threadIdx.x;
-  RowInfo ri = row_info(p, a.by_seq, blockIdx.x);
-  if (!ri.valid) return;
-  if (a.pack_tokens) {   // the token's partials were written by its chunk's waves, whose splits follow the chunk's last token
-    const int q0 = (ri.q_pos >> a.pack_shift) << a.pack_shift;
-    ri.n_keys = max(0, min(ri.ctx_len + min(q0 + a.pack_tokens, ri.q_len), ri.ctx_len + ri.q_len));
+  RowInfo ri;
+  if (a.pack_tokens) {   // rows are (unit, token of the unit's chunk); the partials' splits follow the chunk's LAST token
+    const int unit = blockIdx.x >> a.pack_shift, tq = blockIdx.x & (a.pack_tokens - 1);
+    ri.seq = a.pack_cps == 1 ? unit : unit / a.pack_cps;
+    if (ri.seq >= p.num_seqs) return;
+    const int q_start = p.cu_seqlens_q[ri.seq], q0 = (unit - ri.seq * a.pack_cps) << a.pack_shift;
+    ri.q_len = p.cu_seqlens_q[ri.seq + 1] - q_start;
+    ri.q_pos = q0 + tq;
+    if (ri.q_pos >= ri.q_len || (p.only_decodes && ri.q_len > p.only_decodes)) return;
+    const int seq_len = p.seqused_k[ri.seq];
+    ri.ctx_len = seq_len - ri.q_len;
+    ri.token = q_start + ri.q_pos;
+    ri.first_key = 0;
+    ri.n_keys = max(0, min(ri.ctx_len + min(q0 + a.pack_tokens, ri.q_len), seq_len));
+    ri.valid = true;
+  } else {
+    ri = row_info(p, a.by_seq, blockIdx.x);
+    if (!ri.valid) return;
   }
   const int tile_lo = ri.first_key / kTileKeys;
   const int tile_hi = (ri.n_keys + kTileKeys - 1) / kTileKeys;
@@ -901,15 +915,17 @@ static int query_head_groups(const mi355_attn_params& p) { return (p.num_q_heads
 // head sizes up to 128), both rounded down to a power of two; one group is taken when the longest query fits it.
 // MI355_DECODE_PACK=0 switches packing off, =1 keeps it to one column group (A/B).
 static int pow2_floor_shift(int x) { return x < 1 ? -1 : 31 - __builtin_clz((unsigned)x); }
+// only_decodes = N > 1 (the decode launch of a mixed batch): the rows of sequences with up to N query tokens.
+static int pack_max_q(const mi355_attn_params& p) { return p.only_decodes > 1 ? p.only_decodes : p.max_seqlen_q; }
 int decode_pack_groups(const mi355_attn_params& p) {
-  if (p.max_seqlen_q <= 1 || p.num_tokens <= p.num_seqs || p.only_decodes || p.skip_decodes || p.write_new_kv) return 0;
+  if (pack_max_q(p) <= 1 || p.num_tokens <= p.num_seqs || p.only_decodes == 1 || p.skip_decodes || p.write_new_kv) return 0;
   if (p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0) return 0;
   if (!layout_is_flash(p) || p.head_size != padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype))) return 0;
   const int G = p.num_q_heads / p.num_kv_heads;
   const char* e = getenv("MI355_DECODE_PACK");
   if (e && e[0] == '0') return 0;
   const bool one_ok = G <= 8, two_ok = G <= 16 && p.head_size <= 128 && !(e && e[0] == '1');
-  if (one_ok && (p.max_seqlen_q <= (1 << pow2_floor_shift(16 / G)) || !two_ok)) return 1;
+  if (one_ok && (pack_max_q(p) <= (1 << pow2_floor_shift(16 / G)) || !two_ok)) return 1;
   return two_ok ? 2 : 0;
 }
 // log2 of the query tokens one work unit holds (0 = not packed)
@@ -918,15 +934,26 @@ int decode_pack_shift(const mi355_attn_params& p) {
   return groups ? pow2_floor_shift(16 * groups / (p.num_q_heads / p.num_kv_heads)) : 0;
 }
 
-static int pack_chunks_per_seq(const mi355_attn_params& p, int ps) { return (p.max_seqlen_q + (1 << ps) - 1) >> ps; }
+static int pack_chunks_per_seq(const mi355_attn_params& p, int ps) { return (pack_max_q(p) + (1 << ps) - 1) >> ps; }
+// A mixed batch's rows with up to this many query tokens go to the decode launch (1: only one-token rows). The host
+// cannot know whether multi-token decode rows (speculative decoding) ride along with the prefills, and it need not:
+// one column group holds 16 / G tokens at the cost of a one-token row.
+int decode_rows_max_q(const mi355_attn_params& p) {
+  const int G = p.num_q_heads / p.num_kv_heads;
+  if (G > 8) return 1;
+  mi355_attn_params q = p;
+  q.skip_decodes = 0;
+  q.only_decodes = 1 << pow2_floor_shift(16 / G);
+  return (q.only_decodes > 1 && decode_pack_groups(q) == 1) ? q.only_decodes : 1;
+}
 // work units: sequences (only_decodes), query tokens, or - packed - chunks of query tokens
 static long decode_units(const mi355_attn_params& p) {
   const int ps = decode_pack_shift(p);
   if (ps) return (long)p.num_seqs * pack_chunks_per_seq(p, ps);
-  return p.only_decodes ? p.num_seqs : p.num_tokens;
+  return p.only_decodes == 1 ? p.num_seqs : p.num_tokens;
 }
-// rows of split partials: one per work unit and query head; packed units keep them by query token
-static long partial_rows(const mi355_attn_params& p) { return decode_pack_shift(p) ? p.num_tokens : decode_units(p); }
+// rows of split partials: one per work unit and query head; packed units keep one per token of their chunk
+static long partial_rows(const mi355_attn_params& p) { return decode_units(p) << decode_pack_shift(p); }
 
 // Capture-stable split policy: depends only on host-known sizes (units, Hk, max_seqlen_k).
 static SplitPlan plan_splits(const mi355_attn_params& p) {
@@ -997,7 +1024,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.group = p.num_q_heads / p.num_kv_heads;
   a.qgroups = query_head_groups(p);
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
-  a.by_seq = p.only_decodes ? 1 : 0;
+  a.by_seq = p.only_decodes == 1 ? 1 : 0;     // (only_decodes = N > 1 on a kernel that does not pack: token by token)
   a.d_valid = p.head_size;
   a.unit_is_seq = (!p.only_decodes && p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) ? 1 : 0;
   a.pack_shift = PACK ? decode_pack_shift(p) : 0;

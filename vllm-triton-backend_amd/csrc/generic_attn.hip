@@ -36,8 +36,8 @@ __global__ __launch_bounds__(64) void generic_attn_kernel(const GenericArgs a) {
   if (seq < 0 || seq >= p.num_seqs) return;
   const int q_start = p.cu_seqlens_q[seq];
   const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
-  if (p.skip_decodes && q_len == 1) return;
-  if (p.only_decodes && q_len != 1) return;
+  if (q_len <= p.skip_decodes) return;                       // (N: rows of sequences with up to N query tokens are another launch's)
+  if (p.only_decodes && q_len > p.only_decodes) return;
   const int seq_len = p.seqused_k[seq];
   const int ctx_len = seq_len - q_len;
   const int q_pos = token - q_start;          // position inside the query

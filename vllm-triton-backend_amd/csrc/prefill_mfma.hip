@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
   const int qb_local = qblock - (q_start / BQ + seq);
   if (qb_local * BQ >= q_len) return;                      // surplus program (:338-339)
-  if (p.skip_decodes && q_len == 1) return;
-  if (p.only_decodes && q_len != 1) return;
+  if (q_len <= p.skip_decodes) return;                     // (N: rows of sequences with up to N query tokens are another launch's)
+  if (p.only_decodes && q_len > p.only_decodes) return;
   const int seq_len = p.seqused_k[seq];
   const int ctx_len = seq_len - q_len;
   const int tok0 = qb_local * BQ;                          // first query token (local) of this Q block
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
   const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
   const int qb_local = qblock - (q_start / BQ + seq);
   const int seq_len = p.seqused_k[seq];
-  if (qb_local * BQ >= q_len || (p.skip_decodes && q_len == 1) || (p.only_decodes && q_len != 1)) {
+  if (qb_local * BQ >= q_len || q_len <= p.skip_decodes || (p.only_decodes && q_len > p.only_decodes)) {
     if constexpr (BT_IN_LDS) glds_wait_all();   // never leave with a DMA into this workgroup's LDS in flight
     return;
   }
@@ -1326,9 +1326,9 @@ __global__ __launch_bounds__(256) void merge_key_splits_kernel(const MergeArgs a
   const int64_t tok = row / p.num_q_heads;
   const int hq = (int)(row % p.num_q_heads);
   if (p.cu_seqlens_q && tok >= p.cu_seqlens_q[p.num_seqs]) return;   // padding tokens past the last sequence belong to nobody
-  if (p.skip_decodes && p.cu_seqlens_q) {      // rows of query_len == 1 sequences were not computed and must stay untouched
+  if (p.skip_decodes && p.cu_seqlens_q) {      // rows of query_len <= skip_decodes sequences were not computed and must stay untouched
     const int seq = find_seq_by_token(p.cu_seqlens_q, p.num_seqs, (int)tok);
-    if (p.cu_seqlens_q[seq + 1] - p.cu_seqlens_q[seq] == 1) return;
+    if (p.cu_seqlens_q[seq + 1] - p.cu_seqlens_q[seq] <= p.skip_decodes) return;
   }
   float lse[kMaxKeySplits], m = -INFINITY;
 #pragma unroll

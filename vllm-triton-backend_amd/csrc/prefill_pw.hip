@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       }
       if (seq < 0) return false;
       const int qb_local = qblock - (div_bq(q_start) + seq);
-      if (qb_local * BQ >= q_len || (sa.skip_decodes && q_len == 1) || (sa.only_decodes && q_len != 1)) return false;
+      if (qb_local * BQ >= q_len || q_len <= sa.skip_decodes || (sa.only_decodes && q_len > sa.only_decodes)) return false;
       I.seq = seq; I.q_start = q_start; I.q_len = q_len; I.seq_len = seq_len;
       // non-causal (prefill_flash_attention(causal=False)): every row sees all seq_len keys - which is what every
       // visibility formula below gives for a context that already covers the whole sequence
