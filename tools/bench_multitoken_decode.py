@@ -18,6 +18,8 @@ import bench_mixed  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", nargs="*", default=["64x4x8192", "64x2x8192", "64x8x8192", "16x4x32768", "128x4x2048", "8x4x512", "64x3x8192", "64x16x8192"])
+    ap.add_argument("--mixed", nargs="*", type=lambda x: tuple(int(v) for v in x.split("x")), default=[],
+                    help="rows x tokens x keys x chunks x chunk-tokens, e.g. 32x4x8192x2x2048")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--hq", type=int, default=32)
     ap.add_argument("--hk", type=int, default=8)
@@ -34,6 +36,15 @@ def main():
             t, fl, by, kern = bench_mixed.run([ql] * b, [kv] * b, dev, iters=a.iters)
             row.append(f"{'packed' if pack != '0' else 'former'} {t * 1e6:8.1f} us {by / t / 1e12:5.2f} TB/s {kern}")
         print(f"{sh:>14}: " + "   |   ".join(row), flush=True)
+    # a step that mixes prefill chunks with multi-token decode rows: rows x tokens x keys + chunks x tokens (no context)
+    for rows, ql, kv, chunks, cl in a.mixed:
+        row = []
+        for pack in ("0", "2"):
+            os.environ["MI355_DECODE_PACK"] = pack
+            torch.manual_seed(0)
+            t, fl, by, kern = bench_mixed.run([ql] * rows + [cl] * chunks, [kv] * rows + [cl] * chunks, dev, iters=a.iters)
+            row.append(f"{'packed' if pack != '0' else 'former'} {t * 1e6:8.1f} us {kern}")
+        print(f"{rows}x{ql}x{kv} + {chunks}x{cl}: " + "   |   ".join(row), flush=True)
     os.environ.pop("MI355_DECODE_PACK", None)
 
 
