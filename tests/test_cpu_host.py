@@ -116,7 +116,7 @@ def test_workspace_bytes_is_host_arithmetic(lib):
 
 def test_workspace_bytes_of_a_multi_token_decode_step(lib):
     """Speculative-decoding / MTP verification batches whose longest query fits the decode kernel's packed columns take
-    the decode kernel (host-known sizes only): partials per QUERY TOKEN and head, splits planned per sequence."""
+    the decode kernel (host-known sizes only): partials per token slot of a unit and head, splits planned per sequence."""
     h = lib.load()
     buf = np.zeros(64, dtype=np.uint8)
     addr = (buf.ctypes.data + 15) & ~15
@@ -128,7 +128,8 @@ def test_workspace_bytes_of_a_multi_token_decode_step(lib):
     for q_len in (2, 3, 4, 8):                                      # one column group holds 4 tokens, two hold 8
         p.num_tokens, p.max_seqlen_q = 64 * q_len, q_len
         n = h.mi355_attn_workspace_bytes(C.byref(p))
-        assert n == counters + 64 * q_len * 32 * splits * slot, (q_len, n)
+        per_unit = 4 if q_len <= 4 else 8                            # partial rows: one per (sequence, token slot of its unit)
+        assert n == counters + 64 * per_unit * 32 * splits * slot, (q_len, n)
     p.num_tokens, p.max_seqlen_q = 64 * 9, 9                        # more than the columns hold: the prefill path (a uniform batch: no decode rows)
     assert h.mi355_attn_workspace_bytes(C.byref(p)) in (0, counters)
     p.num_tokens, p.max_seqlen_q = 64 * 4, 4
