@@ -698,7 +698,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   // (two column groups: one after the other, every lane on its own column - NS = 1)
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) {
-  const int C = PACK ? min(16, (G << a.pack_shift) - 16 * cg) : G;            // columns of this group in use
+  // columns of this group in use - by THIS unit's tokens: a unit with fewer tokens than the chunk holds (a one-token row
+  // of a mixed step) spreads its splits over the idle lanes like the plain kernel does
+  const int C = PACK ? min(16, G * min(a.pack_tokens, ri.q_len - ri.q_pos) - 16 * cg) : G;
   const int Gp = NCG > 1 ? 16 : C <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(C - 1)));   // ... rounded up to a power of two
   const int NS = 16 / Gp;
   const int gm = g & (Gp - 1), sub = g / Gp;
@@ -1057,7 +1059,9 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     // loads in flight, see the kernel's epilogue); more splits than that merge faster in a launch of
     // their own, which is one round trip at any split count
     const int G = std::min(a.group, 16) << a.pack_shift, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // columns in use
-    const int one_trip = (PACK == 2 ? 1 : 16 / Gp) * (D >= 128 ? 2 : 4);
+    // (one column group of packed tokens: two trips at worst - a unit with every column in use - against a merge launch
+    // over all token slots; units with fewer tokens walk their splits on more lanes, see the kernel)
+    const int one_trip = (PACK == 2 ? 1 : PACK == 1 ? 2 : 16 / Gp) * (D >= 128 ? 2 : 4);
     a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip) ? 0 : 1;
   }
   const long units = decode_units(p);
