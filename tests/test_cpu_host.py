@@ -133,7 +133,9 @@ def test_workspace_bytes_of_a_multi_token_decode_step(lib):
     p.num_tokens, p.max_seqlen_q = 64 * 9, 9                        # more than the columns hold: the prefill path (a uniform batch: no decode rows)
     assert h.mi355_attn_workspace_bytes(C.byref(p)) in (0, counters)
     p.num_tokens, p.max_seqlen_q = 64 * 4, 4
-    p.sliding_window = 128                                          # the packed kernels are plain attention only
+    p.sliding_window = 128                                          # features: the same, on one column group ...
+    assert h.mi355_attn_workspace_bytes(C.byref(p)) > counters
+    p.num_tokens, p.max_seqlen_q = 64 * 8, 8                        # ... and no second one: the prefill path
     assert h.mi355_attn_workspace_bytes(C.byref(p)) in (0, counters)
 
 

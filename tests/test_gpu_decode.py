@@ -400,7 +400,9 @@ def test_multi_token_decode_dispatch():
     inp = orc.make_paged_inputs(37, [4, 4], [300, 200], 16, 2, 256, 16, torch.bfloat16)      # head size 256: one column group only
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
     inp = orc.make_paged_inputs(32, [4, 4], [300, 200], 8, 2, 128, 16, torch.bfloat16)
-    assert "pack" not in _check(inp, torch.bfloat16, force=None, window=64)
+    assert "pack" in _check(inp, torch.bfloat16, force=None, window=64)                      # features: one column group
+    inp = orc.make_paged_inputs(32, [8, 8], [300, 200], 8, 2, 128, 16, torch.bfloat16)
+    assert "pack" not in _check(inp, torch.bfloat16, force=None, window=64)                  # ... and no second one
     inp = orc.make_paged_inputs(33, [2, 2], [300, 200], 34, 2, 128, 16, torch.bfloat16)      # G = 17
     assert "pack" not in _check(inp, torch.bfloat16, force=None)
     inp = orc.make_paged_inputs(34, [40, 33], [300, 200], 32, 8, 128, 16, torch.bfloat16)
@@ -426,10 +428,24 @@ def test_mixed_batch_sends_multi_token_decode_rows_to_the_decode_launch():
         assert "+decode" in kernel and "pack" in kernel, kernel
         assert not torch.isnan(out).any() and torch.isfinite(lse).all(), (hq, hk)
         torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
-    # features keep the one-token split
+    # with a sliding window: the packed kernel's feature instantiation
     inp = orc.make_paged_inputs(62, query_lens, kv_lens, 32, 8, 128, 16, torch.bfloat16)
     ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
                                        inp["scale"], sliding_window=100, mode="2d", block_n=64)
     out, kernel = gpu_util.run_unified(gpu_util.to_dev(inp), inp["scale"], window=100)
-    assert "pack" not in kernel, kernel
+    assert "+decode" in kernel and "pack" in kernel, kernel
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("hq,hk,q_lens", [(32, 8, [4, 1, 3, 2, 4, 4]), (16, 2, [2, 1, 2, 2, 1, 2]), (8, 8, [16, 5, 9, 1, 12, 16])])
+def test_multi_token_decode_features_window_softcap_alibi(hq, hk, q_lens):
+    """The packed kernel's feature instantiation: per-column window starts (token i of a chunk sees keys from
+    ctx_len + i - window + 1 on), soft-cap, ALiBi slopes per column's head; windows shorter than a tile, shorter than
+    the chunk, and longer than the context."""
+    kv_lens = [700 + q_lens[0], 45, 3 + q_lens[2], q_lens[3], 1030, 65 + q_lens[5]]
+    inp = orc.make_paged_inputs(71, q_lens, kv_lens, hq, hk, 128, 16, torch.float16)
+    alibi = torch.tensor([2.0 ** (-(i % 8 + 1)) for i in range(hq)], dtype=torch.float32)
+    for kw in (dict(window=3), dict(window=8), dict(window=33), dict(window=100), dict(window=5000), dict(softcap=30.0), dict(alibi=alibi),
+               dict(window=64, softcap=20.0, alibi=alibi)):
+        kernel = _check(inp, torch.float16, force=None, expect="decode_s", **kw)
+        assert "pack" in kernel, (kernel, kw)

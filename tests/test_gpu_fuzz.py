@@ -96,27 +96,34 @@ def test_packed_multi_token_decode_agrees_with_the_generic_kernel(case_id):
     kv_dtype = rng.choice([None, None, torch.float8_e4m3fn, torch.float8_e5m2])
     page = rng.choice([16, 16, 32, 128])
     segments = rng.choice([0, 0, 1, 2, 3, 8, 33])
+    window = rng.choice([0, 0, 0, 0, 3, 40, 300])
+    softcap = rng.choice([0.0, 0.0, 0.0, 25.0])
+    use_alibi = rng.random() < 0.15
+    feat = window > 0 or softcap > 0 or use_alibi
     kw = dict(kv_dtype=kv_dtype, kv_scale=0.5) if kv_dtype is not None else {}
     inp = orc.make_paged_inputs(PACK_SEED + case_id, q_lens, kv_lens, hk * g, hk, d, page, dtype, **kw)
     t = gpu_util.to_dev(inp)
     scale = 1.0 / math.sqrt(d)
     n_tok = t["q"].shape[0]
     ref_lse = torch.full((n_tok, hk * g), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
-    ref, ref_kernel = gpu_util.run_unified(t, scale, kv_scale=0.5 if kv_dtype is not None else None, force=9, lse=ref_lse)
+    if use_alibi:
+        t["alibi_slopes"] = torch.tensor([2.0 ** (-(i % 8 + 1)) for i in range(hk * g)], dtype=torch.float32, device=gpu_util.DEV)
+    ref, ref_kernel = gpu_util.run_unified(t, scale, window=window, softcap=softcap, kv_scale=0.5 if kv_dtype is not None else None, force=9, lse=ref_lse)
     assert ref_kernel == "generic"
     out = torch.full_like(t["q"], float("nan"))
     lse = torch.full_like(ref_lse, float("nan"))
     descale = torch.tensor([0.5], dtype=torch.float32, device=gpu_util.DEV) if kv_dtype is not None else None
     p, keep = ua_mod.fill_attn_params(t["q"], t["k_cache"], t["v_cache"], out, t["cu_seqlens_q"], max(q_lens), t["seqused_k"], max(kv_lens),
-                                      scale, (-1, -1), t["block_table"], 0.0, descale, descale, None, 3, num_segments=segments, lse=lse)
+                                      scale, (window - 1, 0) if window else (-1, -1), t["block_table"], softcap, descale, descale, t.get("alibi_slopes"), 3,
+                                      num_segments=segments, lse=lse)
     ua_mod.launch(p, gpu_util.DEV)
     torch.cuda.synchronize()
     kernel = _lib.last_kernel()
-    packable = max(q_lens) > 1 and sum(q_lens) > n_seq and (g <= 8 or d <= 128)
+    packable = max(q_lens) > 1 and sum(q_lens) > n_seq and (g <= 8 or (d <= 128 and not feat))      # features: one column group
     assert ("pack" in kernel) == packable, (kernel, g, d, q_lens)
     assert not torch.isnan(out).any(), (kernel, q_lens, kv_lens)
     atol, rtol = golden_io.tolerance(dtype, kv_dtype)
-    case = dict(g=g, hk=hk, d=d, q_lens=q_lens, kv_lens=kv_lens, page=page, segments=segments, kv_dtype=kv_dtype)
+    case = dict(g=g, hk=hk, d=d, q_lens=q_lens, kv_lens=kv_lens, page=page, segments=segments, kv_dtype=kv_dtype, window=window, softcap=softcap, alibi=use_alibi)
     torch.testing.assert_close(out.float(), ref.float(), atol=atol, rtol=rtol, msg=lambda m: f"[{kernel}] {case}\n{m}")
     torch.testing.assert_close(lse, ref_lse, atol=5e-2, rtol=0, msg=lambda m: f"[{kernel}] lse {case}\n{m}")
 

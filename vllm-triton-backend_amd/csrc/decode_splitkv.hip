@@ -49,6 +49,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
+#ifndef DECODE_TU
+#define DECODE_TU 0
+#endif
 constexpr int kTileKeys = 32;
 constexpr int kMaxSplits = 128;
 constexpr int kSlotPad = 32;   // floats appended to a D-float partial (m, l, padding to a 128-byte multiple)
@@ -178,7 +181,8 @@ __device__ __forceinline__ RowInfo row_info(const mi355_attn_params& p, int by_s
 template <typename T, typename KVT, int D, int WAVES, bool FEAT, bool PAD, bool V0, int PACK = 0>
 __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const DecodeArgs a) {
   static_assert(!V0 || (__is_same(T, KVT) && !PAD), "the v0 layout path serves same-type 16-bit caches of a built head size");
-  static_assert(!PACK || (!FEAT && !PAD && !V0), "packed query tokens: plain attention on a flash-layout cache of a built head size");
+  static_assert(!PACK || (!PAD && !V0), "packed query tokens: a flash-layout cache of a built head size");
+  static_assert(PACK != 2 || !FEAT, "two column groups: plain attention only");
   static_assert(PACK != 2 || D <= 128, "two column groups: O, Q and the K/V tiles in flight fit the register file up to head size 128");
   constexpr int NCG = PACK == 2 ? 2 : 1;            // column groups (16 matrix columns each) per wave
   constexpr bool FP8 = !__is_same(T, KVT);
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     ri.ctx_len = seq_len - ri.q_len;
     ri.token = q_start + ri.q_pos;
     ri.n_keys = max(0, min(ri.ctx_len + ri.q_pos + rows, seq_len));               // the chunk's last token sees the most
-    ri.first_key = 0;
+    ri.first_key = (FEAT && p.sliding_window > 0) ? max(0, ri.ctx_len + ri.q_pos - p.sliding_window + 1) : 0;   // the chunk's FIRST token's (the lowest)
     ri.valid = true;
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
@@ -311,6 +315,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     n_keys_col[cg] = PACK ? max(0, min(ctx_len + ri.q_pos + tq[cg] + 1, n_keys)) : n_keys;
   }
   const int n_keys_min = PACK ? max(0, min(ctx_len + ri.q_pos + 1, n_keys)) : n_keys;
+  // sliding window: the first key this lane's column sees / the highest first key of any column (tiles from it on need no window mask)
+  const int first_key_col = (PACK && FEAT && p.sliding_window > 0) ? max(0, ctx_len + ri.q_pos + tq[0] - p.sliding_window + 1) : first_key;
+  const int first_key_max = (PACK && FEAT && p.sliding_window > 0) ? max(0, n_keys - p.sliding_window) : first_key;
 
   const int tile_lo = first_key / kTileKeys;
   const int tile_hi = (n_keys + kTileKeys - 1) / kTileKeys;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 
   const float k_scale = (FP8 && p.k_scale) ? p.k_scale[0] : 1.0f;
   const float v_scale = (FP8 && p.v_scale) ? p.v_scale[0] : 1.0f;
-  const float slope = (FEAT && p.alibi_slopes && g_ok[0]) ? p.alibi_slopes[hq[0]] : 0.0f;
+  const float slope = (FEAT && p.alibi_slopes && g_ok[0]) ? p.alibi_slopes[hq[0]] : 0.0f;   // (FEAT kernels have one column group)
   const float scale_nat = p.scale * k_scale;     // fp8: K is used un-scaled, its scale moves here
   const float scale2 = scale_nat * kLog2e;
   const int32_t* bt = p.block_table + (int64_t)ri.seq * p.block_table_stride;
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     float alpha[NCG];
     s16x8_t pf[NCG];
     const bool plain = !FEAT || (!(p.softcap > 0.0f) && !p.alibi_slopes);
-    const bool need_mask = (PACK ? tile * kTileKeys + kTileKeys > n_keys_min : tail) || (FEAT && tile * kTileKeys < first_key);
+    const bool need_mask = (PACK ? tile * kTileKeys + kTileKeys > n_keys_min : tail) || (FEAT && tile * kTileKeys < first_key_max);
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
     float sv[8];
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
         const int key = tile * kTileKeys + (j >> 2) * 16 + grp * 4 + (j & 3);
         float x = sv[j] * scale_nat;
         if (p.softcap > 0.0f) x = softcap_fast(x, p.softcap, 2.0f * kLog2e / p.softcap);
-        if (key >= n_keys || key < first_key) x = -INFINITY;
+        if (key >= n_keys_col[cg] || key < first_key_col) x = -INFINITY;
         if (p.alibi_slopes) x += slope * (float)(key - ctx_len);
         sv[j] = x * kLog2e;
       }
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const DecodeArgs a) 
     const int seq_len = p.seqused_k[ri.seq];
     ri.ctx_len = seq_len - ri.q_len;
     ri.token = q_start + ri.q_pos;
-    ri.first_key = 0;
+    ri.first_key = p.sliding_window > 0 ? max(0, ri.ctx_len + q0 - p.sliding_window + 1) : 0;   // the chunk's first token's
     ri.n_keys = max(0, min(ri.ctx_len + min(q0 + a.pack_tokens, ri.q_len), seq_len));
     ri.valid = true;
   } else {
@@ -875,6 +882,7 @@ static bool layout_is_v0(const mi355_attn_params& p) {
          (p.head_size == 64 || p.head_size == 128 || p.head_size == 256);
 }
 
+#if DECODE_TU == 0
 bool decode_supported(const mi355_attn_params& p) {
   if (!(p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16)) return false;
   if (p.kv_dtype != p.q_dtype && !is_fp8_dtype(p.kv_dtype)) return false;
@@ -898,13 +906,16 @@ bool decode_supported(const mi355_attn_params& p) {
   if (p.k_stride_page >= (1LL << 31) || p.v_stride_page >= (1LL << 31)) return false;
   return true;
 }
+#endif
 
+#if DECODE_TU == 0
 bool decode_write_fusable(const mi355_attn_params& p) {
   mi355_attn_params q = p;
   q.write_new_kv = 1;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;   // (the feature kernels take the general row lookup)
   return !feat && p.kernel_select != MI355_SELECT_GENERIC && p.kernel_select != MI355_SELECT_2D && decode_supported(q);
 }
+#endif
 
 struct SplitPlan { int num_splits, tiles_per_split; };
 
@@ -919,27 +930,32 @@ static int query_head_groups(const mi355_attn_params& p) { return (p.num_q_heads
 static int pow2_floor_shift(int x) { return x < 1 ? -1 : 31 - __builtin_clz((unsigned)x); }
 // only_decodes = N > 1 (the decode launch of a mixed batch): the rows of sequences with up to N query tokens.
 static int pack_max_q(const mi355_attn_params& p) { return p.only_decodes > 1 ? p.only_decodes : p.max_seqlen_q; }
+#if DECODE_TU == 0
 int decode_pack_groups(const mi355_attn_params& p) {
   if (pack_max_q(p) <= 1 || p.num_tokens <= p.num_seqs || p.only_decodes == 1 || p.skip_decodes || p.write_new_kv) return 0;
-  if (p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0) return 0;
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;   // (one column group only)
   if (!layout_is_flash(p) || p.head_size != padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype))) return 0;
   const int G = p.num_q_heads / p.num_kv_heads;
   const char* e = getenv("MI355_DECODE_PACK");
   if (e && e[0] == '0') return 0;
-  const bool one_ok = G <= 8, two_ok = G <= 16 && p.head_size <= 128 && !(e && e[0] == '1');
+  const bool one_ok = G <= 8, two_ok = G <= 16 && p.head_size <= 128 && !feat && !(e && e[0] == '1');
   if (one_ok && (pack_max_q(p) <= (1 << pow2_floor_shift(16 / G)) || !two_ok)) return 1;
   return two_ok ? 2 : 0;
 }
+#endif
 // log2 of the query tokens one work unit holds (0 = not packed)
+#if DECODE_TU == 0
 int decode_pack_shift(const mi355_attn_params& p) {
   const int groups = decode_pack_groups(p);
   return groups ? pow2_floor_shift(16 * groups / (p.num_q_heads / p.num_kv_heads)) : 0;
 }
+#endif
 
 static int pack_chunks_per_seq(const mi355_attn_params& p, int ps) { return (pack_max_q(p) + (1 << ps) - 1) >> ps; }
 // A mixed batch's rows with up to this many query tokens go to the decode launch (1: only one-token rows). The host
 // cannot know whether multi-token decode rows (speculative decoding) ride along with the prefills, and it need not:
 // one column group holds 16 / G tokens at the cost of a one-token row.
+#if DECODE_TU == 0
 int decode_rows_max_q(const mi355_attn_params& p) {
   const int G = p.num_q_heads / p.num_kv_heads;
   if (G > 8) return 1;
@@ -948,6 +964,7 @@ int decode_rows_max_q(const mi355_attn_params& p) {
   q.only_decodes = 1 << pow2_floor_shift(16 / G);
   return (q.only_decodes > 1 && decode_pack_groups(q) == 1) ? q.only_decodes : 1;
 }
+#endif
 // work units: sequences (only_decodes), query tokens, or - packed - chunks of query tokens
 static long decode_units(const mi355_attn_params& p) {
   const int ps = decode_pack_shift(p);
@@ -1006,6 +1023,7 @@ static bool counters_fit(const mi355_attn_params& p) {
   return (size_t)decode_units(p) * p.num_kv_heads * query_head_groups(p) * sizeof(int) <= kCounterRegionBytes;
 }
 
+#if DECODE_TU == 0
 size_t decode_workspace_bytes(const mi355_attn_params& p) {
   if (!decode_supported(p)) return 0;
   const int splits = plan_splits(p).num_splits;
@@ -1013,6 +1031,7 @@ size_t decode_workspace_bytes(const mi355_attn_params& p) {
   const size_t slots = (size_t)partial_rows(p) * p.num_q_heads * splits;
   return counters_bytes(p) + slots * (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) + kSlotPad) * sizeof(float);
 }
+#endif
 
 template <typename T, typename KVT, int D, bool FEAT, bool PAD, bool V0, int PACK = 0>
 static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -1088,6 +1107,31 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   return rc;
 }
 
+// The PACK instantiations are built in a translation unit of their own (decode_splitkv_pack.hip: this source with
+// DECODE_TU = 1), so that the library's objects keep compiling side by side in about a minute each.
+template <typename T, typename KVT, int D>
+int launch_decode_pack(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream, bool feat, int groups);
+
+#if DECODE_TU == 1
+template <typename T, typename KVT, int D>
+int launch_decode_pack(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream, bool feat, int groups) {
+  if (groups == 1)
+    return feat ? launch_decode_t<T, KVT, D, true, false, false, 1>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, false, 1>(p, ws, ws_bytes, stream);
+  if constexpr (D <= 128)
+    if (groups == 2 && !feat) return launch_decode_t<T, KVT, D, false, false, false, 2>(p, ws, ws_bytes, stream);
+  set_error("decode: no packed kernel for %d column groups at head size %d", groups, D);
+  return MI355_ERR_UNSUPPORTED;
+}
+#define MI355_PACK_INST(T, KVT) \
+  template int launch_decode_pack<T, KVT, 64>(const mi355_attn_params&, void*, size_t, hipStream_t, bool, int); \
+  template int launch_decode_pack<T, KVT, 128>(const mi355_attn_params&, void*, size_t, hipStream_t, bool, int); \
+  template int launch_decode_pack<T, KVT, 256>(const mi355_attn_params&, void*, size_t, hipStream_t, bool, int);
+MI355_PACK_INST(bf16_t, bf16_t) MI355_PACK_INST(bf16_t, e4m3_t) MI355_PACK_INST(bf16_t, e5m2_t)
+MI355_PACK_INST(f16_t, f16_t) MI355_PACK_INST(f16_t, e4m3_t) MI355_PACK_INST(f16_t, e5m2_t)
+#undef MI355_PACK_INST
+#endif
+
+#if DECODE_TU == 0
 template <typename T, typename KVT, int D>
 static int launch_decode_f(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStream_t stream) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
@@ -1095,9 +1139,7 @@ static int launch_decode_f(const mi355_attn_params& p, void* ws, size_t ws_bytes
     if (!layout_is_flash(p))   // decode_supported admitted it: the legacy v0 layout
       return feat ? launch_decode_t<T, KVT, D, true, false, true>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, true>(p, ws, ws_bytes, stream);
   }
-  if (!feat && decode_pack_groups(p) == 1) return launch_decode_t<T, KVT, D, false, false, false, 1>(p, ws, ws_bytes, stream);
-  if constexpr (D <= 128)
-    if (!feat && decode_pack_groups(p) == 2) return launch_decode_t<T, KVT, D, false, false, false, 2>(p, ws, ws_bytes, stream);
+  if (const int groups = decode_pack_groups(p)) return launch_decode_pack<T, KVT, D>(p, ws, ws_bytes, stream, feat, groups);
   if (p.head_size != D)
     return feat ? launch_decode_t<T, KVT, D, true, true, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, true, false>(p, ws, ws_bytes, stream);
   return feat ? launch_decode_t<T, KVT, D, true, false, false>(p, ws, ws_bytes, stream) : launch_decode_t<T, KVT, D, false, false, false>(p, ws, ws_bytes, stream);
@@ -1129,5 +1171,6 @@ int launch_decode(const mi355_attn_params& p, void* ws, size_t ws_bytes, hipStre
   if (p.q_dtype == MI355_BF16) return launch_decode_kv<bf16_t>(p, ws, ws_bytes, stream);
   return launch_decode_kv<f16_t>(p, ws, ws_bytes, stream);
 }
+#endif
 
 }  // namespace mi355
