@@ -31,6 +31,7 @@ def c4_lens(batch=64, seqlen=4096, page=16):
 
 
 HQ, HK = 32, 8
+WINDOW = 0          # sliding window (keys), 0 = none
 
 
 def run(qlens, kvlens, dev, iters=10):
@@ -52,7 +53,7 @@ def run(qlens, kvlens, dev, iters=10):
     cu = cu.to(dev)
     sl = torch.tensor(kvlens, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
-    p, keep = ua.fill_attn_params(q, k, v, out, cu, max(qlens), sl, max(kvlens), 1 / math.sqrt(D), (-1, -1), bt, 0.0, None, None, None, None)
+    p, keep = ua.fill_attn_params(q, k, v, out, cu, max(qlens), sl, max(kvlens), 1 / math.sqrt(D), (WINDOW - 1, 0) if WINDOW else (-1, -1), bt, 0.0, None, None, None, None)
     for _ in range(3):
         ua.launch(p, dev)
     torch.cuda.synchronize()

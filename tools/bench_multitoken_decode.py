@@ -23,9 +23,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--hq", type=int, default=32)
     ap.add_argument("--hk", type=int, default=8)
+    ap.add_argument("--window", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    bench_mixed.HQ, bench_mixed.HK = a.hq, a.hk
+    bench_mixed.HQ, bench_mixed.HK, bench_mixed.WINDOW = a.hq, a.hk, a.window
+    if a.window:
+        print(f"# sliding window {a.window} (the stream rate column still counts ALL keys of the context)")
     print(f"# sequences x query tokens x keys (Hq {a.hq} / Hk {a.hk} / D 128, bf16): median us, K/V stream rate, kernel")
     for sh in a.shapes:
         b, ql, kv = (int(x) for x in sh.split("x"))
