@@ -26,9 +26,12 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 400 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 500 /* major*10000 + minor*100 + patch */
 /*
  * Version notes (what a caller written against an older header must know)
+ *   0.5.0  Multi-token decode steps (speculative decoding / MTP verification) on the split-KV decode kernel, several
+ *          query tokens of a sequence per wave. skip_decodes / only_decodes became query-length thresholds (1 keeps
+ *          its meaning); reserved2 became decode_rows_hint (0 = as before).
  *   0.4.0  mi355_attn_params grew at its END (slot_mapping, slot_mapping_i32, new_kv_all_rows, reserved2): zero the
  *          struct before filling it and nothing changes. A fused decode write (write_new_kv) now honours
  *          slot_mapping[i] < 0 (padding row: the cache is not written) when a slot mapping is handed in.
@@ -192,7 +195,12 @@ typedef struct mi355_attn_params {
    * linear tensors as well (self-attention over linear K/V with no cache behind it, prefill_flash_attention); 0 = the
    * legacy ops' rule, such rows read the cache only (chunked_prefill_paged_decode) */
   int32_t new_kv_all_rows;
-  int32_t reserved2;
+  /* library version >= 0.5.0. A step that mixes prefills with shorter rows is served by two launches, and sequences of
+   * up to N query tokens are the decode launch's. 0: the library picks N = 16 / G (what one column group of the packed
+   * decode kernel holds - a one-token row costs nothing extra there). A caller that KNOWS its decode rows carry more
+   * tokens (speculative decoding with k drafts: 1 + k) says so here and gets N = that, up to 32 / G (two column groups;
+   * ignored where they do not apply: features, head size 256, more). Host-known, so capture-stable. */
+  int32_t decode_rows_hint;
 } mi355_attn_params;
 
 /*

@@ -289,7 +289,7 @@ def test_op_signatures_keep_the_reference_parameter_names():
         "q", "k", "v", "out", "cu_seqlens_q", "max_seqlen_q", "seqused_k", "max_seqlen_k", "avg_seqlen_q", "avg_seqlen_k",
         "softmax_scale", "causal", "window_size", "block_table", "softcap", "q_descale", "k_descale", "v_descale",
         "alibi_slopes", "force_selection",
-        "softmax_lse"]                                   # extension (optional second output), after the reference's parameters
+        "softmax_lse", "decode_rows_hint"]               # extensions (optional second output; decode-row length of a speculative step), after the reference's parameters
     assert names(kernels.prefill_flash_attention) == [
         "q", "k", "v", "max_seqlen_q", "max_seqlen_k", "cu_seqlens_q", "cu_seqlens_k", "causal", "sm_scale", "bias", "config",
         "in_place_output", "do_not_return_softmax_encodings"]

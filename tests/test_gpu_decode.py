@@ -449,3 +449,30 @@ def test_multi_token_decode_features_window_softcap_alibi(hq, hk, q_lens):
                dict(window=64, softcap=20.0, alibi=alibi)):
         kernel = _check(inp, torch.float16, force=None, expect="decode_s", **kw)
         assert "pack" in kernel, (kernel, kw)
+
+
+def test_mixed_batch_with_a_decode_row_hint_uses_two_column_groups():
+    """A caller that knows its decode rows carry 1 + k tokens (speculative decoding) says so: rows of up to that many
+    tokens - beyond what one column group holds - ride the decode launch on two column groups; a hint the packed kernels
+    cannot hold (features, too long) falls back to the library's own threshold. Every row exactly once, against the oracle."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels import unified_attention
+
+    query_lens = [300, 4, 1, 3, 5, 2, 4, 64, 1, 8]
+    kv_lens = [900, 640, 17, 2048, 333, 2, 4, 64, 513, 1000]
+    for hq, hk, hint, window, want in [(64, 8, 4, 0, "pack2"), (32, 8, 8, 0, "pack2"), (32, 8, 4, 0, "pack"), (32, 8, 8, 100, "pack"), (32, 8, 64, 0, "pack")]:
+        inp = orc.make_paged_inputs(63, query_lens, kv_lens, hq, hk, 128, 16, torch.bfloat16)
+        ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                           inp["scale"], sliding_window=window, mode="2d", block_n=64)
+        d = gpu_util.to_dev(inp)
+        out = torch.full_like(d["q"], float("nan"))
+        unified_attention(q=d["q"], k=d["k_cache"], v=d["v_cache"], out=out, cu_seqlens_q=d["cu_seqlens_q"], max_seqlen_q=max(query_lens),
+                          seqused_k=d["seqused_k"], max_seqlen_k=max(kv_lens), avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=inp["scale"], causal=True,
+                          window_size=(window - 1, 0) if window else (-1, -1), block_table=d["block_table"], softcap=0, q_descale=None,
+                          k_descale=None, v_descale=None, decode_rows_hint=hint)
+        torch.cuda.synchronize()
+        kernel = _lib.last_kernel()
+        assert "+decode" in kernel and want in kernel and (want != "pack" or "pack2" not in kernel), (kernel, hq, hint, window)
+        assert not torch.isnan(out).any(), (hq, hint)
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)

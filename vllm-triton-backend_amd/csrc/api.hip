@@ -53,6 +53,7 @@ static int validate(const mi355_attn_params* p) {
     return MI355_ERR_BAD_ARG;
   }
   if (p->lse && p->lse_stride_token < p->num_q_heads) { set_error("lse_stride_token %lld is smaller than num_q_heads %d", (long long)p->lse_stride_token, p->num_q_heads); return MI355_ERR_BAD_ARG; }
+  if (p->decode_rows_hint < 0) { set_error("decode_rows_hint must not be negative"); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes < 0 || p->only_decodes < 0) { set_error("skip_decodes / only_decodes are query-length thresholds: not negative"); return MI355_ERR_BAD_ARG; }
   if (p->skip_decodes && p->only_decodes) { set_error("skip_decodes and only_decodes exclude each other"); return MI355_ERR_BAD_ARG; }
   if (p->non_causal && (p->sliding_window > 0 || p->alibi_slopes || p->write_new_kv)) {

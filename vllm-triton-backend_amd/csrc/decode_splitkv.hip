@@ -958,9 +958,13 @@ static int pack_chunks_per_seq(const mi355_attn_params& p, int ps) { return (pac
 #if DECODE_TU == 0
 int decode_rows_max_q(const mi355_attn_params& p) {
   const int G = p.num_q_heads / p.num_kv_heads;
-  if (G > 8) return 1;
   mi355_attn_params q = p;
   q.skip_decodes = 0;
+  if (p.decode_rows_hint > 1) {      // the caller knows its decode rows' length: whatever the packed kernels hold of it
+    q.only_decodes = p.decode_rows_hint;
+    if (decode_pack_groups(q) > 0 && p.decode_rows_hint <= (1 << decode_pack_shift(q))) return p.decode_rows_hint;
+  }
+  if (G > 8) return 1;
   q.only_decodes = 1 << pow2_floor_shift(16 / G);
   return (q.only_decodes > 1 && decode_pack_groups(q) == 1) ? q.only_decodes : 1;
 }

@@ -101,7 +101,7 @@ class AttnParams(C.Structure):
         ("slot_mapping", C.c_void_p),
         ("slot_mapping_i32", C.c_void_p),
         ("new_kv_all_rows", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("decode_rows_hint", C.c_int32),
     ]
 
 

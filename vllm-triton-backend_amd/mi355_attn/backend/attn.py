@@ -55,6 +55,9 @@ class MI355AttentionMetadata:
 
     scheduler_metadata: Optional[torch.Tensor] = None
     prefix_scheduler_metadata: Optional[torch.Tensor] = None
+    # (not in the reference) query tokens of a decode row when speculative decoding is on, 1 + num_speculative_tokens: lets a
+    # step that mixes prefills with verification rows send the latter to the decode launch (0: the library's own choice)
+    decode_rows_hint: int = 0
 
     @dataclass
     class LocalAttentionMetadata:
@@ -80,6 +83,9 @@ class MI355AttentionMetadataBuilder(AttentionMetadataBuilder[MI355AttentionMetad
         self.block_size = kv_cache_spec.block_size
         self.kv_cache_spec = kv_cache_spec
         self.block_table = block_table
+        # host-known and fixed for the engine's life (capture-stable)
+        spec = getattr(getattr(runner, "vllm_config", None), "speculative_config", None) or getattr(runner, "speculative_config", None)
+        self.decode_rows_hint = 1 + int(getattr(spec, "num_speculative_tokens", 0) or 0) if spec is not None else 0
 
     def build_for_cudagraph_capture(self, common_attn_metadata: CommonAttentionMetadata) -> MI355AttentionMetadata:
         attn_metadata = self.build(0, common_attn_metadata)
@@ -135,7 +141,7 @@ class MI355AttentionMetadataBuilder(AttentionMetadataBuilder[MI355AttentionMetad
             use_cascade=False, common_prefix_len=common_prefix_len,
             cu_prefix_query_lens=None, prefix_kv_lens=None, suffix_kv_lens=None,
             local_attn_metadata=self._local_window_metadata(n_seqs, pages), prefix_scheduler_metadata=None,
-            avg_query_len=mean_queries, avg_seq_len=mean_keys)
+            avg_query_len=mean_queries, avg_seq_len=mean_keys, decode_rows_hint=self.decode_rows_hint)
 
     def can_run_in_cudagraph(self, common_attn_metadata: CommonAttentionMetadata) -> bool:
         return True  # static launch grids, caller-owned workspace, no host sync
@@ -334,5 +340,5 @@ class MI355AttentionImpl(AttentionImpl):
         torch.ops.mi355_attn.unified_attention(
             q, key_cache, value_cache, out, cu_seqlens_q, int(max_seqlen_q), seqused_k, int(max_seqlen_k), float(self.scale),
             int(self.sliding_window[0]), int(self.sliding_window[1]), block_table, float(self.logits_soft_cap), layer._k_scale, layer._v_scale,
-            self._alibi_dev, self.kv_cache_dtype)
+            self._alibi_dev, self.kv_cache_dtype, int(getattr(attn_metadata, "decode_rows_hint", 0)))
         return output

@@ -35,6 +35,7 @@ def fill_attn_params(
     block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection,
     k_new=None, v_new=None, skip_decodes=False, only_decodes=False, num_segments=0,
     legacy_v0_layout=False, lse=None, write_new_kv=False, non_causal=False, slot_mapping=None, new_kv_all_rows=False,
+    decode_rows_hint=0,
 ):
     """Build the C struct. Returns (params, keepalive) — keepalive holds temporaries whose device
     memory the struct points to."""
@@ -110,6 +111,7 @@ def fill_attn_params(
     except KeyError:
         raise ValueError(f"force_selection must be None, 2, 3 or 9, got {force_selection}") from None
     p.num_segments = int(num_segments)
+    p.decode_rows_hint = int(decode_rows_hint or 0)
     p.write_new_kv = int(bool(write_new_kv))
     p.non_causal = int(bool(non_causal))
     p.new_kv_all_rows = int(bool(new_kv_all_rows))
@@ -161,6 +163,7 @@ def unified_attention(
     alibi_slopes=None,
     force_selection=None,  # None, 2, 3 to select kernel (9: generic correctness kernel)
     softmax_lse=None,      # extension: float32 [num_tokens, num_heads], receives log(sum(exp(scores))) per row
+    decode_rows_hint=0,    # extension: query tokens of this step's decode rows when the caller knows (1 + speculative drafts); 0 = library picks
 ):
     """Causal paged attention over vLLM block tables; writes `out` in place and returns None, as
     the reference does. `avg_seqlen_q/k` only fed the reference's autotuner keys
@@ -173,7 +176,7 @@ def unified_attention(
         raise RuntimeError("mi355_attn.unified_attention needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
     p, keep = fill_attn_params(
         q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_size,
-        block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection, lse=softmax_lse,
+        block_table, softcap, k_descale, v_descale, alibi_slopes, force_selection, lse=softmax_lse, decode_rows_hint=decode_rows_hint,
     )
     launch(p, q.device)
     del keep

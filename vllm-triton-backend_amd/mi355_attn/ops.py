@@ -23,7 +23,7 @@ _DEF = torch.library.Library("mi355_attn", "DEF")
 _DEF.define(
     "unified_attention(Tensor q, Tensor k, Tensor v, Tensor(a!) out, Tensor cu_seqlens_q, int max_seqlen_q, Tensor seqused_k, "
     "int max_seqlen_k, float softmax_scale, int window_left, int window_right, Tensor block_table, float softcap, "
-    "Tensor? k_descale, Tensor? v_descale, Tensor? alibi_slopes, str kv_cache_dtype) -> ()"
+    "Tensor? k_descale, Tensor? v_descale, Tensor? alibi_slopes, str kv_cache_dtype, int decode_rows_hint=0) -> ()"
 )
 _DEF.define(
     "reshape_and_cache_flash(Tensor key, Tensor value, Tensor(a!) key_cache, Tensor(b!) value_cache, Tensor slot_mapping, "
@@ -41,13 +41,13 @@ _FP8 = {"fp8": torch.float8_e4m3fn, "fp8_e4m3": torch.float8_e4m3fn, "fp8_e5m2":
 
 def _unified_attention_impl(q, k, v, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, window_left, window_right,
                             block_table, softcap, k_descale: Optional[torch.Tensor], v_descale: Optional[torch.Tensor],
-                            alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str) -> None:
+                            alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str, decode_rows_hint: int = 0) -> None:
     if kv_cache_dtype in _FP8 and k.dtype == torch.uint8:      # vLLM hands fp8 caches over as uint8
         k, v = k.view(_FP8[kv_cache_dtype]), v.view(_FP8[kv_cache_dtype])
     _unified_attention(q=q, k=k, v=v, out=out, cu_seqlens_q=cu_seqlens_q, max_seqlen_q=max_seqlen_q, seqused_k=seqused_k,
                        max_seqlen_k=max_seqlen_k, avg_seqlen_q=0, avg_seqlen_k=0, softmax_scale=softmax_scale, causal=True,
                        window_size=(window_left, window_right), block_table=block_table, softcap=softcap, q_descale=None,
-                       k_descale=k_descale, v_descale=v_descale, alibi_slopes=alibi_slopes)
+                       k_descale=k_descale, v_descale=v_descale, alibi_slopes=alibi_slopes, decode_rows_hint=decode_rows_hint)
 
 
 def _reshape_and_cache_flash_impl(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype: str,
