@@ -537,14 +537,20 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) park(k_lds, ld_row[i], ld_piece[i], (PAD && ld_pad[i]) ? u32x4_t{0, 0, 0, 0} : kcur[h][i]);
+      f32x4_t acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      // (all of a group's fragment reads are issued before its first matrix instruction: written as one read per
+      // k-step in front of its instruction, hipcc serialised read -> wait -> instruction in some builds of this kernel,
+      // eight exposed LDS latencies per tile and ~3 % of C3)
+      u32x4_t kf[KSTEPS];
 #pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) s[cg][h] = f32x4_t{0, 0, 0, 0};
+      for (int c = 0; c < KSTEPS; ++c) kf[c] = *(const u32x4_t*)(k_lds + g * RS + c * 64 + grp * 16);  // lane = key row g of the group
 #pragma unroll
       for (int c = 0; c < KSTEPS; ++c) {
-        const u32x4_t kf = *(const u32x4_t*)(k_lds + g * RS + c * 64 + grp * 16);  // lane = key row g of the group
-#pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) s[cg][h] = mma<T>::run(__builtin_bit_cast(s16x8_t, kf), qf[cg][c], s[cg][h]);
+        acc = mma<T>::run(__builtin_bit_cast(s16x8_t, kf[c]), qf[0][c], acc);
+        if constexpr (NCG > 1) acc1 = mma<T>::run(__builtin_bit_cast(s16x8_t, kf[c]), qf[NCG - 1][c], acc1);
       }
+      s[0][h] = acc;
+      if constexpr (NCG > 1) s[NCG - 1][h] = acc1;
     }
 
     // ---- scores -> log2 domain, masks (reference order: scale, softcap, causal, window, +alibi) ---
