@@ -139,6 +139,43 @@ def test_workspace_bytes_of_a_multi_token_decode_step(lib):
     assert h.mi355_attn_workspace_bytes(C.byref(p)) in (0, counters)
 
 
+def test_a_non_causal_call_never_takes_the_packed_decode_kernel(lib):
+    """The decode kernels mask causally. A non-causal varlen call with sequences of 2..16/G tokens (prefill_flash_attention
+    (causal=False)) must not be sized - nor dispatched, same `choose()` - as a packed multi-token decode step: only
+    one-token rows are the same under both masks. (non_causal = 1 with q_len 2 / 4 / 8 returned exactly the
+    causal packed-decode workspace sizes.)"""
+    h = lib.load()
+    buf = np.zeros(64, dtype=np.uint8)
+    addr = (buf.ctypes.data + 15) & ~15
+    p = _c3_like_params(lib, addr)
+    p.max_seqlen_k = 8192
+    for q_len in (2, 4, 8):
+        p.num_tokens, p.num_seqs, p.max_seqlen_q = 64 * q_len, 64, q_len
+        p.non_causal = 0
+        causal = h.mi355_attn_workspace_bytes(C.byref(p))
+        assert causal > (256 << 10)                              # the packed decode step's partials
+        p.non_causal = 1
+        assert h.mi355_attn_workspace_bytes(C.byref(p)) != causal, q_len
+    # mixed-length batch (not uniform): the decode launch of a non-causal call takes one-token rows only
+    p.num_tokens, p.num_seqs, p.max_seqlen_q, p.non_causal = 64 * 2 + 4096, 65, 4096, 1
+    n_nc = h.mi355_attn_workspace_bytes(C.byref(p))
+    p.non_causal = 0
+    assert n_nc <= h.mi355_attn_workspace_bytes(C.byref(p))
+
+
+def test_one_version_number(lib):
+    """include/mi355_attn.h is the version source: the library, the Python package and setup.py report it."""
+    import mi355_attn
+
+    n = int(re.search(r"#define MI355_ATTN_VERSION (\d+)", open(HEADER).read()).group(1))
+    want = f"{n // 10000}.{n // 100 % 100}.{n % 100}"
+    assert lib.load().mi355_attn_version() == n
+    assert mi355_attn.__version__ == want
+    got = subprocess.check_output([sys.executable, "setup.py", "--version"], cwd=os.path.join(ROOT, "vllm-triton-backend_amd"), text=True,
+                                  stderr=subprocess.DEVNULL).strip().splitlines()[-1]
+    assert got == want
+
+
 def _c3_like_params(lib, addr):
     p = lib.AttnParams()
     for f in ("q", "out", "k_cache", "v_cache", "block_table", "cu_seqlens_q", "seqused_k"):

@@ -147,3 +147,41 @@ def test_self_attention_prefill_reads_the_linear_tensors_in_one_library_call(dty
     assert _lib.last_kernel().startswith("repack+prefill_mfma_pw" if not causal else "repack+prefill_"), _lib.last_kernel()
     tol = 2e-2 if dtype == torch.bfloat16 else 2e-3
     torch.testing.assert_close(out.double().cpu(), ref, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("lens", [[2] * 6, [3] * 5, [4] * 7, [2, 3, 4, 1, 4, 2], [2, 300, 4, 3, 129, 1, 2, 700], [4, 4, 4, 2048]])
+def test_non_causal_sequences_of_a_few_tokens_see_all_their_keys(dtype, lens):
+    """Non-causal varlen attention whose sequences carry 2..4 tokens - uniform, ragged, and mixed with long ones - is
+    what a packed multi-token DECODE step looks like to the dispatch (a few query tokens per sequence), and the decode
+    kernels mask causally: such a call must never reach them (only one-token rows are the same under both
+    masks). Against a dense float64 softmax over every key of the sequence."""
+    from mi355_attn import _lib
+    from mi355_attn.kernels import prefill_flash_attention
+
+    hq, hk, d = 32, 8, 128             # G = 4: one packed column group holds 4 tokens, two hold 8
+    g = torch.Generator().manual_seed(97 + len(lens))
+    cu = [0] + torch.tensor(lens).cumsum(0).tolist()
+    q = (torch.rand(cu[-1], hq, d, generator=g) * 2 - 1).to(dtype)
+    k = (torch.rand(cu[-1], hk, d, generator=g) * 2 - 1).to(dtype)
+    v = (torch.rand(cu[-1], hk, d, generator=g) * 2 - 1).to(dtype)
+    scale = 1.0 / math.sqrt(d)
+    ref = torch.zeros(q.shape, dtype=torch.float64)
+    for i in range(len(lens)):
+        a, b = cu[i], cu[i + 1]
+        for h in range(hq):
+            s = scale * (q[a:b, h].double() @ k[a:b, h // (hq // hk)].double().T)
+            ref[a:b, h] = torch.softmax(s, dim=-1) @ v[a:b, h // (hq // hk)].double()
+    dev = torch.device("cuda:0")
+    cud = torch.tensor(cu, dtype=torch.int32, device=dev)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-3
+    # self-attention (one library call over the linear tensors) and the two-range form (scratch pages + unified_attention's launch)
+    out = prefill_flash_attention(q.to(dev), k.to(dev), v.to(dev), max(lens), max(lens), cud, cud, causal=False, sm_scale=scale)
+    torch.cuda.synchronize()
+    assert "decode" not in _lib.last_kernel() or max(lens) > 4, _lib.last_kernel()
+    assert "pack" not in _lib.last_kernel(), _lib.last_kernel()
+    torch.testing.assert_close(out.double().cpu(), ref, atol=tol, rtol=tol)
+    out2 = prefill_flash_attention(q.to(dev), k.to(dev), v.to(dev), max(lens), max(lens), cud, cud.clone(), causal=False, sm_scale=scale)
+    torch.cuda.synchronize()
+    assert "pack" not in _lib.last_kernel(), _lib.last_kernel()
+    torch.testing.assert_close(out2.double().cpu(), ref, atol=tol, rtol=tol)

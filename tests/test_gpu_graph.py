@@ -186,11 +186,12 @@ def test_decode_graph_captured_at_max_model_len_replays_any_length():
             assert t_replay <= 1.5 * t_eager + 0.01, (t_replay, t_eager)
 
 
-def test_capture_with_the_plain_torch_idiom_after_a_warm_up_on_another_stream():
+def test_capture_with_the_plain_torch_idiom_gets_a_workspace_of_its_own():
     """`torch.cuda.graph(g)` without `stream=` captures on torch's private capture stream, on which no eager call ever
     ran (what `triton.testing.do_bench_cudagraph` - the reference harness's CUDA_GRAPHS mode, scripts/benchmark.py
-    :1733-1738 - and vLLM's full-graph capture do). The binding keys workspaces by stream; a capture borrows the
-    device's largest workspace instead of raising, and raises only when none is big enough."""
+    :1733-1738 - and vLLM's full-graph capture do). The binding gives every capture a workspace of its own, allocated
+    inside the capture (no eager warm-up needed), so a replay on one stream and eager calls on another never count
+    arrivals or park partials in the same bytes."""
     import gpu_util
     from mi355_attn import _lib
     from mi355_attn.kernels import unified_attention
@@ -201,36 +202,43 @@ def test_capture_with_the_plain_torch_idiom_after_a_warm_up_on_another_stream():
     inp = orc.make_paged_inputs(45, query_lens, kv_lens, Hq, Hk, D, page, torch.bfloat16)
     d = gpu_util.to_dev(inp)
     out = torch.zeros_like(d["q"])
+    q_eager, out_eager = d["q"].clone(), torch.zeros_like(d["q"])
 
-    def step():
-        unified_attention(q=d["q"], k=d["k_cache"], v=d["v_cache"], out=out, cu_seqlens_q=d["cu_seqlens_q"], max_seqlen_q=1,
-                          seqused_k=d["seqused_k"], max_seqlen_k=max(kv_lens), avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=inp["scale"],
-                          causal=True, window_size=(-1, -1), block_table=d["block_table"], softcap=0, q_descale=None, k_descale=None,
-                          v_descale=None)
+    def step(q=None, o=None):
+        unified_attention(q=d["q"] if q is None else q, k=d["k_cache"], v=d["v_cache"], out=out if o is None else o, cu_seqlens_q=d["cu_seqlens_q"],
+                          max_seqlen_q=1, seqused_k=d["seqused_k"], max_seqlen_k=max(kv_lens), avg_seqlen_q=1, avg_seqlen_k=1,
+                          softmax_scale=inp["scale"], causal=True, window_size=(-1, -1), block_table=d["block_table"], softcap=0,
+                          q_descale=None, k_descale=None, v_descale=None)
 
     _lib._workspaces.clear()
     graph = torch.cuda.CUDAGraph()
-    with pytest.raises(RuntimeError, match="before graph capture"):      # nothing to borrow yet: the error names the remedy
-        with torch.cuda.graph(graph):
-            step()
-    torch.cuda.synchronize()
-    step()                                        # eager warm-up on the CURRENT (default) stream
-    torch.cuda.synchronize()
-    n_before = len(_lib._workspaces)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):                 # torch's own capture stream
+    with torch.cuda.graph(graph):                 # torch's own capture stream, nothing warmed up
         step()
-    assert len(_lib._workspaces) == n_before      # borrowed, nothing allocated inside the capture
+    cap_keys = [k for k in _lib._workspaces if k[2] == "capture"]
+    assert len(cap_keys) == 1 and cap_keys[0][3] != 0, cap_keys       # keyed by the capture's id
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):                # a second capture on the same private stream: bytes of its own
+        step()
+    assert len([k for k in _lib._workspaces if k[2] == "capture"]) == 2
+    ptrs = {ws.data_ptr() for k, ws in _lib._workspaces.items()}
+    side = torch.cuda.Stream()
     for seed in (1, 2):
         g = torch.Generator().manual_seed(seed)
         q2 = (torch.rand(5, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
         d["q"].copy_(q2.to(dev))
+        q_eager.copy_(q2.to(dev))
         out.fill_(float("nan"))
-        graph.replay()
-        step()                                    # an eager call on the replay stream, sharing the borrowed buffer, in order behind it
+        out_eager.fill_(float("nan"))
+        torch.cuda.synchronize()
+        for _ in range(20):                       # replays on the current stream, eager calls on another, free to overlap
+            graph.replay()
+            with torch.cuda.stream(side):
+                step(q_eager, out_eager)
         torch.cuda.synchronize()
         ref = orc.unified_attention_oracle(q2, inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"])
         torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+        torch.testing.assert_close(out_eager.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+    assert len({ws.data_ptr() for ws in _lib._workspaces.values()}) == len(ptrs) + 1     # (the side stream's eager workspace)
 
 
 def test_multi_token_decode_graph_replays_other_lengths_and_draft_counts():

@@ -939,10 +939,13 @@ static int pack_max_q(const mi355_attn_params& p) { return p.only_decodes > 1 ? 
 #if DECODE_TU == 0
 int decode_pack_groups(const mi355_attn_params& p) {
   if (pack_max_q(p) <= 1 || p.num_tokens <= p.num_seqs || p.only_decodes == 1 || p.skip_decodes || p.write_new_kv) return 0;
+  // the decode kernels mask causally (n_keys of a column = ctx + q_pos + 1): only one-token rows are the same under both
+  // masks, so a non-causal call never packs several tokens of a sequence
+  if (p.non_causal) return 0;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;   // (one column group only)
   if (!layout_is_flash(p) || p.head_size != padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype))) return 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  const char* e = getenv("MI355_DECODE_PACK");
+  static const char* const e = getenv("MI355_DECODE_PACK");     // read once per process, like the other switches
   if (e && e[0] == '0') return 0;
   const bool one_ok = G <= 8, two_ok = G <= 16 && p.head_size <= 128 && !feat && !(e && e[0] == '1');
   if (one_ok && (pack_max_q(p) <= (1 << pow2_floor_shift(16 / G)) || !two_ok)) return 1;
@@ -964,6 +967,7 @@ static int pack_chunks_per_seq(const mi355_attn_params& p, int ps) { return (pac
 #if DECODE_TU == 0
 int decode_rows_max_q(const mi355_attn_params& p) {
   const int G = p.num_q_heads / p.num_kv_heads;
+  if (p.non_causal) return 1;       // (see decode_pack_groups)
   mi355_attn_params q = p;
   q.skip_decodes = 0;
   if (p.decode_rows_hint > 1) {      // the caller knows its decode rows' length: whatever the packed kernels hold of it

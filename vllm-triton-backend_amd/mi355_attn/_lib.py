@@ -226,37 +226,64 @@ def current_stream_handle(device: torch.device) -> int:
 # A buffer that has been handed out is NEVER freed: a HIP graph captured earlier holds its raw address (arrival
 # counters, split partials) and replays into it long after a later, larger call made the binding move on to a bigger
 # buffer. Growth is geometric, so the retired buffers together stay below the size of the live one.
-# While a stream is CAPTURING nothing is allocated. `torch.cuda.graph(g)` without `stream=` captures on a private
-# stream no eager call ever ran on (torch's default capture stream; `triton.testing.do_bench_cudagraph` and vLLM's
-# full-graph capture do exactly that), so the capture borrows the device's largest workspace: capture serialises with
-# the warm-up that allocated it, and a replay runs on whatever stream the caller replays on - stream-ordered with the
-# eager calls of that stream, which is the only stream the borrowed buffer can meet it on.
+# A CAPTURING stream gets a workspace of its own per capture (keyed by the capture's id, hipStreamGetCaptureInfo): it is
+# allocated inside the capture - from the graph's private pool, like any tensor the captured model code allocates -
+# and kept alive for the life of the process. `torch.cuda.graph(g)` without `stream=` captures on a private stream no
+# eager call ever ran on (torch's default capture stream; `triton.testing.do_bench_cudagraph` and vLLM's full-graph
+# capture do exactly that), and the graph is later replayed on whatever stream the caller picks: with bytes of its own
+# a replay can run beside eager calls and beside other graphs' replays on any stream without two calls counting
+# arrivals or parking partials in the same place. (Rounds 2-3 lent the capture the device's largest eager workspace,
+# which is only safe while the replay stream is the lender's stream.) The counters at the head are zero-filled by a
+# memset node of the graph (256 KiB, once per graph, harmless on replay: every call leaves them at zero anyway).
 _workspaces: dict = {}
 _retired: list = []
+_COUNTER_BYTES = 256 << 10
+_hip = None
 
 
-def _largest_on_device(device: torch.device):
-    best = None
-    for (dtype_, index_, _stream), ws in _workspaces.items():
-        if dtype_ == device.type and index_ == device.index and (best is None or ws.numel() > best.numel()):
-            best = ws
-    return best
+def _capture_id(stream_handle: int) -> int:
+    """Id of the capture the stream is in (unique per hipStreamBeginCapture), 0 when it cannot be told."""
+    global _hip
+    try:
+        if _hip is None:
+            _hip = C.CDLL("libamdhip64.so")
+            _hip.hipStreamGetCaptureInfo.restype = C.c_int
+            _hip.hipStreamGetCaptureInfo.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        status, cid = C.c_int(0), C.c_ulonglong(0)
+        if _hip.hipStreamGetCaptureInfo(C.c_void_p(stream_handle), C.byref(status), C.byref(cid)) != 0:
+            return 0
+        return int(cid.value)
+    except (OSError, AttributeError):
+        return 0
+
+
+def _capture_workspace(device: torch.device, nbytes: int, stream_handle: int) -> torch.Tensor:
+    key = (device.type, device.index, "capture", _capture_id(stream_handle))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _retired.append(ws)         # earlier nodes of this capture hold its address
+        try:
+            ws = torch.empty(max(nbytes, 1 << 20, 2 * (ws.numel() if ws is not None else 0)), dtype=torch.uint8, device=device)
+            ws[:_COUNTER_BYTES].zero_()
+        except RuntimeError as e:       # a capture torch's allocator does not know of (raw hipStreamBeginCapture)
+            raise RuntimeError(
+                f"mi355_attn workspace ({nbytes} bytes) cannot be allocated inside this stream capture ({e}); capture with "
+                "torch.cuda.graph, or pass a workspace of your own through the C ABI"
+            ) from None
+        _workspaces[key] = ws
+    return ws
 
 
 def workspace(device: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     if nbytes == 0:
         return None
-    key = (device.type, device.index, current_stream_handle(device))
+    stream = current_stream_handle(device)
+    if torch.cuda.is_current_stream_capturing():
+        return _capture_workspace(device, nbytes, stream)
+    key = (device.type, device.index, stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        if torch.cuda.is_current_stream_capturing():
-            best = _largest_on_device(device)
-            if best is not None and best.numel() >= nbytes:
-                return best
-            raise RuntimeError(
-                f"mi355_attn workspace ({nbytes} bytes) must be allocated before graph capture: run one eager call of "
-                "the largest shape on this device first (any stream)"
-            )
         if ws is not None:
             _retired.append(ws)
         # zero-filled once: the head of the workspace holds the split-merge arrival counters, which

@@ -32,14 +32,16 @@ _dummy_cache: dict = {}
 
 
 def _scratch_cache(dev, num_pages, hk, d, dtype):
-    """The paged scratch K/V of a call whose key ranges differ from its query ranges, kept per (device, heads, head
-    size, dtype) and grown geometrically. Stream-ordered reuse on one stream: the next call's cache write is enqueued
-    behind this call's attention. A capturing stream never allocates: it borrows the buffer an eager call sized."""
-    key = (dev.type, dev.index, hk, d, dtype)
+    """The paged scratch K/V of a call whose key ranges differ from its query ranges, kept per (device, STREAM, heads,
+    head size, dtype) and grown geometrically. Stream-ordered reuse on one stream: the next call's cache write is
+    enqueued behind this call's attention; calls on two streams never share a buffer (one stream's cache write could
+    otherwise overwrite pages the other stream's attention is still reading). A capturing stream never allocates
+    here: an eager call on the same stream sizes the buffer first."""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream, hk, d, dtype)
     buf = _scratch.get(key)
     if buf is None or buf.shape[1] < num_pages:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("prefill_flash_attention: run one eager call of the largest shape before graph capture")
+            raise RuntimeError("prefill_flash_attention: run one eager call of the largest shape on this stream before graph capture")
         if buf is not None:
             _retired.append(buf)
         grow = max(num_pages, 2 * (buf.shape[1] if buf is not None else 0))
