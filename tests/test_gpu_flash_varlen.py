@@ -178,10 +178,10 @@ def test_non_causal_sequences_of_a_few_tokens_see_all_their_keys(dtype, lens):
     # self-attention (one library call over the linear tensors) and the two-range form (scratch pages + unified_attention's launch)
     out = prefill_flash_attention(q.to(dev), k.to(dev), v.to(dev), max(lens), max(lens), cud, cud, causal=False, sm_scale=scale)
     torch.cuda.synchronize()
-    assert "decode" not in _lib.last_kernel() or max(lens) > 4, _lib.last_kernel()
-    assert "pack" not in _lib.last_kernel(), _lib.last_kernel()
+    # (one-token rows may ride a decode launch: they are the same under both masks; no PACKED multi-token launch may appear)
+    assert "_pack" not in _lib.last_kernel(), _lib.last_kernel()
     torch.testing.assert_close(out.double().cpu(), ref, atol=tol, rtol=tol)
     out2 = prefill_flash_attention(q.to(dev), k.to(dev), v.to(dev), max(lens), max(lens), cud, cud.clone(), causal=False, sm_scale=scale)
     torch.cuda.synchronize()
-    assert "pack" not in _lib.last_kernel(), _lib.last_kernel()
+    assert "_pack" not in _lib.last_kernel(), _lib.last_kernel()
     torch.testing.assert_close(out2.double().cpu(), ref, atol=tol, rtol=tol)

@@ -67,6 +67,9 @@ struct DecodeArgs {
   int* ws_cnt;     // [units*Hk] arrival counters of the in-kernel merge; zero on entry, zero on exit
   uint32_t ws_slot_bytes_total;
   int fused_merge; // 1: the last-arriving split of a (unit, KV head) merges in the kernel, no second launch
+  int tree;        // 1: two-level merge (round 4). The four waves of a workgroup are four CONSECUTIVE splits of one (unit, KV head,
+                   // query-head group): they fold their partials through LDS, the workgroup writes ONE partial (slot rows of
+                   // num_splits / 4), and the last workgroup to arrive folds those with all four waves - any split count in one launch
   int num_splits;
   int tiles_per_split;
   int group;       // G = Hq / Hk
@@ -213,13 +216,17 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 
   // ---- which (unit, split, kv head) this wave owns (all wave-uniform) ----------------------------
   const int Hk = p.num_kv_heads;
-  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave_in_wg);
+  const bool tree = PACK == 0 && a.tree;
+  static_assert(WAVES == 4, "the two-level merge folds the four waves of a workgroup");
+  // (tree: the workgroup is (unit, group of four splits, KV head, query-head group) and its waves are the group's splits)
+  const int item = __builtin_amdgcn_readfirstlane(tree ? (int)blockIdx.x : (int)(blockIdx.x * WAVES + wave_in_wg));
   // (the waves of one KV head's query-head groups are neighbours: they stream the same K/V pages through one L2)
   const int hitem = item % (Hk * a.qgroups);
   const int head = hitem / a.qgroups, qg = hitem % a.qgroups;
   const int rest = item / (Hk * a.qgroups);
-  const int split = rest % a.num_splits;
-  const int unit = rest / a.num_splits;
+  const int nsp = tree ? a.num_splits >> 2 : a.num_splits;
+  const int split = tree ? (rest % nsp) * 4 + wave_in_wg : rest % nsp;
+  const int unit = rest / nsp;
   const int hq0 = head * a.group + 16 * qg;   // first query head of this wave
   const int G = min(16, a.group - 16 * qg);   // query heads of this wave
   const int g = lane & 15, grp = lane >> 4;
@@ -329,7 +336,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   const int t0 = tile_lo + split * tps;
   const int t1 = min(t0 + tps, tile_hi);
   const bool direct = a.num_splits == 1;
-  if (t0 >= t1) {
+  const int n_tiles = max(0, tile_hi - tile_lo);
+  const int active = min(a.num_splits, (n_tiles + tps - 1) / tps);       // splits of this row that hold a tile
+  const bool empty = t0 >= t1;
+  // (tree: an empty split whose workgroup holds a partial stays for the workgroup's barriers and its share of the merge)
+  if (empty && (!tree || (split & ~3) >= active)) {
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg)
     if (split == 0 && g_ok[cg]) {  // no visible key at all (no split has a tile): the reference returns acc/L = 0/1 = 0
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
     // near max_seqlen_k); a second group past the sequence re-reads the first
     pg[0] = pg_first[0];
     pg[1] = (t0 * 2 + 1 > last_group) ? pg_first[0] : pg_first[1];
-  } else {
+  } else if (!empty) {
     lookup_pages(t0);
   }
 #pragma unroll
@@ -654,6 +665,133 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   float l_tot[NCG];
 #pragma unroll
   for (int cg = 0; cg < NCG; ++cg) l_tot[cg] = sum_over_lane_groups(l_run[cg]);
+  if constexpr (PACK == 0) {
+  if (tree) {
+    // ---- two-level merge (reference: reduce_segments, :757-836) -----------------------------------------------------
+    // Level 1, inside the workgroup: every wave parks its partial in its own (now idle) LDS region, lane by lane - the
+    // four waves share one lane layout (column g, rows 16b + 4grp ..) - and wave w folds the 16-column blocks b = w, w + 4, ..
+    // of all of them. One partial per workgroup then leaves for the workspace (or, with four splits in all, the output).
+    constexpr int NB = DBLK / 4;
+    constexpr int SLOT = D + kSlotPad;
+    const int SH = a.num_splits >> 2, split_hi = split >> 2;
+    const int nw = min(4, active - 4 * split_hi);                    // waves of this workgroup that hold a partial
+    float* const mine = (float*)(smem + wave_in_wg * LDS_PER_WAVE);
+    if (!empty) {
+#pragma unroll
+      for (int b = 0; b < DBLK; ++b) *(f32x4_t*)(mine + (b * 64 + lane) * 4) = o_acc[0][b];
+      if (grp == 0) *(f32x2_t*)(mine + DBLK * 256 + 2 * g) = f32x2_t{l_tot[0] > 0.0f ? m_run[0] : -INFINITY, l_tot[0]};
+    }
+    __syncthreads();
+    float m_all = -INFINITY, l_all = 0.0f, wgt[4];
+    f32x2_t ml[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ml[i] = i < nw ? *(const f32x2_t*)((const float*)(smem + i * LDS_PER_WAVE) + DBLK * 256 + 2 * g) : f32x2_t{-INFINITY, 0.0f};
+      m_all = fmaxf(m_all, ml[i][0]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wgt[i] = ml[i][0] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(ml[i][0] - m_all);
+      l_all += ml[i][1] * wgt[i];
+    }
+    f32x4_t om[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      om[j] = f32x4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nw) om[j] += *(const f32x4_t*)((const float*)(smem + i * LDS_PER_WAVE) + ((wave_in_wg + 4 * j) * 64 + lane) * 4) * wgt[i];
+    }
+    auto store_out = [&](int tok, int hqx, float m_fin, float l_fin, const f32x4_t (&ov)[NB]) {
+      if (p.lse && grp == 0 && wave_in_wg == 0)
+        p.lse[(int64_t)tok * p.lse_stride_token + hqx] = l_fin > 0.0f ? (m_fin + __builtin_amdgcn_logf(l_fin)) * kLn2 : -INFINITY;
+      const float inv = l_fin > 0.0f ? v_scale / l_fin : 0.0f;              // "0 if the overall sum is 0" (:828)
+      const int64_t o = (int64_t)tok * p.out_stride_token + (int64_t)hqx * p.out_stride_head;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int b = wave_in_wg + 4 * j;
+        if (!PAD || 16 * b + 4 * grp < a.d_valid) *(u32x2_t*)((uint16_t*)p.out + o + 16 * b + 4 * grp) =
+            u32x2_t{mma<T>::pack2(ov[j][0] * inv, ov[j][1] * inv), mma<T>::pack2(ov[j][2] * inv, ov[j][3] * inv)};
+      }
+    };
+    if (SH == 1) {                       // four splits in all: the workgroup's fold is the result
+      if (g_ok[0]) store_out(token[0], hq[0], m_all, l_all, om);
+      return;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.ws_slots, 0, (int)a.ws_slot_bytes_total, 0x00020000);
+    const uint32_t slot_g0 = (uint32_t)(((uint32_t)unit * p.num_q_heads + hq0) * SH);     // slot of (g = 0, split group 0)
+    if (g_ok[0]) {
+      const uint32_t so = ((slot_g0 + (uint32_t)(g * SH + split_hi)) * SLOT) * 4u;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, om[j]), rsrc, so + (16 * (wave_in_wg + 4 * j) + 4 * grp) * 4, 0, 16);
+      if (grp == 0 && wave_in_wg == 0)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(uint32_t, m_all), __builtin_bit_cast(uint32_t, l_all)}, rsrc, so + D * 4, 0, 16);
+    }
+    // Level 2: the last workgroup of this (unit, KV head, query-head group) to arrive folds the workgroups' partials, again
+    // wave w the blocks b = w, w + 4, ..: every wave drains its stores, the workgroup meets, ONE ticket is drawn.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                 // (also: every wave is done reading the parked partials)
+    int* cnt = a.ws_cnt + ((unit * Hk + head) * a.qgroups + qg);
+    int* const tk = (int*)smem;
+    if (wave_in_wg == 0 && lane == 0) *tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(*tk);
+    const int active_hi = (active + 3) >> 2;
+    if (ticket != active_hi - 1) return;
+    // every load below is an sc1 load (bypasses this CU's L1, which may hold lines of an earlier launch); lanes g >= G,
+    // idle in the compute layout, take further partials: lane (gm, sub, grp) walks partials sub, sub + NS, .. of head gm
+    // with ALL of its loads in flight at once (one round trip up to NS * U2 partials = 128 splits at G <= 4)
+    const int Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));
+    const int NS = 16 / Gp, gm = g & (Gp - 1), sub = g / Gp;
+    const bool gm_ok = gm < G;
+    float m_acc = -INFINITY, l_acc = 0.0f;
+    f32x4_t acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = f32x4_t{0, 0, 0, 0};
+    auto fold = [&](float m_in, float l_in, const f32x4_t (&v_in)[NB]) {
+      const float m_new = fmaxf(m_acc, m_in);
+      const float wa = m_acc == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m_acc - m_new);
+      const float wb = m_in == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m_in - m_new);
+      l_acc = l_acc * wa + l_in * wb;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = acc[j] * wa + v_in[j] * wb;
+      m_acc = m_new;
+    };
+    if (gm_ok) {
+      constexpr int U2 = D >= 256 ? 4 : 8;
+      const uint32_t s0 = ((slot_g0 + (uint32_t)(gm * SH)) * SLOT) * 4u;
+      for (int base = sub; base < active_hi; base += NS * U2) {
+        float m_in[U2], l_in[U2];
+        f32x4_t v_in[U2][NB];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+          const int sidx = base + u * NS;
+          const uint32_t so = sidx < active_hi ? s0 + (uint32_t)sidx * (SLOT * 4u) : 0x80000000u;
+          m_in[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, so + D * 4, 0, 16));
+          l_in[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, so + D * 4 + 4, 0, 16));
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            v_in[u][j] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, so + (16 * (wave_in_wg + 4 * j) + 4 * grp) * 4, 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) fold(base + u * NS < active_hi ? m_in[u] : -INFINITY, l_in[u], v_in[u]);
+      }
+    }
+    for (int off = Gp; off < 16; off <<= 1) {
+      const float m_in = __shfl_xor(m_acc, off), l_in = __shfl_xor(l_acc, off);
+      f32x4_t v_in[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v_in[j][r] = __shfl_xor(acc[j][r], off);
+      fold(m_in, l_in, v_in);
+    }
+    if (gm_ok && sub == 0) store_out(ri.token, hq0 + gm, m_acc, l_acc, acc);
+    if (wave_in_wg == 0 && lane == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero for the next call
+    return;
+  }
+  }
   if (direct) {
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
@@ -695,8 +833,6 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
 
   // ---- in-kernel merge by the last-arriving split of this (unit, KV head) (reference: reduce_segments, :757-836)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains before it signals
-  const int n_tiles = max(0, tile_hi - tile_lo);
-  const int active = min(a.num_splits, (n_tiles + tps - 1) / tps);
   int* cnt = a.ws_cnt + ((unit * Hk + head) * a.qgroups + qg);
   int ticket = 0;
   if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1037,12 +1173,45 @@ static bool counters_fit(const mi355_attn_params& p) {
   return (size_t)decode_units(p) * p.num_kv_heads * query_head_groups(p) * sizeof(int) <= kCounterRegionBytes;
 }
 
+// How a launch merges its splits (host arithmetic on host-known sizes, shared by the workspace query and the launch):
+//   flat  - the last-arriving split reads every partial of its (unit, KV head) in ONE round trip (<= one_trip splits);
+//   tree  - more splits than that on the plain (not packed) kernels: split count rounded up to a multiple of four, the four
+//           waves of a workgroup fold their partials through LDS, slot rows of num_splits / 4, the last workgroup folds those;
+//   launch - reduce_splits_kernel: packed multi-token steps with many splits, more (unit, KV head) pairs than counters,
+//           MI355_DECODE_MERGE_KERNEL=1 (A/B).
+struct MergePlan { int num_splits, tiles_per_split, slot_rows; bool flat, tree; };
+static MergePlan plan_merge(const mi355_attn_params& p) {
+  const SplitPlan sp = plan_splits(p);
+  MergePlan m = {sp.num_splits, sp.tiles_per_split, sp.num_splits, false, false};
+  if (sp.num_splits <= 1) return m;
+  static const bool two_launch = getenv("MI355_DECODE_MERGE_KERNEL") != nullptr;   // A/B switch: separate merge launch
+  static const bool no_tree = getenv("MI355_DECODE_TREE") != nullptr && getenv("MI355_DECODE_TREE")[0] == '0';
+  if (two_launch || !counters_fit(p)) return m;
+  const int pack = decode_pack_groups(p), ps = decode_pack_shift(p);
+  const int D = padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype));
+  // in-kernel flat merge only where the last arriver reads its partials in ONE round trip (NS lanes x U
+  // loads in flight, see the kernel's epilogue)
+  const int G = std::min(p.num_q_heads / p.num_kv_heads, 16) << ps, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // columns in use
+  // (one column group of packed tokens: two trips at worst - a unit with every column in use - against a merge launch
+  // over all token slots; units with fewer tokens walk their splits on more lanes, see the kernel)
+  const int one_trip = (pack == 2 ? 1 : pack == 1 ? 2 : 16 / Gp) * (D >= 128 ? 2 : 4);
+  if (sp.num_splits <= one_trip) { m.flat = true; return m; }
+  if (pack == 0 && !no_tree) {
+    const int max_tiles = (p.max_seqlen_k + kTileKeys - 1) / kTileKeys;
+    m.num_splits = std::min((sp.num_splits + 3) & ~3, kMaxSplits);
+    m.tiles_per_split = (max_tiles + m.num_splits - 1) / m.num_splits;
+    m.slot_rows = m.num_splits / 4;
+    m.tree = true;
+  }
+  return m;
+}
+
 #if DECODE_TU == 0
 size_t decode_workspace_bytes(const mi355_attn_params& p) {
   if (!decode_supported(p)) return 0;
-  const int splits = plan_splits(p).num_splits;
-  if (splits == 1) return 0;
-  const size_t slots = (size_t)partial_rows(p) * p.num_q_heads * splits;
+  const MergePlan mp = plan_merge(p);
+  if (mp.num_splits == 1) return 0;
+  const size_t slots = (size_t)partial_rows(p) * p.num_q_heads * mp.slot_rows;
   return counters_bytes(p) + slots * (padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype)) + kSlotPad) * sizeof(float);
 }
 #endif
@@ -1053,9 +1222,10 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   constexpr bool FP8 = !__is_same(T, KVT);
   DecodeArgs a;
   a.p = p;
-  const SplitPlan sp = plan_splits(p);
+  const MergePlan sp = plan_merge(p);
   a.num_splits = sp.num_splits;
   a.tiles_per_split = sp.tiles_per_split;
+  a.tree = (PACK == 0 && sp.tree) ? 1 : 0;
   a.group = p.num_q_heads / p.num_kv_heads;
   a.qgroups = query_head_groups(p);
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
@@ -1073,7 +1243,7 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
   a.ws_slot_bytes_total = 0;
   a.fused_merge = 0;
   if (sp.num_splits > 1) {
-    const size_t slots = (size_t)partial_rows(p) * p.num_q_heads * sp.num_splits;
+    const size_t slots = (size_t)partial_rows(p) * p.num_q_heads * sp.slot_rows;
     const size_t slot_bytes = slots * (D + kSlotPad) * sizeof(float);
     const size_t need = counters_bytes(p) + slot_bytes;
     if (!ws || ws_bytes < need) {
@@ -1087,26 +1257,18 @@ static int launch_decode_t(const mi355_attn_params& p, void* ws, size_t ws_bytes
     a.ws_cnt = (int*)ws;
     a.ws_slots = (float*)((char*)ws + counters_bytes(p));
     a.ws_slot_bytes_total = (uint32_t)slot_bytes;
-    static const bool two_launch = getenv("MI355_DECODE_MERGE_KERNEL") != nullptr;   // A/B switch: separate merge launch
-    // in-kernel merge only where the last arriver reads its partials in ONE round trip (NS lanes x U
-    // loads in flight, see the kernel's epilogue); more splits than that merge faster in a launch of
-    // their own, which is one round trip at any split count
-    const int G = std::min(a.group, 16) << a.pack_shift, Gp = G <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(G - 1)));   // columns in use
-    // (one column group of packed tokens: two trips at worst - a unit with every column in use - against a merge launch
-    // over all token slots; units with fewer tokens walk their splits on more lanes, see the kernel)
-    const int one_trip = (PACK == 2 ? 1 : PACK == 1 ? 2 : 16 / Gp) * (D >= 128 ? 2 : 4);
-    a.fused_merge = (two_launch || !counters_fit(p) || sp.num_splits > one_trip) ? 0 : 1;
+    a.fused_merge = sp.flat ? 1 : 0;
   }
   const long units = decode_units(p);
   if (units == 0) return MI355_OK;
   const long items = units * sp.num_splits * p.num_kv_heads * a.qgroups;
-  const int grid = (int)((items + WAVES - 1) / WAVES);
+  const int grid = (int)((items + WAVES - 1) / WAVES);      // (tree: num_splits is a multiple of four - one workgroup per group of four)
   if (PACK && (a.group << a.pack_shift) > 16 * PACK) { set_error("decode: packed columns exceed the wave's"); return MI355_ERR_UNSUPPORTED; }
   const size_t lds = (size_t)WAVES * (16 * (D * 2 + 32) + (V0 ? D * 80 : 32 * (D * 2 + 32)));
   hipLaunchKernelGGL((decode_splitkv_kernel<T, KVT, D, WAVES, FEAT, PAD, V0, PACK>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
   int rc = check_hip(hipGetLastError(), "decode_splitkv_kernel launch");
   if (rc != MI355_OK) return rc;
-  if (sp.num_splits > 1 && !a.fused_merge) {
+  if (sp.num_splits > 1 && !a.fused_merge && !a.tree) {
     const dim3 rgrid((unsigned)partial_rows(p), p.num_q_heads);
     if (sp.num_splits <= 32) hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 32>), rgrid, dim3(256), 0, stream, a);
     else if (sp.num_splits <= 64) hipLaunchKernelGGL((reduce_splits_kernel<T, FP8, D, 64>), rgrid, dim3(256), 0, stream, a);
