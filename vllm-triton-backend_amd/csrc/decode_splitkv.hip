@@ -714,7 +714,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
             u32x2_t{mma<T>::pack2(ov[j][0] * inv, ov[j][1] * inv), mma<T>::pack2(ov[j][2] * inv, ov[j][3] * inv)};
       }
     };
-    if (SH == 1) {                       // four splits in all: the workgroup's fold is the result
+    if (active <= 4) {                   // this row's tiles fit one workgroup (the others left at once): its fold is the result
       if (g_ok[0]) store_out(token[0], hq[0], m_all, l_all, om);
       return;
     }
@@ -1185,7 +1185,6 @@ static MergePlan plan_merge(const mi355_attn_params& p) {
   MergePlan m = {sp.num_splits, sp.tiles_per_split, sp.num_splits, false, false};
   if (sp.num_splits <= 1) return m;
   static const bool two_launch = getenv("MI355_DECODE_MERGE_KERNEL") != nullptr;   // A/B switch: separate merge launch
-  static const bool no_tree = getenv("MI355_DECODE_TREE") != nullptr && getenv("MI355_DECODE_TREE")[0] == '0';
   if (two_launch || !counters_fit(p)) return m;
   const int pack = decode_pack_groups(p), ps = decode_pack_shift(p);
   const int D = padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype));
@@ -1196,7 +1195,16 @@ static MergePlan plan_merge(const mi355_attn_params& p) {
   // over all token slots; units with fewer tokens walk their splits on more lanes, see the kernel)
   const int one_trip = (pack == 2 ? 1 : pack == 1 ? 2 : 16 / Gp) * (D >= 128 ? 2 : 4);
   if (sp.num_splits <= one_trip) { m.flat = true; return m; }
-  if (pack == 0 && !no_tree) {
+  // Where the two-level merge pays (round 4, one box): a decode step of a few sequences planned for a long context - what a
+  // graph captured at max_model_len is - merges 64 / 128 slot rows per (token, head) in its second launch; one launch with
+  // the fold inside is 0.4-0.7 us per layer faster there (tools/e2e_proxy.py: 10.7 -> 10.05 us per token and layer at 600
+  // keys, 15.4 -> 15.05 at 13 300; batch 1 at 32768 keys 28.6 -> 27.7). With few splits the merge launch is the cheaper
+  // one (batch 1 at 512 keys, 16 splits: 7.4 us against 8.4), and a batch that fills the chip loses its streaming order to
+  // the four-splits-per-workgroup deal (C5, 16 splits: 173 -> 205 us). MI355_DECODE_TREE=0 | 1 forces either (A/B).
+  static const char* const tree_env = getenv("MI355_DECODE_TREE");
+  const long base = std::max(1L, decode_units(p) * p.num_kv_heads * query_head_groups(p));
+  const bool want_tree = tree_env ? tree_env[0] == '1' : (sp.num_splits > 32 && base <= 32);
+  if (pack == 0 && want_tree) {
     const int max_tiles = (p.max_seqlen_k + kTileKeys - 1) / kTileKeys;
     m.num_splits = std::min((sp.num_splits + 3) & ~3, kMaxSplits);
     m.tiles_per_split = (max_tiles + m.num_splits - 1) / m.num_splits;
