@@ -106,8 +106,27 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     sus = e0.elapsed_time(e1) * 1e-3 / n
+    # GPU-side figure: the same launch 50 times in a HIP graph, replayed (no host issue between launches: a short kernel's
+    # back-to-back figure above is bounded by the ~7 us a Python -> ctypes -> hipLaunchKernel call takes)
+    gs = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(gs):
+        ua_mod.launch(p, dev)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=gs):
+            for _ in range(50):
+                ua_mod.launch(p, dev)
+        for _ in range(5):
+            g.replay()
+        e0.record(gs)
+        for _ in range(10):
+            g.replay()
+        e1.record(gs)
+    torch.cuda.synchronize()
+    gr = e0.elapsed_time(e1) * 1e-3 / 500
     print(f"B={B} L={L} kernel={_lib.last_kernel()} median {med*1e6:8.1f} us  min {ts[0]*1e6:8.1f} us  {flops/med/1e12:7.1f} TFLOP/s "
-          f"(min-time {flops/ts[0]/1e12:7.1f})  frac_of_2.5PF={flops/med/2.5e15:5.3f}  | sustained {sus*1e6:8.1f} us {flops/sus/1e12:7.1f} TFLOP/s", flush=True)
+          f"(min-time {flops/ts[0]/1e12:7.1f})  frac_of_2.5PF={flops/med/2.5e15:5.3f}  | sustained {sus*1e6:8.1f} us {flops/sus/1e12:7.1f} TFLOP/s"
+          f"  | graph {gr*1e6:8.1f} us {flops/gr/1e12:7.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -393,6 +393,8 @@ int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool s
 bool prefill_pw_applicable(const mi355_attn_params& p);    // beyond prefill_supported()
 int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream);
 bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks);   // launch_prefill would hand this call to prefill_pw_kernel
+bool prefill_lat_applicable(const mi355_attn_params& p);   // short-prompt (latency) prefill kernel, prefill_lat.hip: beyond prefill_supported()
+int launch_prefill_lat(const mi355_attn_params& p, hipStream_t stream);
 
 inline int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return MI355_OK;
