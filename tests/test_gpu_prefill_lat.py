@@ -56,17 +56,20 @@ def test_page_sizes(page):
     _check(inp, torch.bfloat16)
 
 
-def test_eight_prompts_of_512_tokens():
-    """8 x 512 (the third shape of VERDICT r03 item 1): sampled rows of every sequence against the oracle."""
+@pytest.mark.parametrize("batch,expect", [(2, "prefill_mfma_lat"), (8, "prefill_mfma")])
+def test_several_prompts_of_512_tokens(batch, expect):
+    """2 x 512 (the four-wave form: two workgroups per CU) and 8 x 512 (the third shape of VERDICT r03 item 1; 2048 Q blocks
+    of 64 rows: the dispatch keeps it on the 128-row kernel, see launch_prefill): sampled rows of every sequence against
+    the oracle."""
     import gpu_util
 
-    lens = [512] * 8
+    lens = [512] * batch
     inp = orc.make_paged_inputs(323, lens, lens, 32, 8, 128, 16, torch.bfloat16)
     d = gpu_util.to_dev(inp)
     out, kernel = gpu_util.run_unified(d, inp["scale"])
-    assert kernel == "prefill_mfma_lat", kernel
+    assert kernel == expect, kernel
     assert not torch.isnan(out).any()
-    for s in range(8):
+    for s in range(batch):
         for t in (0, 1, 63, 64, 300, 511):
             row = s * 512 + t
             ref = gpu_util.oracle_row(orc, inp["q"][row:row + 1], inp["k_cache"], inp["v_cache"], inp["block_table"][s], t + 1, inp["scale"])
@@ -99,12 +102,10 @@ def test_lse_of_the_latency_kernel_against_float64():
                 assert abs(lse[cu[s] + t, h].item() - want) < 2e-3, (s, t, h)
 
 
-def test_non_causal_short_sequences_pinned_on_the_latency_kernel(monkeypatch):
-    """Non-causal attention (every row sees its sequence's whole key range) on this kernel: the dispatch sends such calls to
-    prefill_pw_kernel, so the kernel is pinned through `kernel_select` = 2 and the library's MI355_PREFILL switch is not
-    needed - the parameter block's `non_causal` reaches it through launch_prefill when prefill_pw_kernel does not apply
-    (here: a strided output the 64-rows-per-wave kernel refuses is not needed either - the call below simply checks
-    whichever matrix-core kernel the dispatch picks against the dense reference)."""
+def test_non_causal_short_sequences_on_the_matrix_core_kernels():
+    """prefill_flash_attention(causal=False) over the two-range form (a scratch cache + the unified launch): every row sees
+    its sequence's whole key range. The dispatch sends non-causal calls to prefill_pw_kernel where that applies; this
+    kernel serves `non_causal` too (a pinned build, MI355_PREFILL=lat, runs this test on it)."""
     from mi355_attn import _lib
     from mi355_attn.kernels import prefill_flash_attention
 
