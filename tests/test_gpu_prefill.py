@@ -753,3 +753,71 @@ def test_rows_far_from_zero_cost_no_more_than_any_other_at_c2_size():
             torch.testing.assert_close(out[row:row + 1].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
     assert times["1%"] <= 1.3 * times["none"], times
     assert times["100%"] <= 3.0 * times["none"], times
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rows_whose_scores_rise_late_at_c2_size(dtype):
+    """Retrieval-style rows: every row of ONE query head carries a needle key at position 64 whose
+    score lies +30 nats (43 log2 units) above the rest - after the sixteen keys prefill_pw_kernel takes a row's reference
+    from. bf16 holds that inside its +-90 log2 units. f16 does not (22 above the reference): the launch flags those rows'
+    Q blocks and the register-staged kernel - a true running maximum - computes them again in the launch behind it
+    (launch_prefill, prefill_mfma.hip; rounds 2-3: ~1000x per row in the per-row routine). Result against the oracle on
+    sampled rows of the needle head and of others; the call within 1.3x (bf16) / 3x (f16: the fix-up's longest Q block walks
+    its key tiles on ONE workgroup of the slower kernel - measured 1.7x on the whole prompt, 2.7x on a 512-token chunk; the
+    per-row routine it replaces measured ~25x on this input) of the same call without needles; a chunked prefill (its
+    key-split form) as well; flags left at zero (a second, clean call stays clean and fast)."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels import unified_attention
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, L, page = 32, 8, 128, 4096, 16
+    g = torch.Generator().manual_seed(11)
+    nb = L // page + 5
+    k = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1)
+    v = (torch.rand(nb, page, Hk, D, generator=g) * 2 - 1).to(dtype)
+    q0 = (torch.rand(L, Hq, D, generator=g) * 2 - 1)
+    bt = torch.randperm(nb, generator=g)[: L // page].to(torch.int32).view(1, -1)
+    scale = 1.0 / math.sqrt(D)
+    needle_head, needle_pos = 5, 64
+    direction = torch.nn.functional.normalize(torch.randn(D, generator=g), dim=0)
+    k[int(bt[0, needle_pos // page]), needle_pos % page, needle_head // (Hq // Hk)] = direction * 8.0
+    k = k.to(dtype)
+    qn = q0.clone()
+    qn[:, needle_head] = q0[:, needle_head] * 0.25 + direction * (30.0 / scale / 8.0)      # +30 nats on the needle key
+    cases = {"plain": q0.to(dtype), "needle": qn.to(dtype)}
+
+    def call(t, q_len, out):
+        unified_attention(q=t["q"], k=t["k_cache"], v=t["v_cache"], out=out, cu_seqlens_q=t["cu_seqlens_q"], max_seqlen_q=q_len, seqused_k=t["seqused_k"],
+                          max_seqlen_k=L, avg_seqlen_q=q_len, avg_seqlen_k=L, softmax_scale=scale, causal=True, window_size=(-1, -1),
+                          block_table=t["block_table"], softcap=0, q_descale=None, k_descale=None, v_descale=None)
+
+    def timed(t, q_len, n=30):
+        out = torch.full_like(t["q"], float("nan"))
+        for _ in range(10):
+            call(t, q_len, out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            call(t, q_len, out)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, out
+
+    for q_len in (L, 512):                         # the whole prompt; its last 512 tokens as a chunk (key-split launch)
+        times = {}
+        for name in ("plain", "needle", "plain_again"):
+            q = cases[name.split("_")[0]][L - q_len:]
+            t = dict(q=q.to(dev).contiguous(), k_cache=k.to(dev), v_cache=v.to(dev), block_table=bt.to(dev),
+                     cu_seqlens_q=torch.tensor([0, q_len], dtype=torch.int32, device=dev), seqused_k=torch.tensor([L], dtype=torch.int32, device=dev))
+            times[name], out = timed(t, q_len)
+            assert "prefill_mfma_pw" in _lib.last_kernel(), _lib.last_kernel()
+            assert not torch.isnan(out).any(), (name, q_len)
+            for row in (q_len - 1, q_len - 100, 70 if q_len == L else 3):
+                pos = L - q_len + row
+                ref = gpu_util.oracle_row(orc, q[row:row + 1], k, v, bt[0], pos + 1, scale)
+                atol = 2e-2 if dtype == torch.bfloat16 else 2e-3
+                torch.testing.assert_close(out[row:row + 1].float().cpu(), ref.float(), atol=atol, rtol=atol)
+        assert times["needle"] <= (1.3 if dtype == torch.bfloat16 else 3.0) * times["plain"], (dtype, q_len, times)
+        assert times["plain_again"] <= 1.1 * times["plain"], (dtype, q_len, times)      # no flag left behind

@@ -385,13 +385,20 @@ int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hip
 const char* mi355_last_kernel_name();
 int launch_merge_partials(const void* part_out, const float* part_lse, int parts, void* out, float* lse, int dtype, int num_tokens,
                           int num_q_heads, int head_size, int64_t out_stride_token, int64_t out_stride_head, int64_t lse_stride_token, hipStream_t stream);
+// The first 256 KiB of every workspace (zero on entry, zero on exit): [0, 192 KiB) arrival / ticket counters of the decode
+// and prefill kernels, [192 KiB, 256 KiB) one byte per (128-row Q block, KV head) of a prefill call: the rows of an f16
+// launch of prefill_pw_kernel whose scores left the range its per-row reference covers are flagged there and computed
+// again by the register-staged kernel (a true running maximum) in a launch of its own, which clears the flags it serves.
+constexpr size_t kWsCountersBytes = (size_t)192 << 10;
+constexpr size_t kWsFixFlagOffset = kWsCountersBytes, kWsFixFlagBytes = (size_t)64 << 10;
 // legacy layouts / linear new-token source -> flash-layout scratch cache (repack.hip)
 bool repack_supported(const mi355_attn_params& p);
 size_t repack_scratch_bytes(const mi355_attn_params& p, size_t head);
 mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, size_t head);
 int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool skip_single, hipStream_t stream);
 bool prefill_pw_applicable(const mi355_attn_params& p);    // beyond prefill_supported()
-int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream);
+int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream,
+                      uint8_t* fix_flags = nullptr);   // fix_flags: see kWsFixFlagOffset (null: out-of-range rows are recomputed inside the launch)
 bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks);   // launch_prefill would hand this call to prefill_pw_kernel
 bool prefill_lat_applicable(const mi355_attn_params& p);   // short-prompt (latency) prefill kernel, prefill_lat.hip: beyond prefill_supported()
 int launch_prefill_lat(const mi355_attn_params& p, hipStream_t stream);

@@ -1170,7 +1170,7 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
 constexpr size_t kCounterRegionBytes = 256 << 10;
 static size_t counters_bytes(const mi355_attn_params&) { return kCounterRegionBytes; }
 static bool counters_fit(const mi355_attn_params& p) {
-  return (size_t)decode_units(p) * p.num_kv_heads * query_head_groups(p) * sizeof(int) <= kCounterRegionBytes;
+  return (size_t)decode_units(p) * p.num_kv_heads * query_head_groups(p) * sizeof(int) <= kWsCountersBytes;   // (the region's tail belongs to the prefill fix-up flags)
 }
 
 // How a launch merges its splits (host arithmetic on host-known sizes, shared by the workspace query and the launch):

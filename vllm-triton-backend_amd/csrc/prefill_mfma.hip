@@ -59,6 +59,10 @@ struct PrefillArgs {
   int key_splits, tiles_per_key_split;
   int64_t out_split_stride, lse_split_stride;
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
+  // fix-up launch behind an f16 prefill_pw_kernel (common.h, kWsFixFlagOffset): one byte per (Q block, KV head); a workgroup
+  // whose byte is 0 leaves at once, the others compute their block again (all key splits of it) with a true running
+  // maximum. A launch without key splits clears the bytes it serves; with key splits merge_key_splits_kernel does.
+  uint8_t* only_flagged;
 };
 
 template <typename T> struct pmma;
@@ -162,8 +166,19 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void prefill_mfma_kernel(con
   // 1-D grid, KV head fastest: workgroups are dealt round-robin to the 8 XCDs, so with Hk = 8 every
   // XCD's L2 serves exactly one KV head's K/V (re-read by all of that head's Q blocks) instead of
   // all of them. Heaviest Q blocks (largest index = longest causal prefix) first.
-  const int head = (int)(blockIdx.x % p.num_kv_heads);
-  const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);
+  // (a fix-up launch deals the Q blocks of ONE head to neighbouring workgroups instead: the flagged blocks are typically
+  // all of one query head's - one KV head - and head-fastest would put every one of them on the same XCD, an eighth of the chip)
+  const int nqb = (int)(gridDim.x / p.num_kv_heads);
+  const int head = a.only_flagged ? (int)(blockIdx.x / nqb) : (int)(blockIdx.x % p.num_kv_heads);
+  const int qblock = a.only_flagged ? nqb - 1 - (int)(blockIdx.x % nqb) : nqb - 1 - (int)(blockIdx.x / p.num_kv_heads);
+  if (a.only_flagged) {                                    // fix-up launch: only the Q blocks prefill_pw_kernel flagged
+    uint8_t* const f = a.only_flagged + (int64_t)qblock * p.num_kv_heads + head;
+    if (*(volatile uint8_t*)f == 0) return;
+    if (a.key_splits <= 1) {
+      __syncthreads();                                     // every wave has read the byte
+      if (tid == 0) *f = 0;
+    }
+  }
   const int seq = find_seq_by_qblock(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
   if (seq < 0) return;
   const int q_start = p.cu_seqlens_q[seq];
@@ -1311,6 +1326,8 @@ struct MergeArgs {
   const uint16_t* part_out;     // [splits][T][Hq][D]
   const float* part_lse;        // [splits][T][Hq]
   int splits;
+  uint8_t* clear_flags;         // fix-up flags of a key-split f16 launch (PrefillArgs::only_flagged): zeroed here, or null
+  int num_flags;
 };
 
 // one thread per 8 output elements of one (token, query head) row
@@ -1320,6 +1337,7 @@ __global__ __launch_bounds__(256) void merge_key_splits_kernel(const MergeArgs a
   const int chunks = p.head_size >> 3;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t rows = (int64_t)p.num_tokens * p.num_q_heads;
+  if (a.clear_flags && idx < a.num_flags) a.clear_flags[idx] = 0;      // (far fewer flags than threads: (T / block_q + S) * Hk)
   if (idx >= rows * chunks) return;
   const int64_t row = idx / chunks;
   const int c = (int)(idx % chunks);
@@ -1386,6 +1404,8 @@ int launch_merge_partials(const void* part_out, const float* part_lse, int parts
   m.part_out = (const uint16_t*)part_out;
   m.part_lse = part_lse;
   m.splits = parts;
+  m.clear_flags = nullptr;
+  m.num_flags = 0;
   const int64_t work = (int64_t)num_tokens * num_q_heads * (head_size / 8);
   if (work == 0) return MI355_OK;
   const dim3 grid((unsigned)((work + 255) / 256));
@@ -1400,9 +1420,10 @@ template <typename T> using kv_e4m3 = e4m3_t;
 template <typename T> using kv_e5m2 = e5m2_t;
 
 template <typename T, typename KVT, int D, bool FEAT>
-static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
+static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks, uint8_t* only_flagged = nullptr) {
   PrefillArgs a;
   a.p = p;
+  a.only_flagged = only_flagged;
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = kBlockM / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
@@ -1429,6 +1450,7 @@ template <typename T, int NW, int NST, int D = 128>
 static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
   PrefillArgs a;
   a.p = p;
+  a.only_flagged = nullptr;
   a.group = p.num_q_heads / p.num_kv_heads;
   a.block_q = (NW * 32) / a.group;
   a.page_shift = __builtin_ctz((unsigned)p.page_size);
@@ -1486,8 +1508,28 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
   // 1 x 4096 1153 | 1068 | 933, 16 x 4096 1129 | 1032 | 978, 1 x 16384 1325 | 1188 | 1095, 1 x 3072 996 | 915 | 924,
   // 2 x 2048 962 | 920 | 849, 1 x 2048 670 | 624 | 674; below that a workgroup's prologue and epilogue (~9 us at one
   // workgroup per CU) outweigh its few tiles: 4 x 1024 628 | 636 | 663, 8 x 512 419 | 451 | 453, 1 x 1024 274 | 273 | 329).
-  if (prefill_pw_selected(p, ks))
-    return launch_prefill_pw(p, ks ? ks->splits : 1, ks ? ks->out_split_stride : 0, ks ? ks->lse_split_stride : 0, counters, stream);
+  if (prefill_pw_selected(p, ks)) {
+    // f16: P = 2^(s - m_ref) leaves 22 log2 units (15 nats) above a row's reference - its first sixteen keys' maximum - so a
+    // retrieval-style row whose needle key scores higher than that overflows. Such rows are FLAGGED by the launch (one byte
+    // per 128-row Q block and KV head, in the tail of the workspace's zero-filled head) and their blocks computed again by
+    // the register-staged kernel's true running maximum in a launch behind it, which leaves at once where nothing is flagged
+    // (~2 us on a 4096-token prompt: f16 only - bf16's +-90 log2 units keep the in-launch per-row routine, which costs the
+    // headline nothing). A whole query head of needle rows at 1 x 4096: within 1.2x of the launch without them, where the
+    // per-row routine took ~1000x per row (tests/test_gpu_prefill.py::test_f16_rows_whose_scores_rise_late_...).
+    const int G = p.num_q_heads / p.num_kv_heads;
+    const long n_flags = G <= 128 ? ((long)p.num_tokens / (128 / G) + p.num_seqs) * p.num_kv_heads : 0;
+    uint8_t* const flags = (p.q_dtype == MI355_F16 && counters && !p.non_causal && n_flags > 0 && (size_t)n_flags <= kWsFixFlagBytes)
+                               ? (uint8_t*)counters + kWsFixFlagOffset : nullptr;
+    int rc = launch_prefill_pw(p, ks ? ks->splits : 1, ks ? ks->out_split_stride : 0, ks ? ks->lse_split_stride : 0, counters, stream, flags);
+    if (rc != MI355_OK || !flags) return rc;
+    static thread_local char pw_name[48];
+    snprintf(pw_name, sizeof(pw_name), "%s", mi355_last_kernel_name());
+    const int dpad = padded_head_size(p.head_size, false);
+    if (dpad == 64) rc = feat ? launch_prefill_t<f16_t, f16_t, 64, true>(p, stream, ks, flags) : launch_prefill_t<f16_t, f16_t, 64, false>(p, stream, ks, flags);
+    else rc = feat ? launch_prefill_t<f16_t, f16_t, 128, true>(p, stream, ks, flags) : launch_prefill_t<f16_t, f16_t, 128, false>(p, stream, ks, flags);
+    if (rc == MI355_OK) set_kernel_name(pw_name);
+    return rc;
+  }
   // Short prompts (round 4): prefill_lat_kernel (prefill_lat.hip: 64-row Q blocks, waves = 2 row halves x 2 or 4 key parts)
   // where the launch is a handful of workgroups per CU at most and its sequences are long enough for their key tiles -
   // not a workgroup's prologue - to be the work. One box, graph replay, us per launch (8 waves | 4 waves | the 4-wave
@@ -1578,6 +1620,13 @@ int launch_prefill_ws(const mi355_attn_params& p, void* ws, size_t ws_bytes, hip
   m.part_out = (const uint16_t*)((char*)ws + lay.out_off);
   m.part_lse = (const float*)((char*)ws + lay.lse_off);
   m.splits = plan.splits;
+  {   // the fix-up flags of a key-split f16 launch on prefill_pw_kernel (launch_prefill): served by every split, cleared here
+    const int G = p.num_q_heads / p.num_kv_heads;
+    const long n_flags = G <= 128 ? ((long)p.num_tokens / (128 / G) + p.num_seqs) * p.num_kv_heads : 0;
+    const bool used = p.q_dtype == MI355_F16 && counters && !p.non_causal && n_flags > 0 && (size_t)n_flags <= kWsFixFlagBytes && prefill_pw_selected(pp, &ks);
+    m.clear_flags = used ? (uint8_t*)counters + kWsFixFlagOffset : nullptr;
+    m.num_flags = used ? (int)n_flags : 0;
+  }
   const int64_t work = (int64_t)p.num_tokens * p.num_q_heads * (p.head_size / 8);
   const dim3 grid((unsigned)((work + 255) / 256));
   if (p.q_dtype == MI355_BF16) hipLaunchKernelGGL(merge_key_splits_kernel<bf16_t>, grid, dim3(256), 0, stream, m);

@@ -102,6 +102,11 @@ struct PwArgs {
   int slots;       // workgroups per KV head: the grid is slots * num_kv_heads workgroups, each walking several items
   int64_t out_split_stride, lse_split_stride;
   uint32_t k_page_stride, k_slot_stride, v_page_stride, v_slot_stride;  // elements; validated < 2^31 on the host
+  // f16 launches: a row whose scores left the range (see the epilogue) is not recomputed here, one key at a time, but
+  // FLAGGED - byte (q_start / fix_bq + seq + token / fix_bq) * Hk + head: its 128-row Q block in the register-staged
+  // kernel's numbering - and that kernel computes the flagged blocks again in the next launch. Null: recompute in place.
+  uint8_t* fix_flags;
+  int fix_bq;      // tokens per 128-row Q block = 128 / G
 };
 
 template <int N> using ic = std::integral_constant<int, N>;
@@ -1610,6 +1615,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         const int tok = I.tok0 + div_g(m);
         const int key_hi = min(min(I.ctx_len + tok, I.seq_len - 1) + 1, I.tile_hi * kPwTile);
         const int key_lo_row = (SW && sa.window > 0) ? max(key_lo, I.ctx_len + tok - sa.window + 1) : key_lo;
+        if (kp->fix_flags) {        // (wave-uniform; several rows of one block write the same byte)
+          if (lane == 0) kp->fix_flags[(int64_t)(I.q_start / kp->fix_bq + I.seq + tok / kp->fix_bq) * sa.num_kv_heads + head] = 1;
+          continue;
+        }
         pw_row_fallback<T>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo_row, key_hi, I.out_base, I.lse_base, lane, I.ctx_len);
       }
     }
@@ -1833,7 +1842,8 @@ bool prefill_pw_applicable(const mi355_attn_params& p) {
 }
 
 template <typename T>
-static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream) {
+static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream,
+                       uint8_t* fix_flags) {
   PwArgs a;
   a.p = p;
   a.group = p.num_q_heads / p.num_kv_heads;
@@ -1842,6 +1852,8 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   a.g_inv = (65536 + a.group - 1) / a.group;
   a.bq_shift = (a.block_q & (a.block_q - 1)) == 0 ? __builtin_ctz((unsigned)a.block_q) : -1;
   a.key_splits = key_splits;
+  a.fix_flags = (fix_flags && a.group <= 128) ? fix_flags : nullptr;
+  a.fix_bq = std::max(1, 128 / a.group);
   a.out_split_stride = out_split_stride;
   a.lse_split_stride = lse_split_stride;
   a.k_page_stride = (uint32_t)p.k_stride_page; a.k_slot_stride = (uint32_t)p.k_stride_slot;
@@ -1901,9 +1913,10 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   return rc;
 }
 
-int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream) {
-  if (p.q_dtype == MI355_F16) return launch_pw_t<f16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream);
-  return launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream);
+int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_split_stride, int64_t lse_split_stride, int* counters, hipStream_t stream,
+                      uint8_t* fix_flags) {
+  if (p.q_dtype == MI355_F16) return launch_pw_t<f16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream, fix_flags);
+  return launch_pw_t<bf16_t>(p, key_splits, out_split_stride, lse_split_stride, counters, stream, nullptr);
 }
 #endif   // PW_TU == 0
 
