@@ -17,6 +17,12 @@ Three more workloads are timed the same way right after it and reported in the s
                 (cost-balanced, each rank holds only its sequences' pages)          -> TFLOP/s, strong scaling
   "prefill_b8"  the C2 family's batch of 8: 8 sequences x 4096 tokens, ONE global batch dealt to the ranks
                 the same way                                                         -> TFLOP/s, strong scaling
+  "decode_b64"  C3's batch as ONE global batch of 64 sequences x 8192 keys dealt to the ranks the same way
+                                                                                     -> KV GB/s, strong scaling
+  "prefill_512" the reference's own latency regime (scripts/bench_vllm_latency_range.py:48-50): one 512-token prompt per GPU
+                                                                                     -> us per launch (and TFLOP/s)
+`--verify-gather` (prefill_b8): the ranks' outputs assembled by ONE all_gather (parallel.gather_outputs) and compared with
+the unsharded batch computed on rank 0 (bitwise: same kernel, same per-unit arithmetic order).
 Multi-GPU: the path shards over sequences with no data-path collective: C2/C3/C5 are weak scaling
 (every rank owns its own sequences, KV pages and block table), C4 and prefill_b8 are batch-sharded splits of one batch;
 the only collectives are the timing barrier and the MAX over ranks of the measured time.
@@ -45,8 +51,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 # Untimed launches of the same call before the W warm-up steps (reported as "prewarm_s" in the line): a 120 us kernel timed
 # 20 times right after its inputs were generated measures the device's clock/power ramp out of idle, not the kernel.
 PREWARM_S = float(os.environ.get("MI355_BENCH_PREWARM_S", "0.25"))
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
-ALL_LEGS = ("prefill", "decode", "decode_fp8", "mixed", "prefill_b8")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+ALL_LEGS = ("prefill", "decode", "decode_fp8", "mixed", "prefill_b8", "decode_b64", "prefill_512")
+GLOBAL_LEGS = ("mixed", "prefill_b8", "decode_b64")       # ONE batch (same seed on every rank) dealt to the ranks: strong scaling
 
 
 def spawn_ranks(args) -> int:
@@ -67,6 +74,8 @@ def spawn_ranks(args) -> int:
     cmd += ["--legs", args.legs]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.verify_gather:
+        cmd.append("--verify-gather")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -90,10 +99,12 @@ def make_workload(kind, device, seed, rank, world):
     dt = torch.bfloat16
     gen = torch.Generator(device=device).manual_seed(seed)
     g = torch.Generator(device="cpu").manual_seed(seed)
-    if kind in ("mixed", "prefill_b8"):                   # one GLOBAL batch (same seed on every rank), sharded below
+    if kind in GLOBAL_LEGS:                               # one GLOBAL batch (same seed on every rank), sharded below
         Hq, Hk, D = 32, 8, 128
         if kind == "mixed":                               # C4
             qlens, kvlens = c4_lens()
+        elif kind == "decode_b64":                        # C3's batch, dealt to the ranks (the weak-scaling "decode" leg replicates it)
+            qlens, kvlens = [1] * 64, [8192] * 64
         else:                                             # the C2 family's batch of 8 (B in {2,4,8} for the multi-GPU curve)
             qlens, kvlens = [4096] * 8, [4096] * 8
         S, T = len(qlens), sum(qlens)
@@ -113,6 +124,8 @@ def make_workload(kind, device, seed, rank, world):
         from mi355_attn import parallel
 
         loc = parallel.shard_batch(rank, world, q, k, v, cu, torch.tensor(kvlens, dtype=torch.int32), bt)
+        whole = dict(q=q, k_cache=k, v_cache=v, cu_seqlens_q=cu.to(device), seqused_k=torch.tensor(kvlens, dtype=torch.int32, device=device),
+                     block_table=bt.to(device), q_len=max(qlens), kv_len=max(kvlens)) if (VERIFY_GATHER and kind == "prefill_b8") else None
         del q, k, v
         lq = (loc.cu_seqlens_q[1:] - loc.cu_seqlens_q[:-1]).tolist()
         lk = loc.seqused_k.tolist()
@@ -121,9 +134,11 @@ def make_workload(kind, device, seed, rank, world):
         return dict(kind=kind, q=loc.q.contiguous(), k_cache=loc.k_cache.contiguous(), v_cache=loc.v_cache.contiguous(), block_table=loc.block_table,
                     cu_seqlens_q=loc.cu_seqlens_q, seqused_k=loc.seqused_k, out=torch.empty_like(loc.q), q_len=max(lq), kv_len=max(lk),
                     Hq=Hq, Hk=Hk, D=D, scale=1.0 / math.sqrt(D), k_scale=None, flops=flops_all, bytes=bytes_all, global_work=True,
-                    local=dict(seqs=len(lq), tokens=sum(lq)))
+                    local=dict(seqs=len(lq), tokens=sum(lq)), shard=loc, whole=whole, total_tokens=T)
     if kind == "prefill":      # C2
         Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 1, 4096, 4096, dt
+    elif kind == "prefill_512":   # the latency regime: one 512-token prompt
+        Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 1, 512, 512, dt
     elif kind == "decode":     # C3
         Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 64, 1, 8192, dt
     else:                      # C5 "decode_fp8": Llama-3-70B shape, fp8-e4m3 KV (batch not given in BASELINE: 16)
@@ -140,13 +155,39 @@ def make_workload(kind, device, seed, rank, world):
     w = dict(kind=kind, q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=cu, seqused_k=sl, out=torch.empty_like(q), B=B, q_len=q_len,
              kv_len=kv_len, Hq=Hq, Hk=Hk, D=D, scale=1.0 / math.sqrt(D), global_work=False,
              k_scale=torch.ones(1, device=device) if kvdt != dt else None)
-    if kind == "prefill":
+    if kind in ("prefill", "prefill_512"):
         w["flops"] = 4.0 * q_len * kv_len * D * Hq / 2 * B
         w["bytes"] = (2 * q.numel() + 2 * B * kv_len * Hk * D) * 2.0
     else:
         w["flops"] = 4.0 * B * Hq * kv_len * D
         w["bytes"] = B * kv_len * Hk * D * 2 * float(k.element_size()) + 2 * q.numel() * 2.0 + bt.numel() * 4.0 + (2 * B + 1) * 4.0
     return w
+
+
+VERIFY_GATHER = False
+
+
+def verify_gather(w, device, distributed):
+    """prefill_b8 --verify-gather: every rank's share through the kernels, ONE all_gather_into_tensor of the padded shares
+    (parallel.gather_outputs), compared on rank 0 with the whole batch computed there unsharded. Bitwise: the same
+    kernel computes the same rows in the same order whatever rank holds them."""
+    import torch
+    from mi355_attn import parallel
+    from mi355_attn.kernels import unified as ua
+
+    loc, whole = w["shard"], w["whole"]
+    torch.cuda.synchronize(device)
+    full = parallel.gather_outputs(w["out"], loc, w["total_tokens"]) if distributed else None
+    ref = torch.empty_like(whole["q"])
+    p, keep = ua.fill_attn_params(whole["q"], whole["k_cache"], whole["v_cache"], ref, whole["cu_seqlens_q"], whole["q_len"], whole["seqused_k"],
+                                  whole["kv_len"], w["scale"], (-1, -1), whole["block_table"], 0.0, None, None, None, None)
+    ua.launch(p, device)
+    torch.cuda.synchronize(device)
+    if full is None:                                       # one GPU: the "gather" is the identity on rank 0's share = the batch
+        full = torch.empty_like(ref)
+        full[loc.token_index.to(device)] = w["out"]
+    same = bool(torch.equal(full.view(torch.int16), ref.view(torch.int16)))
+    return {"bitwise_equal_to_unsharded": same, "max_abs_diff": float((full.float() - ref.float()).abs().max())}
 
 
 def build_call(w, device):
@@ -306,11 +347,15 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="prefill_b8: assemble the ranks' outputs with one all_gather and compare with the unsharded batch (rank 0)")
     ap.add_argument("--legs", default=",".join(ALL_LEGS),
                     help="comma list of the workloads to run (profiles of ONE kernel: --legs prefill | decode | decode_fp8 | mixed | prefill_b8); "
                          "the driver's default runs all of them, the headline value is the prefill leg's")
     args = ap.parse_args()
 
+    global VERIFY_GATHER
+    VERIFY_GATHER = args.verify_gather
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # inside torch.distributed.run
     if args.gpus > 1 and not launched:
         raise SystemExit(spawn_ranks(args))
@@ -351,7 +396,7 @@ def main():
     for kind in ALL_LEGS:
         if kind not in legs:
             continue
-        w = make_workload(kind, device, seed=0 if kind in ("mixed", "prefill_b8") else rank, rank=rank, world=world)
+        w = make_workload(kind, device, seed=0 if kind in GLOBAL_LEGS else rank, rank=rank, world=world)
         call = build_call(w, device)
         call()
         torch.cuda.synchronize(device)
@@ -362,6 +407,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max, launch_max = t.tolist()
         results[kind] = dict(w=w, kernel=kernel, wall=wall_max, per_launch=launch_max)
+        if kind == "prefill_b8" and args.verify_gather:
+            results[kind]["gather"] = verify_gather(w, device, distributed)
+        for key in ("shard", "whole"):
+            w.pop(key, None)
         if kind not in ("prefill", "decode"):
             for key in ("q", "k_cache", "v_cache", "out", "_keep"):     # free the big legs before the next one
                 w.pop(key, None)
@@ -370,7 +419,7 @@ def main():
     if rank == 0:
         K = args.steps
         pf, dc, d8, mx = results.get("prefill"), results.get("decode"), results.get("decode_fp8"), results.get("mixed")
-        b8 = results.get("prefill_b8")
+        b8, d64, p512 = results.get("prefill_b8"), results.get("decode_b64"), results.get("prefill_512")
         line = {"legs": legs}
         if pf:
             pf_val = pf["w"]["flops"] * n_gpus * K / pf["wall"] / 1e12
@@ -379,6 +428,8 @@ def main():
                 "value": round(pf_val, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": K, "warmup": args.warmup, "prewarm_s": PREWARM_S,
                 "ms_per_step": round(pf["wall"] / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16", "data": "synthetic",
+                "cache_state": "timed steps reuse the same inputs back to back, no L2 / Infinity-Cache sweep between launches (the reference's do_bench "
+                               "flushes): immaterial for the compute-bound C2 (K/V 16.8 MB) and for C3 / C5, whose 2.1 / 1.1 GB streams dwarf the 256 MB cache",
                 "config": {"workload": "C2 prefill: Llama-3-8B shape Hq32/Hk8/D128, 1 seq x 4096 tokens per GPU, causal, paged KV (16-token pages)",
                            "global_batch": n_gpus, "seq_len": 4096, "parallelism": f"batch-sharded x{n_gpus}, no collective", "kernel": pf["kernel"]},
                 "roofline": roofline("mfma", pf["w"]["flops"], MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12, pf["w"], pf, K, {
@@ -417,6 +468,22 @@ def main():
                                   "config": {"workload": "C2 family: Hq32/Hk8/D128, 8 sequences x 4096 tokens, ONE batch dealt to the ranks by parallel.shard_batch",
                                              "global_batch": 8, "parallelism": f"batch-sharded x{n_gpus}, no collective",
                                              "rank0_share": b8["w"]["local"], "kernel": b8["kernel"]}}
+            if "gather" in b8:
+                line["prefill_b8"]["gather_check"] = b8["gather"]
+        if d64:
+            d64_val = d64["w"]["bytes"] * K / d64["wall"] / 1e9       # ONE global batch: strong scaling
+            line["decode_b64"] = {"metric": "KV GB/s (paged decode, C3's batch of 64 dealt to the ranks)", "value": round(d64_val, 1), "unit": "GB/s",
+                                  "ms_per_step": round(d64["wall"] / K * 1e3, 4), "scaling": "strong",
+                                  "config": {"workload": "C3 as ONE batch: Hq32/Hk8/D128, 64 sequences x kv_len 8192, bf16, dealt to the ranks by parallel.shard_batch",
+                                             "global_batch": 64, "parallelism": f"batch-sharded x{n_gpus}, no collective",
+                                             "rank0_share": d64["w"]["local"], "kernel": d64["kernel"]}}
+        if p512:
+            line["prefill_512"] = {"metric": "us per launch (one 512-token prompt per GPU: the reference's latency regime)",
+                                   "value": round(p512["wall"] / K * 1e6, 2), "unit": "us", "higher_is_better": False,
+                                   "tflops_per_gpu": round(p512["w"]["flops"] * K / p512["wall"] / 1e12, 1),
+                                   "us_per_launch_events": round(p512["per_launch"] * 1e6, 2),
+                                   "config": {"workload": "Hq32/Hk8/D128, 1 seq x 512 tokens per GPU, causal, paged KV (16-token pages), launches back to back",
+                                              "kernel": p512["kernel"]}}
         if n_gpus == 1 and not args.no_cpu_baseline:
             if pf:
                 line["cpu_baseline"] = cpu_baseline(pf["w"], pf["w"]["out"])

@@ -116,3 +116,53 @@ def test_context_parallel_exchange_world2_gloo():
     for rank, err_out, err_lse, lens in sorted(res):
         assert err_out < 1e-5 and err_lse < 1e-5, (rank, err_out, err_lse)
     assert sorted(res)[0][3] == [512, 32, 16, 1] and sorted(res)[1][3] == [488, 8, 1, 0]   # rank 1 holds no key of the last sequence
+
+
+def test_shard_batch_plan_equals_the_per_page_walk():
+    """The vectorised shard plan (tokens, compacted pages, local block table) against the obvious per-sequence, per-page walk
+    on a ragged batch: more ranks than heavy sequences, a sequence without query tokens, one without keys, 1 .. 5 ranks."""
+    import torch
+    from mi355_attn import parallel
+
+    g = torch.Generator().manual_seed(3)
+    q_lens = [7, 1, 0, 40, 1, 129, 3]
+    kv_lens = [70, 45, 16, 70, 0, 300, 3]
+    page, Hq, Hk, D = 16, 4, 2, 8
+    S, T = len(q_lens), sum(q_lens)
+    pps = [(n + page - 1) // page for n in kv_lens]
+    nb = sum(pps) + 5
+    k = torch.rand(nb, page, Hk, D, generator=g)
+    v = torch.rand(nb, page, Hk, D, generator=g)
+    q = torch.rand(T, Hq, D, generator=g)
+    perm = torch.randperm(nb, generator=g).to(torch.int32)
+    bt = torch.full((S, max(pps)), -7, dtype=torch.int32)          # (entries past a sequence's pages hold junk)
+    o = 0
+    for i, n in enumerate(pps):
+        bt[i, :n] = perm[o:o + n]
+        o += n
+    cu = torch.zeros(S + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(torch.tensor(q_lens, dtype=torch.int32), 0)
+    sk = torch.tensor(kv_lens, dtype=torch.int32)
+    for world in (1, 2, 3, 5):
+        owned = parallel.assign_sequences(q_lens, kv_lens, world)
+        assert sorted(i for o_ in owned for i in o_) == list(range(S))
+        seen_tokens = []
+        for rank in range(world):
+            loc = parallel.shard_batch(rank, world, q, k, v, cu, sk, bt)
+            assert loc.seq_ids == owned[rank]
+            tok, pages = [], []
+            for i in owned[rank]:
+                tok += list(range(int(cu[i]), int(cu[i + 1])))
+                pages += bt[i, : pps[i]].tolist()
+            assert loc.token_index.tolist() == tok
+            seen_tokens += tok
+            assert torch.equal(loc.q, q[torch.tensor(tok, dtype=torch.long)] if tok else q[:0])
+            assert torch.equal(loc.k_cache, k[torch.tensor(pages, dtype=torch.long)] if pages else k[:0])
+            assert torch.equal(loc.v_cache, v[torch.tensor(pages, dtype=torch.long)] if pages else v[:0])
+            # every local sequence's pages, through the LOCAL block table, are its global pages in order
+            for row, i in enumerate(owned[rank]):
+                assert int(loc.seqused_k[row]) == kv_lens[i] and int(loc.cu_seqlens_q[row + 1] - loc.cu_seqlens_q[row]) == q_lens[i]
+                lp = loc.block_table[row, : pps[i]].long()
+                assert torch.equal(loc.k_cache[lp], k[bt[i, : pps[i]].long()])
+            assert [m.tolist() for m in loc.rank_token_index] == [[t for i in o_ for t in range(int(cu[i]), int(cu[i + 1]))] for o_ in owned]
+        assert sorted(seen_tokens) == list(range(T))

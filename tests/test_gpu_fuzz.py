@@ -158,3 +158,50 @@ def test_sequences_without_query_tokens_are_skipped(q_lens, kv_lens):
     assert kernel != "generic"
     assert not torch.isnan(out).any() and not torch.isnan(ref).any()
     torch.testing.assert_close(out.float(), ref.float(), atol=2e-2, rtol=2e-2, msg=lambda m: f"[{kernel}] {m}")
+
+
+# ---- the same differential fuzz against the ORACLE (the legs above are kernel-vs-kernel). Small shapes so that
+# the CPU restatement of the reference's kernels (oracle/paged_attention_oracle.py, pinned by tests/golden) takes about a second
+# per case; 48 cases, every feature and cache type of the generator above, whatever kernel the dispatcher picks.
+ORACLE_CASES, ORACLE_SEED = int(os.environ.get("MI355_FUZZ_ORACLE_CASES", "48")), int(os.environ.get("MI355_FUZZ_ORACLE_SEED", "9000"))
+
+
+def _small_case(rng):
+    n_seq = rng.randint(1, 4)
+    kind = rng.choice(["decode", "prefill", "mixed", "mixed"])
+    q_lens, kv_lens = [], []
+    for _ in range(n_seq):
+        ql = 1 if (kind == "decode" or (kind == "mixed" and rng.random() < 0.5)) else rng.choice([2, 5, 16, 31, 64, 65, 129])
+        q_lens.append(ql)
+        kv_lens.append(ql + rng.choice([0, 0, 1, 15, 16, 17, 63, 64, 255, 600]))
+    hk = rng.choice([1, 2, 4])
+    g = rng.choice([1, 2, 3, 4, 8])
+    d = rng.choice([64, 96, 128, 128, 128, 256, 80])
+    page = rng.choice([16, 16, 32, 128])
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    kv_dtype = rng.choice([None, None, torch.float8_e4m3fn, torch.float8_e5m2]) if d % 16 == 0 else None
+    return dict(q_lens=q_lens, kv_lens=kv_lens, hq=hk * g, hk=hk, d=d, page=page, dtype=dtype, kv_dtype=kv_dtype,
+                window=rng.choice([0, 0, 0, 7, 64, 300]), softcap=rng.choice([0.0, 0.0, 0.0, 25.0]), use_alibi=rng.random() < 0.2)
+
+
+@pytest.mark.parametrize("case_id", range(ORACLE_CASES))
+def test_dispatched_kernels_agree_with_the_oracle(case_id):
+    import gpu_util
+
+    rng = random.Random(ORACLE_SEED + case_id)
+    c = _small_case(rng)
+    kv_scale = 0.5 if c["kv_dtype"] is not None else None
+    kw = dict(kv_dtype=c["kv_dtype"], kv_scale=0.5) if c["kv_dtype"] is not None else {}
+    inp = orc.make_paged_inputs(ORACLE_SEED + 500 + case_id, c["q_lens"], c["kv_lens"], c["hq"], c["hk"], c["d"], c["page"], c["dtype"], **kw)
+    alibi = torch.tensor([2.0 ** (-(i % 8 + 1)) for i in range(c["hq"])], dtype=torch.float32) if c["use_alibi"] else None
+    # (mode: the reference's 2D kernel for batches with a prefill, its 3D kernel + reduce_segments for decode batches, :884)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"],
+                                       sliding_window=c["window"], softcap=c["softcap"], alibi_slopes=alibi, k_scale=kv_scale or 1.0, v_scale=kv_scale or 1.0,
+                                       mode="3d" if max(c["q_lens"]) == 1 else "2d")
+    t = gpu_util.to_dev(inp)
+    if alibi is not None:
+        t["alibi_slopes"] = alibi.to(gpu_util.DEV)
+    out, kernel = gpu_util.run_unified(t, inp["scale"], window=c["window"], softcap=c["softcap"], kv_scale=kv_scale)
+    assert not torch.isnan(out).any(), (kernel, c)
+    atol, rtol = golden_io.tolerance(c["dtype"], c["kv_dtype"])
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol, msg=lambda m: f"[{kernel}] {c}\n{m}")

@@ -123,3 +123,53 @@ def test_batch_sharding_and_context_parallel_on_the_hip_kernels_world2():
         assert kernel != "generic", kernel
         owned += seq_ids
     assert sorted(owned) == list(range(10))
+
+
+def test_bench_two_gpu_path_runs_or_refuses():
+    """`bench.py --gpus 2` is the command the driver runs for the scaling curve (one rank per GPU over RCCL: `nccl`
+    process group, barrier, MAX over ranks, the strong-scaling legs dealt by parallel.shard_batch, the gather check). With
+    two devices visible it runs here as a child, a few steps, and its line must carry every leg asked for and a bitwise
+    gather; on a one-GPU box the same command must REFUSE (exit code 2) rather than report a smaller job under that
+    label."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--legs", "mixed,prefill_b8,decode_b64", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--verify-gather"]
+    env = dict(os.environ, MI355_BENCH_PREWARM_S="0.02", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+        assert "refusing" in r.stderr
+        return
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for leg in ("mixed", "prefill_b8", "decode_b64"):
+        assert line[leg]["value"] > 0 and line[leg]["scaling"] == "strong", leg
+    assert line["prefill_b8"]["gather_check"]["bitwise_equal_to_unsharded"] is True
+    assert line["prefill_b8"]["config"]["rank0_share"]["seqs"] == 4
+
+
+def test_bench_one_gpu_gather_check_and_new_legs():
+    """The same legs on ONE GPU (what this box has): the strong-scaling legs' rank-0 share is the whole batch, the gather
+    check degenerates to the identity and must still be bitwise, and the latency leg reports microseconds."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--legs", "prefill_b8,decode_b64,prefill_512", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--verify-gather"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MI355_BENCH_PREWARM_S="0.02"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["prefill_b8"]["gather_check"]["bitwise_equal_to_unsharded"] is True
+    assert line["decode_b64"]["unit"] == "GB/s" and line["decode_b64"]["value"] > 1000
+    assert line["prefill_512"]["unit"] == "us" and 3 < line["prefill_512"]["value"] < 200
+    assert line["prefill_512"]["config"]["kernel"] == "prefill_mfma_lat"
