@@ -163,6 +163,27 @@ def test_a_non_causal_call_never_takes_the_packed_decode_kernel(lib):
     assert n_nc <= h.mi355_attn_workspace_bytes(C.byref(p))
 
 
+def test_self_attention_scratch_is_sized_by_the_tokens_not_by_the_longest_sequence(lib):
+    """prefill_flash_attention's one-call self-attention path (linear k / v as the call's new-token source, no context)
+    gathers the keys into a flash-layout scratch inside the workspace: packed by the reference's Q-block numbering
+    (sequence i's pages start at cu_seqlens[i] / 16 + i), num_tokens / 16 + num_seqs pages, NOT num_seqs x the longest
+    sequence's pages (256 sequences, one of 8192 tokens, Hk 8 / D 128: 8.6 GB)."""
+    h = lib.load()
+    buf = np.zeros(64, dtype=np.uint8)
+    addr = (buf.ctypes.data + 15) & ~15
+    p = _c3_like_params(lib, addr)
+    p.k_new = p.v_new = addr
+    p.new_stride_token, p.new_stride_head = 1024, 128
+    p.new_kv_all_rows = 1
+    p.num_seqs, p.num_tokens, p.max_seqlen_q, p.max_seqlen_k = 256, 8192 + 255 * 32, 8192, 8192
+    p.block_table_stride = 0
+    n = h.mi355_attn_workspace_bytes(C.byref(p))
+    page_bytes = 16 * 8 * 128 * 2
+    pages = p.num_tokens // 16 + p.num_seqs + 1
+    assert 2 * pages * page_bytes <= n <= 2 * pages * page_bytes + (8 << 20), n          # K and V, + counters, table, partials
+    assert n < (1 << 30)                                                                   # (padded: 256 x 512 pages x 64 KiB = 8.6 GB)
+
+
 def test_one_version_number(lib):
     """include/mi355_attn.h is the version source: the library, the Python package and setup.py report it."""
     import mi355_attn

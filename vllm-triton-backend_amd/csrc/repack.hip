@@ -25,6 +25,8 @@ struct RepackArgs {
   uint16_t* v_dst;
   int32_t* bt_dst;
   int pages_per_seq;
+  int total_pages;  // scratch pages in all (block-table entries past a sequence's pages are clamped to it: never dereferenced, but always valid)
+  int tight;        // 1: a sequence's scratch pages start at cu_seqlens_q[seq] / 16 + seq (self-attention: keys == query tokens, see layout())
   int vec_k, vec_v, vec_new;   // 16-byte (fp8: 8-byte) loads of eight head dims are legal for that source
   int v_keys_contiguous;       // V is d-major with a page's keys contiguous (v0): eight KEYS per load, turned in LDS
   int skip_single;             // sequences with query_len == 1 are not repacked (left out or served from the cache)
@@ -119,10 +121,13 @@ template <typename QT, typename KVT>
 __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   const mi355_attn_params& p = a.p;
   const int pg0 = blockIdx.x * kPagesPerWg, seq = blockIdx.y, h = blockIdx.z;
-  if (h == 0 && threadIdx.x < kPagesPerWg && pg0 + (int)threadIdx.x < a.pages_per_seq)
-    a.bt_dst[(int64_t)seq * a.pages_per_seq + pg0 + threadIdx.x] = seq * a.pages_per_seq + pg0 + threadIdx.x;
   const int seq_len = p.seqused_k[seq];
   const int q_start = p.cu_seqlens_q[seq], q_len = p.cu_seqlens_q[seq + 1] - q_start;
+  // first scratch page of this sequence: its row of the padded [num_seqs][pages_per_seq] grid, or - tight - the reference's
+  // Q-block numbering applied to pages (an upper bound of the pages of the sequences before it, :935-943)
+  const int64_t page_base = a.tight ? (int64_t)(q_start / kRepackPage + seq) : (int64_t)seq * a.pages_per_seq;
+  if (h == 0 && threadIdx.x < kPagesPerWg && pg0 + (int)threadIdx.x < a.pages_per_seq)
+    a.bt_dst[(int64_t)seq * a.pages_per_seq + pg0 + threadIdx.x] = (int32_t)min(page_base + pg0 + (int64_t)threadIdx.x, (int64_t)a.total_pages - 1);
   if (q_len <= 0 || (a.skip_single && q_len == 1)) return;
   if (pg0 * kRepackPage >= seq_len) return;
   const int ctx = seq_len - q_len;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
 #pragma unroll
     for (int u = 0; u < kPagesPerWg; ++u) {
       if (pg0 + u >= a.pages_per_seq) break;
-      const int64_t dst = ((int64_t)seq * a.pages_per_seq + pg0 + u) * kRepackPage * Hk * D + ((int64_t)slot * Hk + h) * D + d0;
+      const int64_t dst = (page_base + pg0 + u) * kRepackPage * Hk * D + ((int64_t)slot * Hk + h) * D + d0;
       *(uint4*)(a.k_dst + dst) = kk[u];
       *(uint4*)(a.v_dst + dst) = vv[u];
     }
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
   if (pg >= a.pages_per_seq) break;
   const int j0 = pg * kRepackPage;
   if (j0 >= seq_len) break;
-  const int64_t dst_page = ((int64_t)seq * a.pages_per_seq + pg) * kRepackPage * Hk * D;
+  const int64_t dst_page = (page_base + pg) * kRepackPage * Hk * D;
   if (u > 0) __syncthreads();                   // vt is reused
   // V of a page that comes from the cache as a whole (no new-token rows in it), d-major source
   const bool turn_v = a.v_keys_contiguous && !(use_new && j0 + kRepackPage > ctx);
@@ -254,12 +259,18 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct RepackLayout { size_t bt_off, k_off, v_off, total; };
 
 // the scratch follows `head` bytes that the attention kernels on the scratch use themselves (split-KV partials)
+// Self-attention from linear tensors (new_kv_all_rows: every key is one of the call's own query tokens, no context): the
+// sequences' pages are packed - sequence i's start at cu_seqlens_q[i] / 16 + i, num_tokens / 16 + num_seqs pages in all, host
+// arithmetic - instead of padded to the longest sequence: a skewed varlen batch (256 sequences, one of 8192 tokens) took
+// 8.6 GB of scratch where its 2 x 130k keys need 0.5 GB. Block-table rows stay pages_per_seq wide.
+static bool tight_scratch(const mi355_attn_params& p) { return p.new_kv_all_rows != 0 && p.k_new != nullptr; }
 RepackLayout layout(const mi355_attn_params& p, size_t head) {
-  const size_t pages = (size_t)p.num_seqs * pages_per_seq(p);
+  const size_t grid_pages = (size_t)p.num_seqs * pages_per_seq(p);
+  const size_t pages = tight_scratch(p) ? (size_t)p.num_tokens / kRepackPage + p.num_seqs + 1 : grid_pages;
   const size_t cache_bytes = pages * kRepackPage * p.num_kv_heads * p.head_size * 2;
   RepackLayout l;
   l.bt_off = align256(head);
-  l.k_off = align256(l.bt_off + pages * sizeof(int32_t));
+  l.k_off = align256(l.bt_off + grid_pages * sizeof(int32_t));
   l.v_off = align256(l.k_off + cache_bytes);
   l.total = l.v_off + cache_bytes;
   return l;
@@ -330,6 +341,8 @@ int launch_repack(const mi355_attn_params& p, void* scratch, size_t head, bool s
   a.k_dst = (uint16_t*)(base + l.k_off);
   a.v_dst = (uint16_t*)(base + l.v_off);
   a.pages_per_seq = pages_per_seq(p);
+  a.tight = tight_scratch(p) ? 1 : 0;
+  a.total_pages = (int)(tight_scratch(p) ? (size_t)p.num_tokens / kRepackPage + p.num_seqs + 1 : (size_t)p.num_seqs * pages_per_seq(p));
   a.skip_single = skip_single ? 1 : 0;
   // 16-byte (16-bit cache) / 8-byte (fp8 cache) loads of eight consecutive head dims
   const int64_t unit = is_fp8(p.kv_dtype) ? 8 : 16;
