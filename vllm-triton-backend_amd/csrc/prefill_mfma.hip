@@ -1541,7 +1541,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
   if (!ks && prefill_lat_applicable(p)) {
     const long wgs = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 64 + p.num_seqs) * p.num_kv_heads;   // its grid
     const bool pinned = variant && variant[0] == 'l';
-    const bool pick = wgs <= 288 || (p.max_seqlen_k >= 640 && p.max_seqlen_k < 2048 && wgs <= 1024) || (p.max_seqlen_k >= 384 && p.max_seqlen_k < 640 && wgs <= 512);
+    const bool pick = wgs <= 288 || (p.max_seqlen_k >= 640 && p.max_seqlen_k < 2048 && wgs <= 1024) || (p.max_seqlen_k >= 384 && p.max_seqlen_k < 640 && wgs <= 576);
     if (pinned || (!variant && p.max_seqlen_k < 2048 && pick)) return launch_prefill_lat(p, stream);
   }
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void repack_kernel(RepackArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < kPagesPerWg; ++u) {
-      if (pg0 + u >= a.pages_per_seq) break;
+      if (pg0 + u >= a.pages_per_seq || (pg0 + u) * kRepackPage >= seq_len) break;   // (a page past the sequence is nobody's - packed: the next sequence's)
       const int64_t dst = (page_base + pg0 + u) * kRepackPage * Hk * D + ((int64_t)slot * Hk + h) * D + d0;
       *(uint4*)(a.k_dst + dst) = kk[u];
       *(uint4*)(a.v_dst + dst) = vv[u];
