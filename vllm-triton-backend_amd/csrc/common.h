@@ -334,6 +334,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+// The same with a SCALAR base: lane l's 16 bytes from sbase + voff land at `lds_dst` + 16 l. (M0 is not saved: the kernels
+// that use this form have no other use of it - no indirect register indexing, no GWS / message instructions.)
+__device__ __forceinline__ void glds16_s(uint32_t voff, uint64_t sbase, uint32_t lds_dst) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)sbase), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32));
+  const uint64_t bu = ((uint64_t)bhi << 32) | blo;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(bu), "s"(dst) : "memory");
+}
 // The 4-byte form: lane l's dword lands at `lds_dst` + 4*l (256 bytes per wave-instruction).
 __device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;

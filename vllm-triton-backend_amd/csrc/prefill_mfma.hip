@@ -818,6 +818,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KSTEPS) : "memory");
     __syncthreads();
   }
+  // NW == 4 (round 4): wave w stages 16-key group w of every tile, both matrices - ONE block-table entry and one scalar
+  // base per tile and wave, four K and four V instructions of 1 KiB (rows 4j .. 4j+3 of the group) with constant per-lane
+  // offsets and the base as an SGPR pair. The former deal - every wave a quarter of every 16-row piece - cost each wave
+  // four page look-ups and 64-bit address sums per tile, ~250 instructions where this costs ~50, and one wave per SIMD
+  // pays ~4 cycles for each (prefill_lat.hip: the same change took that kernel from 15.9 to 13.1 us at 1 x 512).
+  constexpr bool WAVE_GROUP = NW == 4 && D == 128;
+  uint64_t wg_kb = 0, wg_vb = 0;              // this wave's group of the tile being staged: scalar bases
+  bool wg_tail = false;
+  int wg_key0 = 0;
+  uint32_t wgk_voff[4], wgv_voff[4];
+  if constexpr (WAVE_GROUP) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * j + (lane >> 4), c = lane & 15;
+      wgk_voff[j] = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((c ^ fk_of(r)) << 4));
+      wgv_voff[j] = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((c ^ fv_of(r)) << 4));
+    }
+  }
   auto dma_begin = [&](int tile) {          // call once per tile before its pieces
     if constexpr (!BT_IN_LDS) {
       const int e0 = (min(tile * 4, last_group) << 4) >> a.page_shift;
@@ -827,9 +845,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
         bt_nxt = bt[min((bt_chunk + 1) * 64 + lane, bt_last_any)];
       }
     }
+    if constexpr (WAVE_GROUP) {
+      const int gi = min(tile * 4 + wave, last_group);
+      wg_key0 = gi << 4;
+      const int slot0 = wg_key0 & page_mask;
+      const uint32_t page = (uint32_t)__builtin_amdgcn_readlane(bt_cur, (wg_key0 >> a.page_shift) & 63);
+      const uint64_t k_off = (uint64_t)page * (a.k_page_stride * 2) + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2;
+      const uint64_t v_off = a.kv_same_strides ? k_off : (uint64_t)page * (a.v_page_stride * 2) + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2;
+      wg_kb = (uint64_t)kbase + k_off;
+      wg_vb = (uint64_t)vbase + v_off;
+      wg_tail = wg_key0 + 16 > seq_len;       // the sequence ends inside this group -> rows past it fetch its last row
+    }
   };
   // piece i of a tile = key rows RP*i .. RP*i+RP-1: one K and one V LDS-DMA per lane (1 KiB each per wave)
   auto dma_piece = [&](int tile, char* stage, int i) {
+    if constexpr (WAVE_GROUP) {             // "piece" i = instruction i of this wave's group: rows 16 wave + 4 i .. + 3
+      uint32_t kvo = wgk_voff[i], vvo = wgv_voff[i];
+      if (wg_tail) {
+        const int rig = 4 * i + (lane >> 4), c = lane & 15, r = min(rig, max(seq_len - 1 - wg_key0, 0));
+        kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((c ^ fk_of(rig)) << 4));
+        vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((c ^ fv_of(rig)) << 4));
+      }
+      const uint32_t dst = lds_addr(stage) + (uint32_t)(wave * (16 * ROWB) + i * 1024);
+      glds16_s(kvo, wg_kb, dst);
+      glds16_s(vvo, wg_vb, dst + KBUF);
+      return;
+    }
     const int gi = min(tile * 4 + grp_of(i), last_group);
     const int key0 = gi << 4;
     const int slot0 = key0 & page_mask;
