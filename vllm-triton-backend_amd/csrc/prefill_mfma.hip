@@ -1572,17 +1572,18 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
     return rc;
   }
   // Short prompts (round 4): prefill_lat_kernel (prefill_lat.hip: 64-row Q blocks, waves = 2 row halves x 2 or 4 key parts)
-  // where the launch is a handful of workgroups per CU at most and its sequences are long enough for their key tiles -
-  // not a workgroup's prologue - to be the work. One box, graph replay, us per launch (8 waves | 4 waves | the 4-wave
-  // 128-row kernel below): 1 x 256 9.5 | 9.1 | 10.7, 1 x 512 12.2 | 13.1 | 16.4, 1 x 768 19.5 | 17.9 | 21.7, 1 x 1024 24.2 | 22.0 |
-  // 26.7, 1 x 1536 43.9 | 33.9 | 39.6, 2 x 1024 48.2 | 34.4 | 36.6, 4 x 128 tokens over 512 keys 14.1 | 17.5 | 19.0; but 3 x 512
-  // 30.5 | 22.4 | 21.4, 4 x 512 39.5 | 27.7 | 21.8, 4 x 256 18.7 | 13.0 | 12.2, 16 x 128 34.1 | 19.8 | 12.4, 8 x 512 75.9 | 48.6 | 37.8
+  // where the launch is about one workgroup per CU - the heaviest Q block's chain of key tiles IS the launch, and twice the
+  // waves on it halve it - or one sequence of up to ~1500 tokens. One box, graph replay, us per launch (8 waves | 4 waves |
+  // the 4-wave 128-row kernel below, which round 4 also taught to issue its LDS-DMA with one scalar base per tile and wave:
+  // 1 x 512 16.4 -> 14.4, 8 x 512 37.8 -> 33.5): 1 x 256 9.5 | 9.1 | 10.1, 1 x 512 12.2 | 13.1 | 14.4, 1 x 768 19.5 | 17.6 | 18.8,
+  // 1 x 1024 24.2 | 21.6 | 22.5, 1 x 1536 43.9 | 32.3 | 33.8, 4 x 128 tokens over 512 keys 14.1 | 17.5 | 19.0; but 2 x 512 20.3 | 17.0 | 15.4,
+  // 3 x 512 30.5 | 22.1 | 19.2, 2 x 1024 48.2 | 33.4 | 31.5, 4 x 512 39.5 | 27.7 | 20.4, 16 x 128 34.1 | 19.8 | 11.7, 8 x 512 75.9 | 48.6 | 33.5
   // (under load a workgroup's prologue - metadata, query rows - queues behind everyone's tile streams: many short Q blocks
   // want the wider ones). MI355_PREFILL=lat pins it wherever it applies.
   if (!ks && prefill_lat_applicable(p)) {
     const long wgs = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 64 + p.num_seqs) * p.num_kv_heads;   // its grid
     const bool pinned = variant && variant[0] == 'l';
-    const bool pick = wgs <= 288 || (p.max_seqlen_k >= 640 && p.max_seqlen_k < 2048 && wgs <= 1024) || (p.max_seqlen_k >= 384 && p.max_seqlen_k < 640 && wgs <= 576);
+    const bool pick = wgs <= 288 || (p.num_seqs == 1 && p.max_seqlen_k >= 640 && wgs <= 1024);
     if (pinned || (!variant && p.max_seqlen_k < 2048 && pick)) return launch_prefill_lat(p, stream);
   }
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
