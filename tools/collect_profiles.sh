@@ -1,27 +1,36 @@
 #!/bin/bash
-# Collect the round's measurement evidence on a GPU box into <out> (default gpurun_out/prof_r03); the summaries are then
+# Collect the round's measurement evidence on a GPU box into <out> (default gpurun_out/prof_r04); the summaries are then
 # copied by hand into profiles/<round>/. Counter passes are separate runs with --kernel-trace only (pool rule).
 #   bash tools/collect_profiles.sh [out]
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=${1:-$REPO/gpurun_out/prof_r03}
+OUT=${1:-$REPO/gpurun_out/prof_r04}
 mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)                  # (a relative path would be lost with the cd below)
 cd /tmp && export TMPDIR=/tmp
 echo "== HBM traffic (FETCH_SIZE / WRITE_SIZE passes)"
 python3 $REPO/tools/collect_traffic.py $OUT/traffic > $OUT/traffic.log 2>&1; tail -60 $OUT/traffic.log
-mkdir -p $REPO/profiles/r03 && cp $OUT/traffic/traffic.json $REPO/profiles/r03/traffic.json   # bench.py reports it when it matches the built sources
+mkdir -p $REPO/profiles/r04 && cp $OUT/traffic/traffic.json $REPO/profiles/r04/traffic.json   # bench.py reports it when it matches the built sources
 echo "== bench.py (default protocol)"
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench.py failed"
 tail -c 3000 $OUT/bench.json
 echo "== rocprofv3 --kernel-trace --stats of bench.py, one leg per run (a kernel symbol serves several legs)"
-for leg in prefill decode decode_fp8 mixed prefill_b8; do
+for leg in prefill decode decode_fp8 mixed prefill_b8 decode_b64 prefill_512; do
   rm -rf $OUT/stats_$leg && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$leg -- python3 $REPO/bench.py --no-cpu-baseline --legs $leg > $OUT/stats_bench_$leg.json 2> $OUT/stats_$leg.err
   f=$(find $OUT/stats_$leg -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats_$leg.csv; cut -c1-230 $OUT/bench_kernel_stats_$leg.csv; fi
   grep -o '"kernel_us": [0-9.]*' $OUT/stats_bench_$leg.json | head -2
   rm -rf $OUT/stats_$leg
 done
+echo "== short prompts (VERDICT r03 item 1): default dispatch, then the kernels pinned; graph column = GPU side"
+for s in "--seq 256" "--seq 512" "--seq 768" "--seq 1024" "--seq 1536" "--seq 512 --batch 2" "--seq 512 --batch 4" "--seq 512 --batch 8" "--seq 128 --batch 16" "--seq 640 --batch 4 --ctx 512"; do
+  python3 $REPO/tools/bench_prefill.py $s 2>&1 | grep -v amdgpu.ids | sed "s/^/default: /"
+  MI355_PREFILL=lat MI355_LAT_WAVES=8 python3 $REPO/tools/bench_prefill.py $s 2>&1 | grep -v amdgpu.ids | sed "s/^/lat8:    /"
+  MI355_PREFILL=lat MI355_LAT_WAVES=4 python3 $REPO/tools/bench_prefill.py $s 2>&1 | grep -v amdgpu.ids | sed "s/^/lat4:    /"
+  MI355_PREFILL=d4 python3 $REPO/tools/bench_prefill.py $s 2>&1 | grep -v amdgpu.ids | sed "s/^/dma4:    /"
+done > $OUT/short_prompts.log 2>&1; cut -c1-60,170- $OUT/short_prompts.log
+rm -rf $OUT/stats_sp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sp -- python3 $REPO/tools/bench_prefill.py --seq 512 > /dev/null 2>&1
+f=$(find $OUT/stats_sp -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats_short_1x512.csv; cut -c1-200 $OUT/bench_kernel_stats_short_1x512.csv; fi; rm -rf $OUT/stats_sp
 echo "== the 2D kernel's matrix: every prefill variant at 1 x 4096 / 16 x 4096, then kernel stats + MFMA busy of the variants on the 64-rows-per-wave kernel"
 bash $REPO/tools/sweeps/prefill_matrix.sh $OUT/prefill_matrix.log; cat $OUT/prefill_matrix.log
 for v in "f16:--dtype f16" "sw1024:--window 1024" "fp8:--kvdtype fp8" "sc30:--softcap 30" "f16_b16:--dtype f16 --batch 16" "sw1024_b16:--window 1024 --batch 16" "fp8_b16:--kvdtype fp8 --batch 16" "sc30_b16:--softcap 30 --batch 16"; do

@@ -199,6 +199,38 @@ __device__ __forceinline__ int find_seq_by_token(const int32_t* __restrict__ cu,
   return left - 1;
 }
 
+// The Q-block form of the search (largest i with cu[i] / block_q + i <= qblock, find_seq_idx :32-52) together with the
+// sequence's three words - query start, query length, key length - in ONE memory round trip for batches of up to 63
+// sequences: lane i takes cu_seqlens_q[i] and seqused_k[i], the search is a ballot (the left side is non-decreasing in i),
+// the words come out with v_readlane. The binary search is ceil(log2 S) + 1 DEPENDENT trips, each ~1-2 us on a loaded chip
+// and with nothing of the workgroup in flight meanwhile: at 8 sequences it was 5 us of a Q block's ~10 us prologue
+// (tools/wg_profile.py, 8 x 512). Returns the sequence or -1 (a surplus Q block); all results are wave-uniform.
+__device__ __forceinline__ int find_seq_and_lengths(const int32_t* __restrict__ cu, const int32_t* __restrict__ seqused, int num_seqs, int qblock,
+                                                    int block_q, int lane, int& q_start, int& q_len, int& seq_len) {
+  if (num_seqs <= 63) {
+    const int c = cu[min(lane, num_seqs)];                        // lanes 0 .. S hold cu[0 .. S]
+    const int k = seqused[min(lane, num_seqs - 1)];
+    const unsigned long long m = __ballot(lane < num_seqs && c / block_q + lane <= qblock);
+    const int seq = __builtin_popcountll(m) - 1;
+    if (seq < 0) { q_start = q_len = seq_len = 0; return -1; }
+    q_start = __builtin_amdgcn_readlane(c, seq);
+    q_len = __builtin_amdgcn_readlane(c, seq + 1) - q_start;
+    seq_len = __builtin_amdgcn_readlane(k, seq);
+    return seq;
+  }
+  int left = 0, right = num_seqs;
+  while (left < right) {
+    const int mid = (left + right) >> 1;
+    if (cu[mid] / block_q + mid <= qblock) left = mid + 1; else right = mid;
+  }
+  const int seq = left - 1;
+  if (seq < 0) { q_start = q_len = seq_len = 0; return -1; }
+  q_start = cu[seq];
+  q_len = cu[seq + 1] - q_start;
+  seq_len = seqused[seq];
+  return seq;
+}
+
 // Head sizes the MFMA kernels are built for; any other multiple of 8 (16 with an fp8 cache) up to 256 runs on the
 // next one with the missing columns never loaded (zero operands) and never stored - the reference pads to the
 // next power of two the same way (HEAD_SIZE_PADDED, triton_unified_attention.py:353,:912). 0 = not served.

@@ -19,7 +19,7 @@
 //     are used here), rows past the sequence redirected to its last row, one barrier per tile;
 //   * the two key halves of a row half meet once, after the loop, through LDS: each wave hands the partner the column
 //     group it does not finish and folds the partner's partial of the one it does, so all four waves normalise and store.
-// One sequence needs no cu_seqlens search (host-known: num_seqs == 1).
+// The sequence of a Q block and its lengths come in one memory round trip (a ballot over the batch's words, common.h).
 // Served: bf16 / f16, head size 128, 16-bit flash-layout cache, causal or not, no window / soft-cap / ALiBi; the host
 // (launch_prefill, prefill_mfma.hip) picks it where the key range is short and the wider kernels' grids underfill the chip.
 #include <cstdlib>
@@ -65,16 +65,6 @@ template <> struct lmma<f16_t> {
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
 };
-
-// largest i with cu[i] / block_q + i <= qblock (reference: find_seq_idx in Q-block mode, :32-52)
-__device__ __forceinline__ int lat_find_seq(const int32_t* __restrict__ cu, int num_seqs, int qblock, int block_q) {
-  int left = 0, right = num_seqs;
-  while (left < right) {
-    const int mid = (left + right) >> 1;
-    if (cu[mid] / block_q + mid <= qblock) left = mid + 1; else right = mid;
-  }
-  return left - 1;
-}
 
 // v_max3_f32 as it stands (fmaxf chains come out as canonicalising v_max pairs: 16 instructions more per tile, and this
 // kernel's tile is what one wave per SIMD can issue)
@@ -139,7 +129,9 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
 
   const int head = (int)(blockIdx.x % p.num_kv_heads);
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);    // heaviest (latest) Q blocks first
-  const int seq = p.num_seqs == 1 ? 0 : lat_find_seq(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
+  // the sequence and its three words in ONE round trip (a ballot over up to 63 sequences' words, common.h)
+  int q_start, q_len, seq_len;
+  const int seq = find_seq_and_lengths(p.cu_seqlens_q, p.seqused_k, p.num_seqs, qblock, BQ, lane, q_start, q_len, seq_len);
   if (seq < 0) return;
   // block-table entries 64 at a time in a VGPR (lane l = entry chunk * 64 + l), picked with v_readlane: requested as
   // soon as the sequence is known, bounded by max_seqlen_k's page count
@@ -148,10 +140,7 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
   int bt_chunk = 0;
   int bt_cur = bt[min(lane, bt_last_any)];
   int bt_nxt = bt[min(64 + lane, bt_last_any)];
-  const int q_start = p.cu_seqlens_q[seq];
-  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
   const int qb_local = qblock - (q_start / BQ + seq);
-  const int seq_len = p.seqused_k[seq];
   if (qb_local < 0 || qb_local * BQ >= q_len || q_len <= p.skip_decodes || (p.only_decodes && q_len > p.only_decodes)) return;
   const int ctx_len = p.non_causal ? seq_len : seq_len - q_len;     // non-causal: every row sees the whole sequence
   const int tok0 = qb_local * BQ;

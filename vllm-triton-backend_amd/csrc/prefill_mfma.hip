@@ -708,12 +708,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
 
   const int head = (int)(blockIdx.x % p.num_kv_heads);
   const int qblock = (int)(gridDim.x / p.num_kv_heads - 1 - blockIdx.x / p.num_kv_heads);
-  const int seq = find_seq_by_qblock(p.cu_seqlens_q, p.num_seqs, qblock, BQ);
+  int q_start, q_len, seq_len;
+  const int seq = find_seq_and_lengths(p.cu_seqlens_q, p.seqused_k, p.num_seqs, qblock, BQ, lane, q_start, q_len, seq_len);
   if (seq < 0) return;
   // Prologue order (every step is a memory round trip of ~1-2 us that nothing else on this CU hides when
-  // the workgroup owns it): sequence index -> {block table, sequence lengths} together -> {first K/V
-  // tiles, Q rows} together. The block table is fetched as soon as the sequence is known, bounded by
-  // max_seqlen_k's page count instead of this Q block's own last page (not known yet).
+  // the workgroup owns it): {sequence index, its lengths} in one trip (round 4: a ballot over the first 63 sequences' words
+  // instead of a binary search's dependent loads) -> block table -> {first K/V tiles, Q rows} together. The block table is
+  // bounded by max_seqlen_k's page count instead of this Q block's own last page.
   const int32_t* bt = p.block_table + (int64_t)seq * p.block_table_stride;
   const int bt_last_any = ((max(p.max_seqlen_k, 1) + p.page_size - 1) >> a.page_shift) - 1;
   constexpr bool BT_IN_LDS = NST >= 3;
@@ -725,10 +726,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
     bt_cur = bt[min(lane, bt_last_any)];
     bt_nxt = bt[min(64 + lane, bt_last_any)];
   }
-  const int q_start = p.cu_seqlens_q[seq];
-  const int q_len = p.cu_seqlens_q[seq + 1] - q_start;
   const int qb_local = qblock - (q_start / BQ + seq);
-  const int seq_len = p.seqused_k[seq];
   if (qb_local * BQ >= q_len || q_len <= p.skip_decodes || (p.only_decodes && q_len > p.only_decodes)) {
     if constexpr (BT_IN_LDS) glds_wait_all();   // never leave with a DMA into this workgroup's LDS in flight
     return;
