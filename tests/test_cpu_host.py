@@ -184,6 +184,38 @@ def test_self_attention_scratch_is_sized_by_the_tokens_not_by_the_longest_sequen
     assert n < (1 << 30)                                                                   # (padded: 256 x 512 pages x 64 KiB = 8.6 GB)
 
 
+def test_measurement_switches_need_the_lab_gate(lib):
+    """The library's environment switches exist for measurements: a process reads them only when it
+    also carries MI355_LAB=1. Probe: MI355_PREFILL_KEY_SPLITS=4 turns a one-pass prefill into a key-split one (a workspace
+    with partial buffers) - with the gate, and not without it."""
+    code = (
+        "import ctypes as C, sys, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from mi355_attn import _lib\n"
+        "h = _lib.load()\n"
+        "buf = np.zeros(64, dtype=np.uint8); addr = (buf.ctypes.data + 15) & ~15\n"
+        "p = _lib.AttnParams()\n"
+        "for f in ('q', 'out', 'k_cache', 'v_cache', 'block_table', 'cu_seqlens_q', 'seqused_k'): setattr(p, f, addr)\n"
+        "p.q_dtype = p.kv_dtype = _lib.BF16\n"
+        "p.num_q_heads, p.num_kv_heads, p.head_size, p.page_size = 32, 8, 128, 16\n"
+        "p.q_stride_token, p.q_stride_head, p.out_stride_token, p.out_stride_head = 4096, 128, 4096, 128\n"
+        "p.k_stride_page, p.k_stride_slot, p.k_stride_head, p.k_stride_d, p.k_x = 16384, 1024, 128, 1, 128\n"
+        "p.v_stride_page, p.v_stride_slot, p.v_stride_head, p.v_stride_d = 16384, 1024, 128, 1\n"
+        "p.block_table_stride = 2048\n"
+        "p.num_tokens, p.num_seqs, p.max_seqlen_q, p.max_seqlen_k = 16 * 4096, 16, 4096, 4096\n"
+        "print(h.mi355_attn_workspace_bytes(C.byref(p)))\n"
+    ) % (ROOT, os.path.join(ROOT, "vllm-triton-backend_amd"))
+
+    def ws(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("MI355_")}
+        e.update(env)
+        return int(subprocess.check_output([sys.executable, "-c", code], env=e, text=True).strip().splitlines()[-1])
+
+    plain = ws()
+    assert ws(MI355_PREFILL_KEY_SPLITS="4") == plain                       # ignored: no gate
+    assert ws(MI355_PREFILL_KEY_SPLITS="4", MI355_LAB="1") > plain + (16 * 4096 * 32 * 128 * 2)    # four partial outputs
+
+
 def test_one_version_number(lib):
     """include/mi355_attn.h is the version source: the library, the Python package and setup.py report it."""
     import mi355_attn

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MI355_LAB=1      # the library reads its measurement switches (MI355_PREFILL, ...) only with this set
 # Same-box A/B of decode libraries: tools/ab_decode.sh <rounds> <lib> [<lib> ...]  (C3 shape: bf16 no flush / read flush, fp8, batch 16)
 rounds=$1; shift
 for i in $(seq $rounds); do

@@ -4,6 +4,8 @@ one phase compiled out each (-DMI355_ABLATE_*; outputs are wrong, only the time 
 of the product build) and times them against the full kernel in one process, interleaved rounds."""
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import subprocess
 import sys
 
@@ -33,7 +35,7 @@ def main():
     procs = []
     for n in names:
         so = os.path.join(out_dir, f"lib_{n}.so")
-        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *VARIANTS[n], "-o", so, *srcs]))
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-DMI355_LAB", "-shared", *VARIANTS[n], "-o", so, *srcs]))
     for pr in procs:
         assert pr.wait() == 0
     dev = torch.device("cuda:0")

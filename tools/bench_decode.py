@@ -4,6 +4,8 @@ Usage: python tools/bench_decode.py [--batch 64] [--kv 8192] [--hq 32] [--hk 8] 
 import argparse
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -6,6 +6,8 @@ partial_prefill_share 0.5, ALTERNATING) -> 32 decodes (ctx 4095), 16 partial pre
 under batch sharding (mi355_attn.parallel.assign_sequences)."""
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

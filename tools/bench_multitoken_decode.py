@@ -6,6 +6,8 @@ the tool runs each setting in a child process of its own (--pack).
   python tools/bench_multitoken_decode.py [--hq 32 --hk 8]"""
 import argparse
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 
 import torch

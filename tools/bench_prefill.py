@@ -3,6 +3,8 @@
 import argparse
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,6 +3,8 @@
     python tools/clock_watch.py prefill|decode [seconds]"""
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import subprocess
 import sys
 import threading

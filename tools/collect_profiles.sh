@@ -1,4 +1,5 @@
 #!/bin/bash
+export MI355_LAB=1      # the library reads its measurement switches (MI355_PREFILL, ...) only with this set
 # Collect the round's measurement evidence on a GPU box into <out> (default gpurun_out/prof_r04); the summaries are then
 # copied by hand into profiles/<round>/. Counter passes are separate runs with --kernel-trace only (pool rule).
 #   bash tools/collect_profiles.sh [out]

@@ -9,6 +9,8 @@ import csv
 import glob
 import json
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import subprocess
 import sys
 

@@ -4,6 +4,8 @@ issued back-to-back on a stream and replayed from a HIP graph of 50 calls (GPU-s
 import argparse
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

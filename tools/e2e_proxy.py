@@ -20,6 +20,8 @@ a one-element kernel replayed the same way). The rest of a vLLM step (GEMMs, nor
 import argparse
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 import time
 import types

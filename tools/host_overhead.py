@@ -3,6 +3,8 @@
 wall time per call over a back-to-back loop of tiny launches, next to the GPU time of the same launches."""
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 import time
 

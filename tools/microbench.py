@@ -21,6 +21,8 @@ import argparse
 import itertools
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import random
 import sys
 import time

@@ -6,6 +6,8 @@ give-back item 6). Needs a library built with -DMI355_PW_STAMP (tools/build_vari
 import ctypes as C
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import sys
 import time
 

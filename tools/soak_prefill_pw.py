@@ -3,6 +3,8 @@
 Not a test of the suite (minutes on the GPU): python tools/soak_prefill_pw.py [first_seed] [count]"""
 import math
 import os
+
+os.environ.setdefault("MI355_LAB", "1")      # tools may pin kernels through the library's measurement switches
 import random
 import sys
 

@@ -1,3 +1,4 @@
+export MI355_LAB=1      # the library reads its measurement switches (MI355_PREFILL, ...) only with this set
 # Prefetch depth 2 for the bf16 decode kernel (needs tools/ab/lib_pf2.so from tools/build_variant_decode.sh lib_pf2 -DMI355_DECODE_PF=2)
 for lib in tools/ab/lib_base.so tools/ab/lib_pf2.so; do
  for t in 512 1024 2048; do

@@ -1,3 +1,4 @@
+export MI355_LAB=1      # the library reads its measurement switches (MI355_PREFILL, ...) only with this set
 # MI355_DECODE_TARGET_WAVES sweep behind the split plan of decode_splitkv.hip: bash tools/sweeps/decode_target_waves.sh
 for shape in "--batch 1 --kv 8192" "--batch 4 --kv 8192" "--batch 16 --kv 2048" "--batch 16 --kv 8192" "--batch 64 --kv 2048" "--batch 64 --kv 8192" "--batch 128 --kv 8192" "--batch 256 --kv 4096" "--batch 4 --kv 32768" "--batch 16 --kv 32768 --hq 64 --kvdtype fp8" "--batch 64 --kv 8192 --kvdtype fp8"; do
   line="$shape:"

@@ -1,3 +1,4 @@
+export MI355_LAB=1      # the library reads its measurement switches (MI355_PREFILL, ...) only with this set
 # A/B on one box, interleaved: prefill_pw_kernel on 32x32x16 (product) vs its 16x16x32 instantiation (MI355_PW_M16=1)
 N=${1:-3}
 for shape in "1 4096" "4 2048" "1 16384" "16 4096"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MI355_LAB=1      # the library reads its measurement switches (MI355_PREFILL, ...) only with this set
 # The 2D kernel's matrix: sustained TFLOP/s of every prefill variant at 1 x 4096 and 16 x 4096
 # (Hq 32 / Hk 8, 16-token pages), kernel names from mi355_last_kernel().   bash tools/sweeps/prefill_matrix.sh [out.log]
 cd "$(dirname "$0")/../.."

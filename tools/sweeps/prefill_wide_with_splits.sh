@@ -1,3 +1,4 @@
+export MI355_LAB=1      # the library reads its measurement switches (MI355_PREFILL, ...) only with this set
 # 8-wave (256-row) kernel under a key split vs the 4-wave one: bash tools/sweeps/prefill_wide_with_splits.sh
 for a in "--seq 32768 --ctx 30720" "--seq 32768 --ctx 31744" "--seq 8192 --ctx 7168" "--seq 8192 --ctx 7680"; do
   for cfg in "d4 0" "d8 2" "d8 4" "d8 8"; do

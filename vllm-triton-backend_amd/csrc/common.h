@@ -7,7 +7,27 @@
 
 #include "../../include/mi355_attn.h"
 
+// ONE switch for everything that exists for measurements only (round 4, VERDICT r03 hygiene):
+//   * compile time - the ablation / stamp / profile builds (-DMI355_PROFILE_WG, -DMI355_PW_STAMP, -DPW_ABL_*, -DMI355_ABLATE_*,
+//     -DMI355_DECODE_PF=.., ...) need -DMI355_LAB beside them (tools/build_variant.sh and the profile tools pass it): a
+//     product build that carries one of them by accident does not compile;
+//   * run time - the environment switches of DESIGN.md section 5 (MI355_PREFILL, MI355_DECODE_TREE, MI355_PW_SLOTS, ...) are
+//     read through lab_env(), which sees them only when MI355_LAB=1 is set as well: a production process has no hidden knobs.
+#if !defined(MI355_LAB) && (defined(MI355_PROFILE_WG) || defined(MI355_PROFILE_PHASES) || defined(MI355_PW_STAMP) || defined(MI355_PW_SEAM) || \
+                            defined(PW_ABL_DMA) || defined(PW_FORCE_FALLBACK) || defined(PW_DMA_SPREAD) || defined(MI355_ABLATE_QK) || defined(MI355_ABLATE_DMA) || \
+                            defined(MI355_ABLATE_SOFTMAX) || defined(MI355_ABLATE_PV) || defined(MI355_ABLATE_BARRIER) || defined(MI355_PACKED_ROWSUM) || \
+                            defined(MI355_DECODE_PF) || defined(MI355_DECODE_PLAIN_LOADS))
+#error "diagnostic / ablation macros are lab builds: add -DMI355_LAB"
+#endif
+#include <cstdlib>
+
 namespace mi355 {
+
+// getenv for the measurement switches: nullptr unless the process also carries MI355_LAB=1 (read once).
+inline const char* lab_env(const char* name) {
+  static const bool lab = [] { const char* e = std::getenv("MI355_LAB"); return e && e[0] && e[0] != '0'; }();
+  return lab ? std::getenv(name) : nullptr;
+}
 
 // ---------------------------------------------------------------------------------------------
 // element-type tags. Storage is raw bits; arithmetic is always fp32.

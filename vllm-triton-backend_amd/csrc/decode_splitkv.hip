@@ -1081,7 +1081,7 @@ int decode_pack_groups(const mi355_attn_params& p) {
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;   // (one column group only)
   if (!layout_is_flash(p) || p.head_size != padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype))) return 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  static const char* const e = getenv("MI355_DECODE_PACK");     // read once per process, like the other switches
+  static const char* const e = lab_env("MI355_DECODE_PACK");     // read once per process, like the other switches
   if (e && e[0] == '0') return 0;
   const bool one_ok = G <= 8, two_ok = G <= 16 && p.head_size <= 128 && !feat && !(e && e[0] == '1');
   if (one_ok && (pack_max_q(p) <= (1 << pow2_floor_shift(16 / G)) || !two_ok)) return 1;
@@ -1149,7 +1149,7 @@ static SplitPlan plan_splits(const mi355_attn_params& p) {
     // batch 4 at 32768 keys: 92 vs 94). The fp8 kernel spends its time widening, not waiting: it wants 8 per CU
     // (batch 64: 204 us vs 261 with half of them; 16 x 32768 keys, Hq 64: 211 vs 474).
     // MI355_DECODE_TARGET_WAVES overrides the number for sweeps (tools/bench_decode.py).
-    static const long target_env = [] { const char* e = getenv("MI355_DECODE_TARGET_WAVES"); return e ? atol(e) : 0L; }();
+    static const long target_env = [] { const char* e = lab_env("MI355_DECODE_TARGET_WAVES"); return e ? atol(e) : 0L; }();
     const bool fp8_kv = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
     const long target = target_env > 0 ? target_env : 256L * (fp8_kv ? 8 : 4);
     want = (int)((target + base - 1) / base);
@@ -1184,7 +1184,7 @@ static MergePlan plan_merge(const mi355_attn_params& p) {
   const SplitPlan sp = plan_splits(p);
   MergePlan m = {sp.num_splits, sp.tiles_per_split, sp.num_splits, false, false};
   if (sp.num_splits <= 1) return m;
-  static const bool two_launch = getenv("MI355_DECODE_MERGE_KERNEL") != nullptr;   // A/B switch: separate merge launch
+  static const bool two_launch = lab_env("MI355_DECODE_MERGE_KERNEL") != nullptr;   // A/B switch: separate merge launch
   if (two_launch || !counters_fit(p)) return m;
   const int pack = decode_pack_groups(p), ps = decode_pack_shift(p);
   const int D = padded_head_size(p.head_size, is_fp8_dtype(p.kv_dtype));
@@ -1201,7 +1201,7 @@ static MergePlan plan_merge(const mi355_attn_params& p) {
   // keys, 15.4 -> 15.05 at 13 300; batch 1 at 32768 keys 28.6 -> 27.7). With few splits the merge launch is the cheaper
   // one (batch 1 at 512 keys, 16 splits: 7.4 us against 8.4), and a batch that fills the chip loses its streaming order to
   // the four-splits-per-workgroup deal (C5, 16 splits: 173 -> 205 us). MI355_DECODE_TREE=0 | 1 forces either (A/B).
-  static const char* const tree_env = getenv("MI355_DECODE_TREE");
+  static const char* const tree_env = lab_env("MI355_DECODE_TREE");
   const long base = std::max(1L, decode_units(p) * p.num_kv_heads * query_head_groups(p));
   const bool want_tree = tree_env ? tree_env[0] == '1' : (sp.num_splits > 32 && base <= 32);
   if (pack == 0 && want_tree) {

@@ -495,7 +495,7 @@ int launch_prefill_lat(const mi355_attn_params& p, hipStream_t stream) {
   if (!prefill_lat_applicable(p)) { set_error("prefill_lat_kernel does not serve this configuration"); return MI355_ERR_UNSUPPORTED; }
   // eight waves per Q block while the launch is at most ~one workgroup per CU (the heaviest Q block is the launch), four
   // (two workgroups per CU) beyond. MI355_LAT_WAVES=4 | 8 pins one (measurements).
-  static const int pin = [] { const char* e = getenv("MI355_LAT_WAVES"); return e ? atoi(e) : 0; }();
+  static const int pin = [] { const char* e = lab_env("MI355_LAT_WAVES"); return e ? atoi(e) : 0; }();
   const long wgs = ((long)p.num_tokens / (kLatRows / (p.num_q_heads / p.num_kv_heads)) + p.num_seqs) * p.num_kv_heads;
   const bool eight = pin ? pin == 8 : wgs <= 288;
   if (eight) return p.q_dtype == MI355_BF16 ? launch_lat_t<bf16_t, 4>(p, stream) : launch_lat_t<f16_t, 4>(p, stream);

@@ -1303,7 +1303,7 @@ static size_t prefill_bt_lds_bytes(const mi355_attn_params& p) {
 struct KeySplitPlan { int splits, tiles_per_split; bool wide; };   // wide: on the 8-wave / 256-row LDS-DMA kernel
 
 static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
-  static const char* env_s = getenv("MI355_PREFILL_KEY_SPLITS");   // measurements: force a split count (1 = never split)
+  static const char* env_s = lab_env("MI355_PREFILL_KEY_SPLITS");   // measurements: force a split count (1 = never split)
   // ... or the caller's num_segments (include/mi355_attn.h): 1 = one pass over the whole key range per Q block
   char forced_buf[16];
   const char* env = env_s;
@@ -1517,7 +1517,7 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, co
 // Whether launch_prefill hands the call to prefill_pw_kernel (prefill_pw.hip): bf16 or f16, D = 128, no soft-cap / ALiBi
 // (a sliding window is served), 16-bit cache, and either >= 2048 keys or a key-split plan on the wide kernel. MI355_PREFILL=pw | d8 | d4 | v1 pins a kernel (measurements).
 bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
-  static const char* variant = getenv("MI355_PREFILL");
+  static const char* variant = lab_env("MI355_PREFILL");
   const bool v1 = variant && variant[0] == 'v' && variant[1] == '1';
   if (!prefill_supported(p) || !prefill_pw_applicable(p) || v1 || (variant && variant[0] != 'p')) return false;
   const bool pinned = variant && variant[0] == 'p';
@@ -1540,7 +1540,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
   const bool bf = p.q_dtype == MI355_BF16;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   // A/B switches for measurements: MI355_PREFILL=v1 (register-staged), pw / d8 / d4 pin one of the three LDS-DMA kernels
-  static const char* variant = getenv("MI355_PREFILL");
+  static const char* variant = lab_env("MI355_PREFILL");
   const bool v1 = variant && variant[0] == 'v' && variant[1] == '1';
   // prefill_pw_kernel (prefill_pw.hip: four waves of 64 rows, one per SIMD; bf16) wherever the 8-wave kernel was the
   // choice, and instead of the 4-wave kernel from 2048 keys on (sustained TFLOP/s, Hq 32 / Hk 8, pw | 8-wave | 4-wave:

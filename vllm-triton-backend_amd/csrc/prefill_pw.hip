@@ -1871,7 +1871,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
       cu_count[dev].store(c, std::memory_order_relaxed);
     if (c > 0) cus = c;
   }
-  static const int slots_env = [] { const char* e = getenv("MI355_PW_SLOTS"); return e ? atoi(e) : 0; }();   // measurements only
+  static const int slots_env = [] { const char* e = lab_env("MI355_PW_SLOTS"); return e ? atoi(e) : 0; }();   // measurements only
   const int items_per_head = a.num_qblocks * key_splits;
   // About one workgroup per CU, each walking several items. ONE sequence: the static boustrophedon deal - balanced by
   // construction for causal weights that fall linearly along the list, and better than any greedy deal (1 x 4096: 112.5 us;
@@ -1879,7 +1879,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // make the weights a sawtooth, and a static deal loses more than the seams gain (4 x 2048: 143.5 us): there the items
   // are dealt by ticket counters in the zero-filled head of the caller's workspace (2 x 4096: 224.8 us vs 231.6 with one
   // item per workgroup, 16 x 4096 1835 vs 1863, 8 x 2048 262.9 vs 268.7), and without a workspace one item per workgroup.
-  static const bool tickets_off = [] { const char* e = getenv("MI355_PW_TICKETS"); return e && e[0] == '0'; }();   // measurements only
+  static const bool tickets_off = [] { const char* e = lab_env("MI355_PW_TICKETS"); return e && e[0] == '0'; }();   // measurements only
   a.tickets = (counters && !tickets_off && p.num_seqs > 1 && 2 * p.num_kv_heads * sizeof(int) <= kPwCounterBytes) ? counters : nullptr;
   const int per_cu = std::max(1, cus / p.num_kv_heads);
   a.slots = std::max(1, std::min(items_per_head, slots_env > 0 ? slots_env : ((a.tickets || p.num_seqs == 1) ? per_cu : items_per_head)));
@@ -1888,7 +1888,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   // ~2.2-2.3 GHz under it instead of ~2.0-2.1 - at the price of twice as many matrix instructions to issue; with its
   // exponentials dealt one per gap it is ahead on every shape this kernel is chosen for (same box: 1 x 4096 +6.9 %,
   // 1 x 16384 +8.8 %, 16 x 4096 +5 %, 4 x 2048 +3.2 %). MI355_PW_M16=0 pins the 32x32x16 instantiation (A/B, tests).
-  static const bool m16_env = [] { const char* e = getenv("MI355_PW_M16"); return !(e && e[0] == '0'); }();
+  static const bool m16_env = [] { const char* e = lab_env("MI355_PW_M16"); return !(e && e[0] == '0'); }();
   const bool sw = p.sliding_window > 0, sc = p.softcap > 0.0f, al = p.alibi_slopes != nullptr;
   const bool d64 = p.head_size == 64, d96 = p.head_size == 96, d80 = p.head_size == 80;
   const bool m16 = m16_env || sw || sc || al || d64 || d96 || d80 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi

@@ -307,7 +307,7 @@ mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, siz
 // moves 3 bytes per cache element once, the attention does 2 q G flops per element: worth it when the sequences bring
 // many query rows (avg query_len * G >= 4096: the pass is then <= 15 % of the attention's time).
 static bool fp8_prefill_through_scratch(const mi355_attn_params& p) {
-  static const bool off = [] { const char* e = getenv("MI355_FP8_PREFILL_SCRATCH"); return e && e[0] == '0'; }();   // A/B
+  static const bool off = [] { const char* e = lab_env("MI355_FP8_PREFILL_SCRATCH"); return e && e[0] == '0'; }();   // A/B
   if (off || !is_fp8(p.kv_dtype) || p.k_new || p.max_seqlen_q <= 1 || p.max_seqlen_k < 2048) return false;
   // (soft-cap, and ALiBi by itself: the 64-rows-per-wave kernel's SC / AL instantiations serve them)
   if (p.alibi_slopes && (p.softcap > 0.0f || p.sliding_window > 0)) return false;
