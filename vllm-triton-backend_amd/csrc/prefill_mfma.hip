@@ -821,15 +821,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
   // offsets and the base as an SGPR pair. The former deal - every wave a quarter of every 16-row piece - cost each wave
   // four page look-ups and 64-bit address sums per tile, ~250 instructions where this costs ~50, and one wave per SIMD
   // pays ~4 cycles for each (prefill_lat.hip: the same change took that kernel from 15.9 to 13.1 us at 1 x 512).
-  constexpr bool WAVE_GROUP = NW == 4 && D == 128;
+  constexpr bool WAVE_GROUP = D == 128;          // (NW == 8: two waves share a 16-key group, eight rows each, two instructions per matrix)
+  constexpr int RPWV = kTileN / NW;              // key rows of a tile one wave stages (16 or 8)
   uint64_t wg_kb = 0, wg_vb = 0;              // this wave's group of the tile being staged: scalar bases
   bool wg_tail = false;
   int wg_key0 = 0;
   uint32_t wgk_voff[4], wgv_voff[4];
   if constexpr (WAVE_GROUP) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = 4 * j + (lane >> 4), c = lane & 15;
+    for (int j = 0; j < RPWV / 4; ++j) {
+      const int r = ((wave * RPWV) & 15) + 4 * j + (lane >> 4), c = lane & 15;       // row within the 16-key group
       wgk_voff[j] = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((c ^ fk_of(r)) << 4));
       wgv_voff[j] = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((c ^ fv_of(r)) << 4));
     }
@@ -844,10 +845,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
       }
     }
     if constexpr (WAVE_GROUP) {
-      const int gi = min(tile * 4 + wave, last_group);
+      const int gi = min(tile * 4 + ((wave * RPWV) >> 4), last_group);
       wg_key0 = gi << 4;
       const int slot0 = wg_key0 & page_mask;
-      const uint32_t page = (uint32_t)__builtin_amdgcn_readlane(bt_cur, (wg_key0 >> a.page_shift) & 63);
+      uint32_t page;
+      if constexpr (BT_IN_LDS) page = (uint32_t)__builtin_amdgcn_readfirstlane(bt_lds[wg_key0 >> a.page_shift]);
+      else page = (uint32_t)__builtin_amdgcn_readlane(bt_cur, (wg_key0 >> a.page_shift) & 63);
       const uint64_t k_off = (uint64_t)page * (a.k_page_stride * 2) + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2;
       const uint64_t v_off = a.kv_same_strides ? k_off : (uint64_t)page * (a.v_page_stride * 2) + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2;
       wg_kb = (uint64_t)kbase + k_off;
@@ -857,14 +860,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
   };
   // piece i of a tile = key rows RP*i .. RP*i+RP-1: one K and one V LDS-DMA per lane (1 KiB each per wave)
   auto dma_piece = [&](int tile, char* stage, int i) {
-    if constexpr (WAVE_GROUP) {             // "piece" i = instruction i of this wave's group: rows 16 wave + 4 i .. + 3
+    if constexpr (WAVE_GROUP) {             // "piece" i = instruction i of this wave's rows: RPWV wave + 4 i .. + 3 of the tile
       uint32_t kvo = wgk_voff[i], vvo = wgv_voff[i];
       if (wg_tail) {
-        const int rig = 4 * i + (lane >> 4), c = lane & 15, r = min(rig, max(seq_len - 1 - wg_key0, 0));
+        const int rig = ((wave * RPWV) & 15) + 4 * i + (lane >> 4), c = lane & 15, r = min(rig, max(seq_len - 1 - wg_key0, 0));
         kvo = (uint32_t)(r * (int)a.k_slot_stride * 2 + ((c ^ fk_of(rig)) << 4));
         vvo = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((c ^ fv_of(rig)) << 4));
       }
-      const uint32_t dst = lds_addr(stage) + (uint32_t)(wave * (16 * ROWB) + i * 1024);
+      const uint32_t dst = lds_addr(stage) + (uint32_t)(wave * (RPWV * ROWB) + i * 1024);
       glds16_s(kvo, wg_kb, dst);
       glds16_s(vvo, wg_vb, dst + KBUF);
       return;
@@ -1527,7 +1530,11 @@ bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
   // 1 x 1536 58 / 40 against 86)
   // (head sizes 96 / 64: the alternative is the register-staged kernel too - 1 x 1024 24 against 30 us, 4 x 1024 45 against 60
   // at 96; 1 x 1536 28 against 31 at 64)
-  const int min_keys = (p.softcap > 0.0f || p.alibi_slopes) ? 512 : (p.head_size == 96 || p.head_size == 80) ? 1024 : p.head_size == 64 ? 1536 : 2048;
+  // (round 4, plain D = 128 with several sequences: from 1536 keys on, from 1024 with sixteen sequences or more - graph replay,
+  // us, this kernel | the 8-wave | the 4-wave LDS-DMA kernel after their round-4 change: 4 x 1536 87.4 | 92.9 | 93.4, 16 x 1024 170.6 |
+  // 180.6 | 178.2, 8 x 1024 92.8 | 94.8 | 93.9; but 8 x 512 42.7 | 36.5 | 34.0, 32 x 512 137.0 | 121.6 | 116.8)
+  const int plain_min = p.num_seqs >= 16 ? 1024 : p.num_seqs >= 2 ? 1536 : 2048;
+  const int min_keys = (p.softcap > 0.0f || p.alibi_slopes) ? 512 : (p.head_size == 96 || p.head_size == 80) ? 1024 : p.head_size == 64 ? 1536 : plain_min;
   const bool use_pw = ks ? ks->wide : p.max_seqlen_k >= min_keys;
   return pinned ? (!ks || ks->wide) : use_pw;
 }
