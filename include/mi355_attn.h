@@ -26,9 +26,16 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 500 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 501 /* major*10000 + minor*100 + patch */
 /*
  * Version notes (what a caller written against an older header must know)
+ *   0.5.1  No change to the structs or the entry points. The workspace's zero-filled 256 KiB head is now two regions:
+ *          [0, 192 KiB) the counters of 0.3.1, [192 KiB, 256 KiB) one byte per (128-row Q block, KV head) of an f16
+ *          prefill call - rows whose scores left the fast kernel's range are flagged there and computed again by a
+ *          second launch of the same call, which clears them (zero on entry, zero on exit, like the counters). New
+ *          kernels behind the same call: a short-prompt prefill kernel, a two-level in-kernel merge for decode steps
+ *          planned with many splits (one launch where a graph captured at max_model_len took two). The measurement
+ *          switches (environment variables) are read only in a process that also sets MI355_LAB=1.
  *   0.5.0  Multi-token decode steps (speculative decoding / MTP verification) on the split-KV decode kernel, several
  *          query tokens of a sequence per wave. skip_decodes / only_decodes became query-length thresholds (1 keeps
  *          its meaning); reserved2 became decode_rows_hint (0 = as before).
@@ -246,8 +253,8 @@ MI355_API const char* mi355_last_kernel(void);
  * Replaces the three per-call torch.empty scratch tensors at triton_unified_attention.py:950-971
  * (decode partials; here also the partials of a key-split prefill and the scratch cache of the repack path).
  * The workspace must be ZERO-FILLED ONCE by its owner after allocation: its first 256 KiB hold the
- * arrival counters of the in-kernel split merge and the work-item ticket counters of the bf16 prefill
- * kernel, which every call leaves at zero again (a call that was aborted mid-kernel does not: zero-fill
+ * arrival counters of the in-kernel split merge, the work-item ticket counters of the bf16 / f16 prefill
+ * kernel and (last 64 KiB) the fix-up flags of an f16 prefill call, all of which every call leaves at zero again (a call that was aborted mid-kernel does not: zero-fill
  * again after a device error). One workspace serves one stream at a time. A prefill call whose answer is
  * exactly those 256 KiB also runs WITHOUT a workspace (NULL, 0): its work items are then dealt statically.
  */
