@@ -26,9 +26,11 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 501 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 600 /* major*10000 + minor*100 + patch */
 /*
  * Version notes (what a caller written against an older header must know)
+ *   0.6.0  write_new_kv is accepted for prefill steps too (see the field): mi355_decode_write_fusable() answers 1 for
+ *          them where the short-prompt prefill kernel serves the call in one launch. Nothing else changes.
  *   0.5.1  No change to the structs or the entry points. The workspace's zero-filled 256 KiB head is now two regions:
  *          [0, 192 KiB) the counters of 0.3.1, [192 KiB, 256 KiB) one byte per (128-row Q block, KV head) of an f16
  *          prefill call - rows whose scores left the fast kernel's range are flagged there and computed again by a
@@ -181,7 +183,12 @@ typedef struct mi355_attn_params {
    * that position - saturating fp8(x / scale) for an fp8 cache, exactly what mi355_reshape_and_cache_flash stores - and
    * attends over it, whatever the cache held there before. Requires max_seqlen_q == 1, num_tokens == num_seqs, the flash
    * layout and the matrix-core decode kernel (mi355_decode_write_fusable() answers for a parameter block); the caches
-   * are written although the struct declares them const. */
+   * are written although the struct declares them const.
+   * Library version >= 0.6.0: also a PREFILL step the short-prompt kernel serves in one launch (max_seqlen_q > 1; one
+   * sequence, or sequences that all carry max_seqlen_q tokens; 16-bit cache of the query's type; mi355_decode_write_fusable()
+   * answers). k_new / v_new [num_tokens, Hk, D] then hold the key / value of EVERY query token (token t of sequence i =
+   * position seqused_k[i] - query_len_i + t): the launch attends over them straight from these tensors and stores them into
+   * their pages - by slot_mapping when one is handed in (negative: not stored), else by position through the block table. */
   int32_t write_new_kv;
   /* 0 (every op of the reference's backend path): causal - query t of a sequence sees keys j <= t + seqused_k - query_len.
    * 1: every query row sees ALL seqused_k keys of its sequence (prefill_flash_attention(causal=False),
@@ -313,7 +320,8 @@ MI355_API int mi355_paged_attention_v0(const mi355_attn_params* p, void* workspa
                                        mi355_stream_t stream);
 
 /* 1 if mi355_unified_attention serves these parameters with write_new_kv = 1 (host arithmetic only), else 0: the caller
- * then issues mi355_reshape_and_cache_flash followed by the plain call. */
+ * then issues mi355_reshape_and_cache_flash followed by the plain call. (The name is 0.3.0's; since 0.6.0 it answers for
+ * prefill steps as well.) */
 MI355_API int mi355_decode_write_fusable(const mi355_attn_params* p);
 
 /*

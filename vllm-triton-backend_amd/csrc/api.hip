@@ -64,11 +64,15 @@ static int validate(const mi355_attn_params* p) {
   if (p->new_kv_all_rows && (!p->k_new || p->write_new_kv)) { set_error("new_kv_all_rows needs k_new / v_new and excludes write_new_kv"); return MI355_ERR_BAD_ARG; }
   if (p->write_new_kv) {
     if (!p->k_new || !p->v_new) { set_error("write_new_kv needs k_new / v_new"); return MI355_ERR_BAD_ARG; }
-    if (p->max_seqlen_q != 1 || p->num_tokens != p->num_seqs || p->skip_decodes || p->only_decodes) {
-      set_error("write_new_kv is for decode steps: one query token per sequence (max_seqlen_q %d, num_tokens %d, num_seqs %d)", p->max_seqlen_q, p->num_tokens, p->num_seqs);
-      return MI355_ERR_BAD_ARG;
+    if (p->skip_decodes || p->only_decodes) { set_error("write_new_kv excludes skip_decodes / only_decodes"); return MI355_ERR_BAD_ARG; }
+    const bool decode_step = p->max_seqlen_q == 1 && p->num_tokens == p->num_seqs;
+    // a decode step (one query token per sequence: the split-KV kernel), or - library 0.6.0 - a prefill step the short-prompt
+    // kernel serves in one launch (prefill_write_fusable); nothing else carries a fused write
+    if (decode_step ? !decode_write_fusable(*p) : !prefill_write_fusable(*p)) {
+      set_error("write_new_kv: this step is not served with a fused cache write (ask mi355_decode_write_fusable first; max_seqlen_q %d, num_tokens %d, num_seqs %d)",
+                p->max_seqlen_q, p->num_tokens, p->num_seqs);
+      return MI355_ERR_UNSUPPORTED;
     }
-    if (!decode_write_fusable(*p)) { set_error("write_new_kv: this configuration is not served by the fused decode kernel (mi355_decode_write_fusable)"); return MI355_ERR_UNSUPPORTED; }
   }
   return MI355_OK;
 }
@@ -80,7 +84,7 @@ enum class Path { Generic, Decode, Prefill, PrefillPlusDecode, Repacked };
 
 static Path choose(const mi355_attn_params& p) {
   const int sel = p.kernel_select;
-  if (p.write_new_kv) return Path::Decode;     // validated: the fused decode kernel takes it
+  if (p.write_new_kv) return (p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) ? Path::Decode : Path::Prefill;     // validated: the fused decode kernel / the short-prompt prefill kernel takes it
   // non-causal: prefill_pw_kernel takes it (a context that covers the whole sequence); everything it does not serve
   // (f32, other head sizes, soft-cap ...) runs on the shape-agnostic kernel, which reads linear k_new / v_new itself
   const bool nc_fast = p.non_causal && sel != MI355_SELECT_GENERIC && sel != MI355_SELECT_3D && (p.k_new ? repack_supported(p) && prefill_pw_applicable(repacked_params(p, nullptr, 0))
@@ -229,7 +233,8 @@ int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t 
 
 int mi355_decode_write_fusable(const mi355_attn_params* p) {
   if (!p || p->num_tokens <= 0 || p->num_seqs <= 0) return 0;
-  return decode_write_fusable(*p) ? 1 : 0;
+  if (p->max_seqlen_q == 1 && p->num_tokens == p->num_seqs) return decode_write_fusable(*p) ? 1 : 0;
+  return prefill_write_fusable(*p) ? 1 : 0;      // (library 0.6.0: a prefill step in one launch of the short-prompt kernel)
 }
 
 int mi355_context_attention_fwd_v0(const mi355_attn_params* p, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {

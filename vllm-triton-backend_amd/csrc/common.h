@@ -462,6 +462,8 @@ int launch_prefill_pw(const mi355_attn_params& p, int key_splits, int64_t out_sp
 bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks);   // launch_prefill would hand this call to prefill_pw_kernel
 bool prefill_lat_applicable(const mi355_attn_params& p);   // short-prompt (latency) prefill kernel, prefill_lat.hip: beyond prefill_supported()
 int launch_prefill_lat(const mi355_attn_params& p, hipStream_t stream);
+bool prefill_lat_selected(const mi355_attn_params& p);     // launch_prefill hands this call to prefill_lat_kernel
+bool prefill_write_fusable(const mi355_attn_params& p);    // a prefill step whose cache write can ride the attention launch (write_new_kv)
 
 inline int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return MI355_OK;

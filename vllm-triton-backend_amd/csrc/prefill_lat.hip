@@ -180,6 +180,28 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
   const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
   const int page_mask = p.page_size - 1;
+  // fused cache write (see issue_dma): the linear key / value rows of this KV head, and this Q block's own tokens stored
+  // into their pages - by slot_mapping when the caller hands one in (a negative slot is a padding token: not stored,
+  // triton_attn.py:149-151), else by position through the block table. 16 bytes per thread and matrix, sixteen rows a pass.
+  const bool fused = p.write_new_kv != 0;
+  const int new_st = (int)p.new_stride_token;
+  const char* const knew = (const char*)p.k_new + (int64_t)head * p.new_stride_head * 2;
+  const char* const vnew = (const char*)p.v_new + (int64_t)head * p.new_stride_head * 2;
+  if (fused) {
+    const int tok_end = min(tok0 + BQ, q_len);
+    for (int tok = tok0 + (tid >> 4); tok < tok_end; tok += NW * 4) {
+      int64_t slot;
+      if (p.slot_mapping) slot = p.slot_mapping[q_start + tok];
+      else if (p.slot_mapping_i32) slot = p.slot_mapping_i32[q_start + tok];
+      else { const int pos = ctx_len + tok; slot = (int64_t)bt[pos >> a.page_shift] * p.page_size + (pos & page_mask); }
+      if (slot < 0) continue;
+      const int64_t pg = slot >> a.page_shift, sl = slot & page_mask;
+      const int64_t src = (int64_t)(q_start + tok) * (new_st * 2) + (tid & 15) * 16;
+      const lu32x4_t kk = *(const lu32x4_t*)(knew + src), vv = *(const lu32x4_t*)(vnew + src);
+      *(lu32x4_t*)((char*)kbase + pg * ((int64_t)a.k_page_stride * 2) + sl * ((int64_t)a.k_slot_stride * 2) + (tid & 15) * 16) = kk;
+      *(lu32x4_t*)((char*)vbase + pg * ((int64_t)a.v_page_stride * 2) + sl * ((int64_t)a.v_slot_stride * 2) + (tid & 15) * 16) = vv;
+    }
+  }
   // Wave w stages 16-key group w of every tile, both matrices: ONE block-table entry and one scalar base per tile and
   // wave, then four K and four V instructions of 1 KiB (rows 4j .. 4j+3 of the group), each with its own constant per-lane
   // byte offset (the source-side swizzle inside) and the base as an SGPR pair: ~50 scalar instructions per tile and wave
@@ -209,6 +231,33 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
     const uint64_t v_off = a.kv_same_strides ? k_off : (uint64_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2;
     const uint64_t kb = (uint64_t)kbase + k_off, vb = (uint64_t)vbase + v_off;
     const uint32_t dst = smem_base + stage_off + (uint32_t)wave * (16 * ROWB);
+    if (fused && key0 + 16 > ctx_len) {
+      // FUSED CACHE WRITE (write_new_kv): keys at positions >= ctx_len are this call's own tokens and come from the linear
+      // key / value tensors, never from the cache (whoever stores them - the Q block that owns the token, above - need not have
+      // done so yet: no order between workgroups is needed). A group of sixteen such keys is sixteen consecutive rows of
+      // [T, Hk, D]: the same shape as a cache page's slots, another scalar base and its own row stride. The one group of a
+      // sequence that straddles ctx_len takes per-lane addresses.
+      if (key0 >= ctx_len) {
+        const uint64_t nb = (uint64_t)(uint32_t)(q_start + key0 - ctx_len) * (uint64_t)(new_st * 2);
+        const uint64_t knb = (uint64_t)knew + nb, vnb = (uint64_t)vnew + nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rig = 4 * j + rin, r = min(rig, max(seq_len - 1 - key0, 0));        // (rows past the sequence: its last row)
+          lat_glds16((uint32_t)(r * new_st * 2 + ((ch ^ rig) << 4)), knb, dst + j * 1024);
+          lat_glds16((uint32_t)(r * new_st * 2 + ((ch ^ (2 * (rig & 7))) << 4)), vnb, dst + KBUF + j * 1024);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rig = 4 * j + rin, pos = min(key0 + rig, seq_len - 1);
+          const bool is_new = pos >= ctx_len;
+          const char* ks = is_new ? knew + (int64_t)(q_start + pos - ctx_len) * (new_st * 2) : (const char*)kb + (int64_t)(pos - key0) * ((int)a.k_slot_stride * 2);
+          const char* vs = is_new ? vnew + (int64_t)(q_start + pos - ctx_len) * (new_st * 2) : (const char*)vb + (int64_t)(pos - key0) * ((int)a.v_slot_stride * 2);
+          glds16(ks + ((ch ^ rig) << 4), dst + j * 1024);
+          glds16(vs + ((ch ^ (2 * (rig & 7))) << 4), dst + KBUF + j * 1024);
+        }
+      }
+    } else
     if (key0 + 16 > seq_len) {              // wave-uniform: the sequence ends inside this group -> rows past it fetch its last row
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -461,6 +510,30 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// Which calls launch_prefill gives this kernel (one box's measurements, see there): about one 64-row Q block per CU, or ONE
+// sequence of 640 .. 2047 keys. MI355_PREFILL (lab switch) pins / excludes it.
+bool prefill_lat_selected(const mi355_attn_params& p) {
+  if (!prefill_lat_applicable(p) || p.max_seqlen_k >= 2048) return false;
+  static const char* const variant = lab_env("MI355_PREFILL");
+  if (variant) return variant[0] == 'l';
+  const long wgs = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 64 + p.num_seqs) * p.num_kv_heads;   // its grid
+  return wgs <= 288 || (p.num_seqs == 1 && p.max_seqlen_k >= 640 && wgs <= 1024);
+}
+
+// A prefill step whose cache write rides the attention launch (write_new_kv with max_seqlen_q > 1; SURVEY.md 8f-2, the pair
+// of calls at LIB/backend/triton_attn.py:393-405 + :437 as ONE): served by this kernel alone so far - a single launch (one
+// sequence, or sequences that all carry max_seqlen_q tokens: no decode rows on the side), 16-bit cache of the query's type.
+bool prefill_write_fusable(const mi355_attn_params& p) {
+  mi355_attn_params q = p;
+  q.write_new_kv = 1;
+  if (!q.k_new || !q.v_new || q.max_seqlen_q <= 1 || q.non_causal || q.skip_decodes || q.only_decodes || q.new_kv_all_rows) return false;
+  if (q.kernel_select != MI355_SELECT_AUTO && q.kernel_select != MI355_SELECT_2D) return false;
+  if (!(q.num_seqs == 1 || (int64_t)q.num_seqs * q.max_seqlen_q == q.num_tokens)) return false;
+  if (q.kv_dtype != q.q_dtype || q.new_stride_token % 8 != 0 || q.new_stride_head % 8 != 0 || ((uintptr_t)q.k_new & 15) != 0 || ((uintptr_t)q.v_new & 15) != 0) return false;
+  if (q.new_stride_token <= 0 || q.new_stride_token >= (1 << 22)) return false;
+  return prefill_lat_selected(q);
+}
+
 bool prefill_lat_applicable(const mi355_attn_params& p) {
   if (!prefill_supported(p)) return false;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;

@@ -1267,7 +1267,7 @@ bool prefill_supported(const mi355_attn_params& p) {
   if (p.kv_dtype != p.q_dtype && !fp8_kv) return false;
   const int dpad = padded_head_size(p.head_size, fp8_kv);
   if (dpad == 0) return false;
-  if (p.k_new || p.v_new) return false;
+  if ((p.k_new || p.v_new) && !p.write_new_kv) return false;      // (write_new_kv: the fused cache write of prefill_lat_kernel)
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   if (p.k_x != p.head_size || p.k_stride_d != 1 || p.v_stride_d != 1) return false;  // flash layout only
   if (p.k_stride_slot >= (1 << 24) || p.v_stride_slot >= (1 << 24)) return false;      // 32-bit in-page offsets
@@ -1585,12 +1585,8 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
   // 3 x 512 30.5 | 22.1 | 19.2, 2 x 1024 48.2 | 33.4 | 31.5, 4 x 512 39.5 | 27.7 | 20.4, 16 x 128 34.1 | 19.8 | 11.7, 8 x 512 75.9 | 48.6 | 33.5
   // (under load a workgroup's prologue - metadata, query rows - queues behind everyone's tile streams: many short Q blocks
   // want the wider ones). MI355_PREFILL=lat pins it wherever it applies.
-  if (!ks && prefill_lat_applicable(p)) {
-    const long wgs = ((long)p.num_tokens * (p.num_q_heads / p.num_kv_heads) / 64 + p.num_seqs) * p.num_kv_heads;   // its grid
-    const bool pinned = variant && variant[0] == 'l';
-    const bool pick = wgs <= 288 || (p.num_seqs == 1 && p.max_seqlen_k >= 640 && wgs <= 1024);
-    if (pinned || (!variant && p.max_seqlen_k < 2048 && pick)) return launch_prefill_lat(p, stream);
-  }
+  if (!ks && prefill_lat_selected(p)) return launch_prefill_lat(p, stream);
+  if (p.write_new_kv) { set_error("write_new_kv: this prefill step is not served with a fused cache write (mi355_decode_write_fusable)"); return MI355_ERR_UNSUPPORTED; }
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped

@@ -29,6 +29,7 @@ import os  # noqa: E402
 
 logger = init_logger(__name__)
 _FUSED_DECODE_WRITE = os.environ.get("MI355_FUSED_DECODE_WRITE", "1") != "0"   # A/B switch: 0 = always two launches
+_FUSED_PREFILL_WRITE = os.environ.get("MI355_FUSED_PREFILL_WRITE", "1") != "0"   # A/B switch: 0 = cache write and attention as two calls for prefill steps too
 _lib.load()  # fail at import, not at the first forward, if the HIP library is missing
 
 
@@ -304,6 +305,23 @@ class MI355AttentionImpl(AttentionImpl):
             torch.ops.mi355_attn.decode_attention_and_cache_write(
                 q, key, value, key_cache, value_cache, out, attn_metadata.query_start_loc, attn_metadata.seq_lens, int(attn_metadata.max_seq_len),
                 float(self.scale), attn_metadata.block_table, attn_metadata.slot_mapping, layer._k_scale, layer._v_scale, self.kv_cache_dtype)
+            return output
+
+        # A plain step that is not a decode step (round 4): the op issues ONE launch where the short-prompt kernel serves the
+        # step with the cache write inside (library 0.6.0: a prompt of a few hundred tokens - the reference's own latency
+        # protocol), and the pair of calls below otherwise - same cache bytes, same output. MI355_FUSED_PREFILL_WRITE=0 keeps the pair.
+        if (plain and attn_metadata.max_query_len > 1 and self.kv_sharing_target_layer_name is None and not self.kv_cache_dtype.startswith("fp8")
+                and not (self.use_irope and attn_metadata.local_attn_metadata is not None) and _FUSED_PREFILL_WRITE):
+            q = query[:num_actual_tokens]
+            out = output[:num_actual_tokens]
+            if out.dim() == 2:
+                out = out.view(-1, self.num_heads, self.head_size)
+            if q.dim() == 2:
+                q = q.view(-1, self.num_heads, self.head_size)
+            torch.ops.mi355_attn.prefill_attention_and_cache_write(
+                q, key, value, key_cache, value_cache, out, attn_metadata.query_start_loc, int(attn_metadata.max_query_len), attn_metadata.seq_lens,
+                int(attn_metadata.max_seq_len), float(self.scale), attn_metadata.block_table, attn_metadata.slot_mapping, layer._k_scale, layer._v_scale,
+                self.kv_cache_dtype, int(getattr(attn_metadata, "decode_rows_hint", 0)))
             return output
 
         if self.kv_sharing_target_layer_name is None:

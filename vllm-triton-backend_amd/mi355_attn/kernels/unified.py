@@ -206,6 +206,29 @@ def decode_attention_and_cache_write(q, key, value, k_cache, v_cache, out, sequs
     return True
 
 
+def prefill_attention_and_cache_write(q, key, value, k_cache, v_cache, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale,
+                                      block_table, slot_mapping=None):
+    """One launch for a PREFILL step the short-prompt kernel serves (library 0.6.0; csrc/prefill_lat.hip): the step's new
+    keys / values (`key`, `value` [num_tokens, Hk, D]: row t belongs to query token t) are attended over straight from
+    these tensors and stored into their cache pages by the Q block that owns the token - `slot_mapping` (the step's, as
+    reshape_and_cache_flash would get it; a negative slot is not stored) or, without one, the position through the block
+    table. Replaces the pair of calls at LIB/backend/triton_attn.py:393-405 + :437 for such steps.
+    Returns False (and does nothing) when the step is not served fused - more than one launch, a long prompt, an fp8
+    cache, features - and the caller issues the two calls."""
+    if not q.is_cuda:
+        raise RuntimeError("mi355_attn.prefill_attention_and_cache_write needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
+    if k_cache.dtype != q.dtype or key.dtype != q.dtype:
+        return False
+    n = q.shape[0]
+    p, keep = fill_attn_params(q, k_cache, v_cache, out, cu_seqlens_q, max_seqlen_q, seqused_k, max_seqlen_k, softmax_scale, (-1, -1), block_table, 0.0,
+                               None, None, None, None, k_new=key[:n], v_new=value[:n], write_new_kv=True, slot_mapping=slot_mapping)
+    if not _lib.load().mi355_decode_write_fusable(C.byref(p)):
+        return False
+    launch(p, q.device)
+    del keep
+    return True
+
+
 _cu_cache: dict = {}
 
 
