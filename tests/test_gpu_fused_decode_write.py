@@ -91,8 +91,9 @@ def test_fused_decode_write_is_declined_where_it_does_not_apply():
     lib = _lib.load()
     assert lib.mi355_decode_write_fusable(C.byref(p)) == 0
     assert lib.mi355_unified_attention(C.byref(p), None, 0, None) == _lib.MI355_ERR_UNSUPPORTED
-    p.max_seqlen_q = 2
-    assert lib.mi355_unified_attention(C.byref(p), None, 0, None) == _lib.MI355_ERR_BAD_ARG
+    p.max_seqlen_q = 2        # (not a decode step: since library 0.6.0 a request the short-prompt prefill kernel may serve - not in f32)
+    assert lib.mi355_decode_write_fusable(C.byref(p)) == 0
+    assert lib.mi355_unified_attention(C.byref(p), None, 0, None) == _lib.MI355_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])

@@ -129,7 +129,8 @@ def main():
     torch.cuda.synchronize()
     prefill_us = e0.elapsed_time(e1) * 1e3 / 20
     print(f"prefill step ({args.input_len} tokens x {B}): {prefill_us:.1f} us for {L} layers = {prefill_us / L:.2f} us per layer "
-          f"(cache write + attention, kernels: reshape_and_cache_flash + {prefill_kernel})", flush=True)
+          f"(cache write + attention; attention kernel {prefill_kernel}, the cache write inside its launch where the library serves the step fused: "
+          f"MI355_FUSED_PREFILL_WRITE={os.environ.get('MI355_FUSED_PREFILL_WRITE', '1')})", flush=True)
 
     # ---- decode steps: one graph captured at max_model_len, replayed per generated token ----------------------
     qd = (torch.rand(B, Hq, D, device=dev) * 2 - 1).to(dt)
