@@ -29,8 +29,8 @@ extern "C" {
 #define MI355_ATTN_VERSION 600 /* major*10000 + minor*100 + patch */
 /*
  * Version notes (what a caller written against an older header must know)
- *   0.6.0  write_new_kv is accepted for prefill steps too (see the field): mi355_decode_write_fusable() answers 1 for
- *          them where the short-prompt prefill kernel serves the call in one launch. Nothing else changes.
+ *   0.6.0  write_new_kv is accepted for steps with prefill rows too (see the field): mi355_decode_write_fusable() answers 1
+ *          for them where the short-prompt kernel or an LDS-DMA kernel serves the prefill rows. Nothing else changes.
  *   0.5.1  No change to the structs or the entry points. The workspace's zero-filled 256 KiB head is now two regions:
  *          [0, 192 KiB) the counters of 0.3.1, [192 KiB, 256 KiB) one byte per (128-row Q block, KV head) of an f16
  *          prefill call - rows whose scores left the fast kernel's range are flagged there and computed again by a
@@ -184,11 +184,13 @@ typedef struct mi355_attn_params {
    * attends over it, whatever the cache held there before. Requires max_seqlen_q == 1, num_tokens == num_seqs, the flash
    * layout and the matrix-core decode kernel (mi355_decode_write_fusable() answers for a parameter block); the caches
    * are written although the struct declares them const.
-   * Library version >= 0.6.0: also a PREFILL step the short-prompt kernel serves in one launch (max_seqlen_q > 1; one
-   * sequence, or sequences that all carry max_seqlen_q tokens; 16-bit cache of the query's type; mi355_decode_write_fusable()
-   * answers). k_new / v_new [num_tokens, Hk, D] then hold the key / value of EVERY query token (token t of sequence i =
-   * position seqused_k[i] - query_len_i + t): the launch attends over them straight from these tensors and stores them into
-   * their pages - by slot_mapping when one is handed in (negative: not stored), else by position through the block table. */
+   * Library version >= 0.6.0: also a step WITH PREFILL ROWS (max_seqlen_q > 1) whose prefill rows the short-prompt kernel or
+   * an LDS-DMA kernel serves (plain attention, head size 128, 16-bit cache of the query's type, key ranges below the
+   * long-prefill kernel's, no key split; mi355_decode_write_fusable() answers): k_new / v_new [num_tokens, Hk, D] then hold the
+   * key / value of EVERY query token (token t of sequence i = position seqused_k[i] - query_len_i + t); the launches attend
+   * over them straight from these tensors and store them into their pages - by slot_mapping when one is handed in
+   * (negative: not stored), else by position through the block table. One-token rows of such a step ride the decode launch
+   * and its fused write. */
   int32_t write_new_kv;
   /* 0 (every op of the reference's backend path): causal - query t of a sequence sees keys j <= t + seqused_k - query_len.
    * 1: every query row sees ALL seqused_k keys of its sequence (prefill_flash_attention(causal=False),

@@ -216,6 +216,32 @@ def test_measurement_switches_need_the_lab_gate(lib):
     assert ws(MI355_PREFILL_KEY_SPLITS="4", MI355_LAB="1") > plain + (16 * 4096 * 32 * 128 * 2)    # four partial outputs
 
 
+def test_lds_dma_and_latency_prefill_kernels_use_no_scratch(tmp_path):
+    """The compiler-scheduled prefill kernels (prefill_dma_kernel<4,2> / <8,3>, prefill_lat_kernel) must not spill: a lambda that
+    hipcc stops inlining turns its captured register arrays into scratch memory and the kernel runs 5x slower with the same
+    results (round 4: the fused cache write grew dma_piece past the inliner's limit - 4 x 512 19 -> 103 us - until the lambdas
+    were marked always_inline). Builds the two sources to assembly and reads every such kernel's private segment size."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "vllm-triton-backend_amd", "csrc")
+    seen = 0
+    for src in ("prefill_lat.hip", "prefill_mfma.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only",
+                               os.path.join(csrc, src), "-o", str(out)], stderr=subprocess.DEVNULL)
+        text = out.read_text()
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+            name, body = m.group(1), m.group(2)
+            if "prefill_dma_kernel" not in name and "prefill_lat_kernel" not in name:
+                continue
+            seen += 1
+            scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+            vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+            assert scratch == 0, (name, scratch)
+            assert vgprs <= 256, (name, vgprs)          # two workgroups of four waves (or one of eight) per CU
+    assert seen >= 8, seen
+
+
 def test_one_version_number(lib):
     """include/mi355_attn.h is the version source: the library, the Python package and setup.py report it."""
     import mi355_attn

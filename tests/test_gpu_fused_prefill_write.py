@@ -71,6 +71,53 @@ def test_fused_prefill_write_matches_separate_write_and_oracle(dtype, q_lens, kv
         torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("q_lens,kv_lens,expect", [
+    ([512] * 4, [512] * 4, "prefill_mfma"),                                        # several prompts: the 4-wave LDS-DMA kernel
+    ([300, 40, 129], [300, 100, 129], "prefill_mfma"),                             # unequal prompts: two launches, no one-token row
+    ([40, 1, 9, 1, 300], [70, 45, 33, 900, 333], "prefill_mfma"),                  # a mixed step: one-token rows on the decode kernel's fused write
+    ([1, 1, 700, 1], [1500, 17, 1200, 1], "prefill_mfma"),                         # chunk over a context beside decode rows (one with a single key)
+    ([1024] * 8, [1024] * 8, "prefill_mfma"),                                      # 8 x 1024: the LDS-DMA kernel at full width
+])
+def test_fused_write_in_steps_of_several_sequences(dtype, q_lens, kv_lens, expect):
+    """Steps with several sequences: the prefill rows on an LDS-DMA kernel (or the short-prompt kernel) with the write inside,
+    the one-token rows of a mixed step on the split-KV decode kernel's own fused write - ONE op, no separate cache write, the
+    cache and the output as the pair of calls gives them."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels import reshape_and_cache_flash
+    from mi355_attn.kernels.unified import prefill_attention_and_cache_write
+
+    hq, hk, d, page = 32, 8, 128, 16
+    inp = _case(65, q_lens, kv_lens, hq, hk, d, page, dtype)
+    d_ = gpu_util.to_dev(inp)
+    kc_ref, vc_ref = d_["k_cache"].clone(), d_["v_cache"].clone()
+    reshape_and_cache_flash(d_["k_new"], d_["v_new"], kc_ref, vc_ref, d_["slots"], "auto", None, None)
+    torch.cuda.synchronize()
+    kc, vc = d_["k_cache"].clone(), d_["v_cache"].clone()
+    kc.view(-1, hk, d)[d_["slots"]] = float("nan")
+    vc.view(-1, hk, d)[d_["slots"]] = float("nan")
+    out = torch.full_like(d_["q"], float("nan"))
+    ok = prefill_attention_and_cache_write(d_["q"], d_["k_new"], d_["v_new"], kc, vc, out, d_["cu_seqlens_q"], max(q_lens), d_["seqused_k"], max(kv_lens),
+                                           inp["scale"], d_["block_table"], d_["slots"])
+    torch.cuda.synchronize()
+    assert ok and _lib.last_kernel().startswith(expect), _lib.last_kernel()
+    assert torch.equal(kc.view(torch.int16), kc_ref.view(torch.int16)) and torch.equal(vc.view(torch.int16), vc_ref.view(torch.int16))
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(dtype, None)
+    if sum(q_lens) <= 2200:
+        ref = orc.unified_attention_oracle(inp["q"], kc_ref.cpu(), vc_ref.cpu(), inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"],
+                                           mode="2d", block_n=64)
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    else:                                         # 8 x 1024: sampled rows
+        cu = inp["cu_seqlens_q"].tolist()
+        for s_ in (0, 3, 7):
+            for t in (0, 511, 1023):
+                row = cu[s_] + t
+                ref = gpu_util.oracle_row(orc, inp["q"][row:row + 1], kc_ref.cpu(), vc_ref.cpu(), inp["block_table"][s_], kv_lens[s_] - q_lens[s_] + t + 1, inp["scale"])
+                torch.testing.assert_close(out[row:row + 1].float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
 def test_negative_slots_are_not_stored_but_attended_over():
     """A token whose slot is negative (a padding token, triton_attn.py:149-151) is attended over like any other - its key comes
     from the linear tensor - and never stored."""
@@ -102,14 +149,14 @@ def test_negative_slots_are_not_stored_but_attended_over():
 
 
 def test_steps_that_are_not_served_fused_say_so_and_the_op_falls_back():
-    """A long prompt (the 64-rows-per-wave kernel's), an fp8 cache, a mixed step: `prefill_attention_and_cache_write` returns
-    False and touches nothing; the registered op then issues the pair of calls - same cache, same output."""
+    """A long prompt, several chunks over long contexts (the 64-rows-per-wave kernel's): `prefill_attention_and_cache_write`
+    returns False and touches nothing; the registered op then issues the pair of calls - same cache, same output."""
     import gpu_util
     from mi355_attn import _lib, ops  # noqa: F401
     from mi355_attn.kernels.unified import prefill_attention_and_cache_write
 
     dtype, hq, hk, d, page = torch.bfloat16, 8, 2, 128, 16
-    for q_lens, kv_lens in (([2100], [2100]), ([40, 1, 9], [70, 45, 33])):
+    for q_lens, kv_lens in (([2100], [2100]), ([600, 700], [2000, 1900])):          # the long-prefill kernel's steps
         inp = _case(63, q_lens, kv_lens, hq, hk, d, page, dtype)
         d_ = gpu_util.to_dev(inp)
         kc, vc = d_["k_cache"].clone(), d_["v_cache"].clone()

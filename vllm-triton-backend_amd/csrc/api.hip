@@ -84,7 +84,10 @@ enum class Path { Generic, Decode, Prefill, PrefillPlusDecode, Repacked };
 
 static Path choose(const mi355_attn_params& p) {
   const int sel = p.kernel_select;
-  if (p.write_new_kv) return (p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) ? Path::Decode : Path::Prefill;     // validated: the fused decode kernel / the short-prompt prefill kernel takes it
+  if (p.write_new_kv) {      // validated: the fused decode kernel / the prefill kernels that carry the write take it
+    if (p.max_seqlen_q == 1 && p.num_tokens == p.num_seqs) return Path::Decode;
+    return (p.num_seqs == 1 || (int64_t)p.num_seqs * p.max_seqlen_q == p.num_tokens) ? Path::Prefill : Path::PrefillPlusDecode;
+  }
   // non-causal: prefill_pw_kernel takes it (a context that covers the whole sequence); everything it does not serve
   // (f32, other head sizes, soft-cap ...) runs on the shape-agnostic kernel, which reads linear k_new / v_new itself
   const bool nc_fast = p.non_causal && sel != MI355_SELECT_GENERIC && sel != MI355_SELECT_3D && (p.k_new ? repack_supported(p) && prefill_pw_applicable(repacked_params(p, nullptr, 0))
@@ -121,7 +124,7 @@ static size_t plain_workspace_bytes(const mi355_attn_params& p) {
     case Path::Prefill: return prefill_workspace_bytes(p);
     case Path::PrefillPlusDecode: {          // the two run one after the other on the stream and share the bytes
       mi355_attn_params pp = p, pd = p;
-      pp.skip_decodes = pd.only_decodes = decode_rows_max_q(p);
+      pp.skip_decodes = pd.only_decodes = p.write_new_kv ? 1 : decode_rows_max_q(p);
       const size_t a = prefill_workspace_bytes(pp), b = decode_workspace_bytes(pd);
       return a > b ? a : b;
     }
@@ -138,7 +141,7 @@ static int dispatch_plain(const mi355_attn_params& p, void* workspace, size_t wo
       return launch_prefill_ws(p, workspace, workspace_bytes, s);
     case Path::PrefillPlusDecode: {
       mi355_attn_params pp = p, pd = p;
-      pp.skip_decodes = pd.only_decodes = decode_rows_max_q(p);    // (1, or what one packed decode unit holds: multi-token decode rows)
+      pp.skip_decodes = pd.only_decodes = p.write_new_kv ? 1 : decode_rows_max_q(p);    // (1, or what one packed decode unit holds: multi-token decode rows; a fused cache write: one-token rows only)
       rc = launch_prefill_ws(pp, workspace, workspace_bytes, s);
       static thread_local char prefill_name[64];
       snprintf(prefill_name, sizeof(prefill_name), "%s", g_kernel);

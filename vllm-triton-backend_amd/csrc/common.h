@@ -463,6 +463,8 @@ bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks);   /
 bool prefill_lat_applicable(const mi355_attn_params& p);   // short-prompt (latency) prefill kernel, prefill_lat.hip: beyond prefill_supported()
 int launch_prefill_lat(const mi355_attn_params& p, hipStream_t stream);
 bool prefill_lat_selected(const mi355_attn_params& p);     // launch_prefill hands this call to prefill_lat_kernel
+bool prefill_dma_selected(const mi355_attn_params& p);     // launch_prefill (no key splits) hands this call to an LDS-DMA kernel
+bool prefill_runs_without_key_splits(const mi355_attn_params& p);
 bool prefill_write_fusable(const mi355_attn_params& p);    // a prefill step whose cache write can ride the attention launch (write_new_kv)
 
 inline int check_hip(hipError_t e, const char* what) {

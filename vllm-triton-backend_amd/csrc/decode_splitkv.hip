@@ -1032,7 +1032,8 @@ bool decode_supported(const mi355_attn_params& p) {
   if ((p.k_new || p.v_new) && !p.write_new_kv) return false;
   if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;        // power of two, >= 16
   const bool v0 = !layout_is_flash(p) && layout_is_v0(p);
-  if (p.write_new_kv && (v0 || p.max_seqlen_q != 1 || p.num_tokens != p.num_seqs || !p.k_new || !p.v_new || p.new_stride_token % 8 != 0 ||
+  // (write_new_kv: a decode step, or - only_decodes = 1 - the one-token rows of a mixed step whose prefill launch stores its own)
+  if (p.write_new_kv && (v0 || ((p.max_seqlen_q != 1 || p.num_tokens != p.num_seqs) && p.only_decodes != 1) || !p.k_new || !p.v_new || p.new_stride_token % 8 != 0 ||
                          p.new_stride_head % 8 != 0 || ((uintptr_t)p.k_new & 15) != 0 || ((uintptr_t)p.v_new & 15) != 0))
     return false;
   if (!layout_is_flash(p) && !v0) return false;

@@ -520,18 +520,26 @@ bool prefill_lat_selected(const mi355_attn_params& p) {
   return wgs <= 288 || (p.num_seqs == 1 && p.max_seqlen_k >= 640 && wgs <= 1024);
 }
 
-// A prefill step whose cache write rides the attention launch (write_new_kv with max_seqlen_q > 1; SURVEY.md 8f-2, the pair
-// of calls at LIB/backend/triton_attn.py:393-405 + :437 as ONE): served by this kernel alone so far - a single launch (one
-// sequence, or sequences that all carry max_seqlen_q tokens: no decode rows on the side), 16-bit cache of the query's type.
+// A step with a prefill whose cache write rides the attention launches (write_new_kv with max_seqlen_q > 1; SURVEY.md 8f-2, the
+// pair of calls at LIB/backend/triton_attn.py:393-405 + :437 as ONE op): the prefill rows on this kernel or on one of the
+// LDS-DMA kernels (prefill_mfma.hip) - they attend over the step's new keys straight from the linear tensors and the Q block
+// that owns a token stores its rows - and, in a step that may carry one-token rows as well (several sequences of unequal
+// query lengths: two launches, api.hip), those rows on the split-KV decode kernel's own fused write. Not the long-prefill
+// kernel (prefill_pw_kernel: from 2048 keys on, 1536 / 1024 with several sequences), key-split launches, features, fp8 caches.
 bool prefill_write_fusable(const mi355_attn_params& p) {
   mi355_attn_params q = p;
   q.write_new_kv = 1;
   if (!q.k_new || !q.v_new || q.max_seqlen_q <= 1 || q.non_causal || q.skip_decodes || q.only_decodes || q.new_kv_all_rows) return false;
-  if (q.kernel_select != MI355_SELECT_AUTO && q.kernel_select != MI355_SELECT_2D) return false;
-  if (!(q.num_seqs == 1 || (int64_t)q.num_seqs * q.max_seqlen_q == q.num_tokens)) return false;
+  if (q.kernel_select != MI355_SELECT_AUTO) return false;
+  if (q.softcap > 0.0f || q.alibi_slopes || q.sliding_window > 0) return false;
   if (q.kv_dtype != q.q_dtype || q.new_stride_token % 8 != 0 || q.new_stride_head % 8 != 0 || ((uintptr_t)q.k_new & 15) != 0 || ((uintptr_t)q.v_new & 15) != 0) return false;
   if (q.new_stride_token <= 0 || q.new_stride_token >= (1 << 22)) return false;
-  return prefill_lat_selected(q);
+  if (!prefill_runs_without_key_splits(q) || !(prefill_lat_selected(q) || prefill_dma_selected(q))) return false;     // (a key-split launch writes partial outputs: no fused write)
+  const bool single_launch = q.num_seqs == 1 || (int64_t)q.num_seqs * q.max_seqlen_q == q.num_tokens;
+  if (single_launch) return true;
+  mi355_attn_params d = q;            // the one-token rows' launch
+  d.only_decodes = 1;
+  return decode_supported(d);
 }
 
 bool prefill_lat_applicable(const mi355_attn_params& p) {

@@ -825,7 +825,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
   constexpr int RPWV = kTileN / NW;              // key rows of a tile one wave stages (16 or 8)
   uint64_t wg_kb = 0, wg_vb = 0;              // this wave's group of the tile being staged: scalar bases
   bool wg_tail = false;
-  int wg_key0 = 0;
+  int wg_key0 = 0, wg_src = 0;                // wg_src: 0 the cache, 1 the linear new-token tensors, 2 both (the group straddles ctx_len)
+  const bool fused = WAVE_GROUP && p.write_new_kv != 0;
+  const int new_st = (int)p.new_stride_token;
+  const char* const knew = (const char*)p.k_new + (int64_t)head * p.new_stride_head * 2;
+  const char* const vnew = (const char*)p.v_new + (int64_t)head * p.new_stride_head * 2;
+  if (fused) {
+    // this Q block's own tokens into their pages (by slot_mapping when the caller hands one in - negative: not stored - else
+    // by position through the block table); nobody in this launch reads them from the cache
+    const int tok_end = min(tok0 + BQ, q_len);
+    for (int tok = tok0 + (tid >> 4); tok < tok_end; tok += NW * 4) {
+      int64_t slot;
+      if (p.slot_mapping) slot = p.slot_mapping[q_start + tok];
+      else if (p.slot_mapping_i32) slot = p.slot_mapping_i32[q_start + tok];
+      else { const int pos = ctx_len + tok; slot = (int64_t)bt[pos >> a.page_shift] * p.page_size + (pos & (p.page_size - 1)); }
+      if (slot < 0) continue;
+      const int64_t pg = slot >> a.page_shift, sl = slot & (p.page_size - 1);
+      const int64_t src = (int64_t)(q_start + tok) * (new_st * 2) + (tid & 15) * 16;
+      const pu32x4_t kk = *(const pu32x4_t*)(knew + src), vv = *(const pu32x4_t*)(vnew + src);
+      *(pu32x4_t*)((char*)kbase + pg * ((int64_t)a.k_page_stride * 2) + sl * ((int64_t)a.k_slot_stride * 2) + (tid & 15) * 16) = kk;
+      *(pu32x4_t*)((char*)vbase + pg * ((int64_t)a.v_page_stride * 2) + sl * ((int64_t)a.v_slot_stride * 2) + (tid & 15) * 16) = vv;
+    }
+  }
   uint32_t wgk_voff[4], wgv_voff[4];
   if constexpr (WAVE_GROUP) {
 #pragma unroll
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
       wgv_voff[j] = (uint32_t)(r * (int)a.v_slot_stride * 2 + ((c ^ fv_of(r)) << 4));
     }
   }
-  auto dma_begin = [&](int tile) {          // call once per tile before its pieces
+  auto dma_begin = [&](int tile) __attribute__((always_inline)) {          // call once per tile before its pieces
     if constexpr (!BT_IN_LDS) {
       const int e0 = (min(tile * 4, last_group) << 4) >> a.page_shift;
       if ((e0 >> 6) != bt_chunk) {            // wave-uniform; entries only ever move forward
@@ -856,11 +877,42 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
       wg_kb = (uint64_t)kbase + k_off;
       wg_vb = (uint64_t)vbase + v_off;
       wg_tail = wg_key0 + 16 > seq_len;       // the sequence ends inside this group -> rows past it fetch its last row
+      // fused cache write (write_new_kv, as in prefill_lat_kernel): a group of this call's own tokens comes from the linear
+      // key / value tensors - sixteen consecutive rows of [T, Hk, D], another scalar base and row stride; the one group of a
+      // sequence that straddles ctx_len takes per-lane addresses
+      wg_src = 0;
+      if (fused && wg_key0 + 16 > ctx_len) {
+        if (wg_key0 >= ctx_len) {
+          const uint64_t nb = (uint64_t)(uint32_t)(q_start + wg_key0 - ctx_len) * (uint64_t)(new_st * 2);
+          wg_kb = (uint64_t)knew + nb;
+          wg_vb = (uint64_t)vnew + nb;
+          wg_src = 1;
+        } else {
+          wg_src = 2;
+        }
+      }
     }
   };
   // piece i of a tile = key rows RP*i .. RP*i+RP-1: one K and one V LDS-DMA per lane (1 KiB each per wave)
-  auto dma_piece = [&](int tile, char* stage, int i) {
+  auto dma_piece = [&](int tile, char* stage, int i) __attribute__((always_inline)) {
     if constexpr (WAVE_GROUP) {             // "piece" i = instruction i of this wave's rows: RPWV wave + 4 i .. + 3 of the tile
+      if (wg_src != 0) {                    // (fused cache write: rows of the linear tensors, see dma_begin)
+        const int rig = ((wave * RPWV) & 15) + 4 * i + (lane >> 4), c = lane & 15;
+        const uint32_t dst = lds_addr(stage) + (uint32_t)(wave * (RPWV * ROWB) + i * 1024);
+        if (wg_src == 1) {
+          const int r = min(rig, max(seq_len - 1 - wg_key0, 0));
+          glds16_s((uint32_t)(r * new_st * 2 + ((c ^ fk_of(rig)) << 4)), wg_kb, dst);
+          glds16_s((uint32_t)(r * new_st * 2 + ((c ^ fv_of(rig)) << 4)), wg_vb, dst + KBUF);
+        } else {
+          const int pos = min(wg_key0 + rig, seq_len - 1);
+          const bool is_new = pos >= ctx_len;
+          const char* ks = is_new ? knew + (int64_t)(q_start + pos - ctx_len) * (new_st * 2) : (const char*)wg_kb + (int64_t)(pos - wg_key0) * ((int)a.k_slot_stride * 2);
+          const char* vs = is_new ? vnew + (int64_t)(q_start + pos - ctx_len) * (new_st * 2) : (const char*)wg_vb + (int64_t)(pos - wg_key0) * ((int)a.v_slot_stride * 2);
+          glds16(ks + ((c ^ fk_of(rig)) << 4), dst);
+          glds16(vs + ((c ^ fv_of(rig)) << 4), dst + KBUF);
+        }
+        return;
+      }
       uint32_t kvo = wgk_voff[i], vvo = wgv_voff[i];
       if (wg_tail) {
         const int rig = ((wave * RPWV) & 15) + 4 * i + (lane >> 4), c = lane & 15, r = min(rig, max(seq_len - 1 - wg_key0, 0));
@@ -893,7 +945,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
     glds16(kbase + k_off + kvo, lds_addr(stage) + lds_wave + i * (RP * ROWB));
     glds16(vbase + v_off + vvo, lds_addr(stage) + KBUF + lds_wave + i * (RP * ROWB));   // (vvo carries V's own swizzle)
   };
-  auto issue_dma = [&](int tile, char* stage) {
+  auto issue_dma = [&](int tile, char* stage) __attribute__((always_inline)) {
     dma_begin(tile);
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma_piece(tile, stage, i);
@@ -1539,6 +1591,19 @@ bool prefill_pw_selected(const mi355_attn_params& p, const KeySplitCtx* ks) {
   return pinned ? (!ks || ks->wide) : use_pw;
 }
 
+// launch_prefill (without key splits) hands this call to one of the two LDS-DMA kernels - plain bf16 / f16 attention at
+// head size 128 over a 16-bit cache that neither prefill_pw_kernel nor prefill_lat_kernel takes, no kernel pinned otherwise.
+// These and prefill_lat_kernel carry the fused cache write (write_new_kv).
+bool prefill_dma_selected(const mi355_attn_params& p) {
+  if (!prefill_supported(p) || prefill_pw_selected(p, nullptr) || prefill_lat_selected(p)) return false;
+  static const char* const variant = lab_env("MI355_PREFILL");
+  const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
+  if (variant && variant[0] == 'v') return false;
+  return !feat && p.head_size == 128 && p.kv_dtype == p.q_dtype && !p.non_causal;
+}
+
+bool prefill_runs_without_key_splits(const mi355_attn_params& p) { return plan_key_splits(p).splits <= 1; }
+
 int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks, int* counters) {
   if (!prefill_supported(p)) {
     set_error("prefill kernel does not support this configuration");
@@ -1554,6 +1619,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
   // 1 x 4096 1153 | 1068 | 933, 16 x 4096 1129 | 1032 | 978, 1 x 16384 1325 | 1188 | 1095, 1 x 3072 996 | 915 | 924,
   // 2 x 2048 962 | 920 | 849, 1 x 2048 670 | 624 | 674; below that a workgroup's prologue and epilogue (~9 us at one
   // workgroup per CU) outweigh its few tiles: 4 x 1024 628 | 636 | 663, 8 x 512 419 | 451 | 453, 1 x 1024 274 | 273 | 329).
+  if (p.write_new_kv && prefill_pw_selected(p, ks)) { set_error("write_new_kv: a prefill step of this length is not served with a fused cache write (mi355_decode_write_fusable)"); return MI355_ERR_UNSUPPORTED; }
   if (prefill_pw_selected(p, ks)) {
     // f16: P = 2^(s - m_ref) leaves 22 log2 units (15 nats) above a row's reference - its first sixteen keys' maximum - so a
     // retrieval-style row whose needle key scores higher than that overflows. Such rows are FLAGGED by the launch (one byte
@@ -1586,7 +1652,7 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
   // (under load a workgroup's prologue - metadata, query rows - queues behind everyone's tile streams: many short Q blocks
   // want the wider ones). MI355_PREFILL=lat pins it wherever it applies.
   if (!ks && prefill_lat_selected(p)) return launch_prefill_lat(p, stream);
-  if (p.write_new_kv) { set_error("write_new_kv: this prefill step is not served with a fused cache write (mi355_decode_write_fusable)"); return MI355_ERR_UNSUPPORTED; }
+  if (p.write_new_kv && (ks || !prefill_dma_selected(p))) { set_error("write_new_kv: this prefill step is not served with a fused cache write (mi355_decode_write_fusable)"); return MI355_ERR_UNSUPPORTED; }
   if (!feat && p.head_size == 128 && !v1 && p.kv_dtype == p.q_dtype) {
     // 8 waves / 256-row Q blocks / 3 stages when that still gives every CU two workgroups' worth of Q blocks
     // (it holds one at a time) and the sequences are long enough to amortise a workgroup's un-overlapped
