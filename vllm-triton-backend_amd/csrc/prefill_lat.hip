@@ -108,7 +108,8 @@ __device__ __forceinline__ void lat_glds16(uint32_t voff, uint64_t sbase, uint32
 //   NKQ 2: four waves, 64-key tiles, 64 KiB of LDS - two workgroups per CU (many Q blocks: their prologues overlap);
 //   NKQ 4: eight waves (two per SIMD), 128-key tiles, 128 KiB - one workgroup per CU with twice the waves on a Q block's
 //          keys: the form for launches of at most one workgroup per CU, where the heaviest Q block IS the launch.
-template <typename T, int NKQ>
+// WR: the instantiation that carries the fused cache write (write_new_kv) - apart, so that the plain one keeps its stream.
+template <typename T, int NKQ, bool WR = false>
 __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kernel(const LatArgs a) {
   constexpr int D = 128, ROWB = D * 2;              // 256-byte rows of 16 chunks of 16 bytes
   constexpr int NW = 2 * NKQ, TILE = 32 * NKQ;      // waves; keys per staged tile (one 16-key group per wave)
@@ -183,11 +184,11 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
   // fused cache write (see issue_dma): the linear key / value rows of this KV head, and this Q block's own tokens stored
   // into their pages - by slot_mapping when the caller hands one in (a negative slot is a padding token: not stored,
   // triton_attn.py:149-151), else by position through the block table. 16 bytes per thread and matrix, sixteen rows a pass.
-  const bool fused = p.write_new_kv != 0;
+  constexpr bool fused = WR;
   const int new_st = (int)p.new_stride_token;
   const char* const knew = (const char*)p.k_new + (int64_t)head * p.new_stride_head * 2;
   const char* const vnew = (const char*)p.v_new + (int64_t)head * p.new_stride_head * 2;
-  if (fused) {
+  if constexpr (fused) {
     const int tok_end = min(tok0 + BQ, q_len);
     for (int tok = tok0 + (tid >> 4); tok < tok_end; tok += NW * 4) {
       int64_t slot;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
     const uint64_t v_off = a.kv_same_strides ? k_off : (uint64_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2;
     const uint64_t kb = (uint64_t)kbase + k_off, vb = (uint64_t)vbase + v_off;
     const uint32_t dst = smem_base + stage_off + (uint32_t)wave * (16 * ROWB);
-    if (fused && key0 + 16 > ctx_len) {
+    if (fused && key0 + 16 > ctx_len) {        // (fused: compile time)
       // FUSED CACHE WRITE (write_new_kv): keys at positions >= ctx_len are this call's own tokens and come from the linear
       // key / value tensors, never from the cache (whoever stores them - the Q block that owns the token, above - need not have
       // done so yet: no order between workgroups is needed). A group of sixteen such keys is sixteen consecutive rows of
@@ -549,7 +550,7 @@ bool prefill_lat_applicable(const mi355_attn_params& p) {
   return !feat && p.head_size == 128 && p.kv_dtype == p.q_dtype && G <= kLatRows && ((uintptr_t)p.out & 7) == 0;
 }
 
-template <typename T, int NKQ>
+template <typename T, int NKQ, bool WR>
 static int launch_lat_t(const mi355_attn_params& p, hipStream_t stream) {
   LatArgs a;
   a.p = p;
@@ -564,9 +565,9 @@ static int launch_lat_t(const mi355_attn_params& p, hipStream_t stream) {
   constexpr size_t stages = (size_t)2 * 2 * (32 * NKQ) * 256, xch = (size_t)2 * NKQ * (2 * 8 * 1024 + 1024);
   constexpr size_t lds = stages > xch ? stages : xch;
   static std::atomic<uint64_t> lds_opt_in{0};
-  const int rc0 = ensure_dynamic_lds((const void*)prefill_lat_kernel<T, NKQ>, (int)lds, lds_opt_in, "hipFuncSetAttribute(prefill_lat)");
+  const int rc0 = ensure_dynamic_lds((const void*)prefill_lat_kernel<T, NKQ, WR>, (int)lds, lds_opt_in, "hipFuncSetAttribute(prefill_lat)");
   if (rc0 != MI355_OK) return rc0;
-  hipLaunchKernelGGL((prefill_lat_kernel<T, NKQ>), dim3(qblocks * p.num_kv_heads), dim3(128 * NKQ), lds, stream, a);
+  hipLaunchKernelGGL((prefill_lat_kernel<T, NKQ, WR>), dim3(qblocks * p.num_kv_heads), dim3(128 * NKQ), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_lat_kernel launch");
   if (rc == MI355_OK) set_kernel_name("prefill_mfma_lat");
   return rc;
@@ -579,8 +580,13 @@ int launch_prefill_lat(const mi355_attn_params& p, hipStream_t stream) {
   static const int pin = [] { const char* e = lab_env("MI355_LAT_WAVES"); return e ? atoi(e) : 0; }();
   const long wgs = ((long)p.num_tokens / (kLatRows / (p.num_q_heads / p.num_kv_heads)) + p.num_seqs) * p.num_kv_heads;
   const bool eight = pin ? pin == 8 : wgs <= 288;
-  if (eight) return p.q_dtype == MI355_BF16 ? launch_lat_t<bf16_t, 4>(p, stream) : launch_lat_t<f16_t, 4>(p, stream);
-  return p.q_dtype == MI355_BF16 ? launch_lat_t<bf16_t, 2>(p, stream) : launch_lat_t<f16_t, 2>(p, stream);
+  const bool bf = p.q_dtype == MI355_BF16;
+  if (p.write_new_kv) {
+    if (eight) return bf ? launch_lat_t<bf16_t, 4, true>(p, stream) : launch_lat_t<f16_t, 4, true>(p, stream);
+    return bf ? launch_lat_t<bf16_t, 2, true>(p, stream) : launch_lat_t<f16_t, 2, true>(p, stream);
+  }
+  if (eight) return bf ? launch_lat_t<bf16_t, 4, false>(p, stream) : launch_lat_t<f16_t, 4, false>(p, stream);
+  return bf ? launch_lat_t<bf16_t, 2, false>(p, stream) : launch_lat_t<f16_t, 2, false>(p, stream);
 }
 
 }  // namespace mi355

@@ -683,7 +683,8 @@ constexpr float kDeferThr = 8.0f;
 // work buys nothing; only doing less work per FLOP does. It is not kept.)
 // (The row geometry is written for D = 128 and D = 256 - 512-byte rows, a wave's LDS-DMA instruction covers two key rows
 // of 32 chunks - but only D = 128 is instantiated: see launch_prefill for what the D = 256 form measured.)
-template <typename T, int NW, int NST, int D = 128>
+// WR: the instantiation that carries the fused cache write (write_new_kv) - apart, so that the plain one keeps its stream.
+template <typename T, int NW, int NST, int D = 128, bool WR = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefill_dma_kernel(const PrefillArgs a) {
   static_assert(D == 128 || D == 256, "rows of 16 or 32 chunks");
   constexpr int ROWB = D * 2;                 // 256-byte rows of 16 chunks of 16 B (D = 256: 512 bytes, 32 chunks)
@@ -826,11 +827,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
   uint64_t wg_kb = 0, wg_vb = 0;              // this wave's group of the tile being staged: scalar bases
   bool wg_tail = false;
   int wg_key0 = 0, wg_src = 0;                // wg_src: 0 the cache, 1 the linear new-token tensors, 2 both (the group straddles ctx_len)
-  const bool fused = WAVE_GROUP && p.write_new_kv != 0;
+  constexpr bool fused = WAVE_GROUP && WR;
   const int new_st = (int)p.new_stride_token;
   const char* const knew = (const char*)p.k_new + (int64_t)head * p.new_stride_head * 2;
   const char* const vnew = (const char*)p.v_new + (int64_t)head * p.new_stride_head * 2;
-  if (fused) {
+  if constexpr (fused) {
     // this Q block's own tokens into their pages (by slot_mapping when the caller hands one in - negative: not stored - else
     // by position through the block table); nobody in this launch reads them from the cache
     const int tok_end = min(tok0 + BQ, q_len);
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
       // key / value tensors - sixteen consecutive rows of [T, Hk, D], another scalar base and row stride; the one group of a
       // sequence that straddles ctx_len takes per-lane addresses
       wg_src = 0;
-      if (fused && wg_key0 + 16 > ctx_len) {
+      if constexpr (fused) if (wg_key0 + 16 > ctx_len) {
         if (wg_key0 >= ctx_len) {
           const uint64_t nb = (uint64_t)(uint32_t)(q_start + wg_key0 - ctx_len) * (uint64_t)(new_st * 2);
           wg_kb = (uint64_t)knew + nb;
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D == 128) ? 2 : 1) void prefil
   // piece i of a tile = key rows RP*i .. RP*i+RP-1: one K and one V LDS-DMA per lane (1 KiB each per wave)
   auto dma_piece = [&](int tile, char* stage, int i) __attribute__((always_inline)) {
     if constexpr (WAVE_GROUP) {             // "piece" i = instruction i of this wave's rows: RPWV wave + 4 i .. + 3 of the tile
-      if (wg_src != 0) {                    // (fused cache write: rows of the linear tensors, see dma_begin)
+      if constexpr (fused) if (wg_src != 0) {   // (fused cache write: rows of the linear tensors, see dma_begin)
         const int rig = ((wave * RPWV) & 15) + 4 * i + (lane >> 4), c = lane & 15;
         const uint32_t dst = lds_addr(stage) + (uint32_t)(wave * (RPWV * ROWB) + i * 1024);
         if (wg_src == 1) {
@@ -1540,7 +1541,7 @@ static int launch_prefill_t(const mi355_attn_params& p, hipStream_t stream, cons
   return rc;
 }
 
-template <typename T, int NW, int NST, int D = 128>
+template <typename T, int NW, int NST, int D = 128, bool WR = false>
 static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, const KeySplitCtx* ks) {
   PrefillArgs a;
   a.p = p;
@@ -1560,10 +1561,10 @@ static int launch_prefill_dma(const mi355_attn_params& p, hipStream_t stream, co
   size_t lds = (size_t)NST * 2 * kTileN * (2 * D);   // NST stages of K + V tiles, unpadded
   if (NST >= 3) lds += prefill_bt_lds_bytes(p);   // + the block-table prefix (the caller checked that it fits)
   static std::atomic<uint64_t> lds_opt_in{0};
-  const int rc0 = ensure_dynamic_lds((const void*)prefill_dma_kernel<T, NW, NST, D>, (int)((size_t)NST * 2 * kTileN * (2 * D) + (NST >= 3 ? bt_lds_max_bytes(NST) : 0)),
+  const int rc0 = ensure_dynamic_lds((const void*)prefill_dma_kernel<T, NW, NST, D, WR>, (int)((size_t)NST * 2 * kTileN * (2 * D) + (NST >= 3 ? bt_lds_max_bytes(NST) : 0)),
                                      lds_opt_in, "hipFuncSetAttribute(prefill_dma)");
   if (rc0 != MI355_OK) return rc0;
-  hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST, D>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(NW * 64), lds, stream, a);
+  hipLaunchKernelGGL((prefill_dma_kernel<T, NW, NST, D, WR>), dim3(qblocks * p.num_kv_heads, a.key_splits), dim3(NW * 64), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_dma_kernel launch");
   if (rc == MI355_OK) set_kernel_name(D == 256 ? "prefill_mfma_d256" : "prefill_mfma");
   return rc;
@@ -1664,6 +1665,11 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
     bool wide = wgs8 >= 2 * 256 && p.max_seqlen_k >= 2048;
     if (ks) wide = ks->wide;
     if (variant && variant[0] == 'd') wide = variant[1] == '8';
+    if (p.write_new_kv) {
+      if (wide && prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3))
+        return bf ? launch_prefill_dma<bf16_t, 8, 3, 128, true>(p, stream, ks) : launch_prefill_dma<f16_t, 8, 3, 128, true>(p, stream, ks);
+      return bf ? launch_prefill_dma<bf16_t, 4, 2, 128, true>(p, stream, ks) : launch_prefill_dma<f16_t, 4, 2, 128, true>(p, stream, ks);
+    }
     if (wide && prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3))
       return bf ? launch_prefill_dma<bf16_t, 8, 3>(p, stream, ks) : launch_prefill_dma<f16_t, 8, 3>(p, stream, ks);
     return bf ? launch_prefill_dma<bf16_t, 4, 2>(p, stream, ks) : launch_prefill_dma<f16_t, 4, 2>(p, stream, ks);
