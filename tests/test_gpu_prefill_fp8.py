@@ -1,0 +1,137 @@
+"""-m gpu: prefill over an fp8 cache on the 64-rows-per-wave kernel's KV8 instantiations (csrc/prefill_pw.hip, round 4): the
+fp8 tiles arrive by LDS-DMA and are widened inside the kernel, as the reference dequantises on load
+(kernel_unified_attention_2d, LIB/kernels/triton_unified_attention.py:434-455: (fp8 -> f32) * scale -> query type); no 16-bit
+scratch cache, the workspace is the 256 KiB counter block. Against the CPU oracle through the C ABI."""
+
+import pytest
+import torch
+
+import golden_io
+from oracle import paged_attention_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+FP8 = [torch.float8_e4m3fn, torch.float8_e5m2]
+
+
+def _run(inp, ks, vs, **kw):
+    import gpu_util
+
+    d = gpu_util.to_dev(inp)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], kv_scale=ks, v_scale=vs, **kw)
+    assert not torch.isnan(out).any()
+    return d, out, kernel
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_dtype", FP8)
+def test_long_prefill_reads_the_fp8_cache_itself(dtype, kv_dtype):
+    """Two prompts (one of them a chunk over 1100 keys of context) and a decode row; k and v scales that are no powers of
+    two and differ. The prefill rows run on `prefill_mfma_pw_fp8`, the decode row on the split-KV kernel's fp8 form."""
+    query_lens, kv_lens = [2100, 1500, 1], [2100, 2600, 2500]
+    ks, vs = 0.0237, 0.041
+    inp = orc.make_paged_inputs(71, query_lens, kv_lens, 8, 2, 128, 16, dtype, kv_dtype=kv_dtype, kv_scale=ks)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], k_scale=ks, v_scale=vs, mode="2d", block_n=64)
+    d, out, kernel = _run(inp, ks, vs)
+    atol, rtol = golden_io.tolerance(dtype, kv_dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    # one pass per Q block (num_segments = 1), as at serving sizes
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out1 = torch.full_like(d["q"], float("nan"))
+    kst, vst = torch.tensor([ks], device=gpu_util.DEV), torch.tensor([vs], device=gpu_util.DEV)
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out1, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], 0.0, kst, vst, None, None, num_segments=1)
+    import ctypes
+    nbytes = _lib.load().mi355_attn_workspace_bytes(ctypes.byref(p))
+    assert nbytes == 256 << 10, nbytes                                       # the counter block: no scratch cache
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("prefill_mfma_pw_fp8+decode_") and _lib.last_kernel().endswith("_fp8"), _lib.last_kernel()
+    torch.testing.assert_close(out1.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("kv_dtype", FP8)
+@pytest.mark.parametrize("hq,hk", [(8, 2), (4, 4), (6, 2), (16, 1)])
+def test_ragged_lengths_and_group_sizes(kv_dtype, hq, hk):
+    """Lengths that end inside a 16-key group, inside a 64-key tile, one key past a tile; a sequence of a single tile and
+    one of two (fewer tiles than the fetch side runs ahead); Q blocks with padding rows (G = 3); pinned to the kernel."""
+    import gpu_util
+    from mi355_attn import _lib
+
+    query_lens = [2049, 63, 130, 700, 17, 2]
+    kv_lens = [2049, 63, 2113, 2751, 65, 4100]
+    ks, vs = 0.5, 1.75
+    inp = orc.make_paged_inputs(72, query_lens, kv_lens, hq, hk, 128, 16, torch.bfloat16, kv_dtype=kv_dtype, kv_scale=ks)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], k_scale=ks, v_scale=vs, mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    from mi355_attn.kernels.unified import fill_attn_params, launch
+    out = torch.full_like(d["q"], float("nan"))
+    kst, vst = torch.tensor([ks], device=gpu_util.DEV), torch.tensor([vs], device=gpu_util.DEV)
+    p, keep = fill_attn_params(d["q"], d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"], max(kv_lens), inp["scale"],
+                               (-1, -1), d["block_table"], 0.0, kst, vst, None, None, num_segments=1)
+    launch(p, gpu_util.DEV)
+    torch.cuda.synchronize()
+    assert _lib.last_kernel().startswith("prefill_mfma_pw_fp8"), _lib.last_kernel()
+    assert not torch.isnan(out).any()
+    atol, rtol = golden_io.tolerance(torch.bfloat16, kv_dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("page", [16, 32, 128])
+def test_page_sizes(page):
+    query_lens, kv_lens = [2300, 1], [2300, 900]            # (36 tiles: the plan takes them in one pass on this kernel)
+    inp = orc.make_paged_inputs(73, query_lens, kv_lens, 8, 2, 128, page, torch.float16, kv_dtype=torch.float8_e4m3fn, kv_scale=0.3)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], k_scale=0.3, v_scale=0.3, mode="2d", block_n=64)
+    d, out, kernel = _run(inp, 0.3, None)
+    assert "prefill_mfma_pw_fp8" in kernel, kernel
+    atol, rtol = golden_io.tolerance(torch.float16, torch.float8_e4m3fn)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+def test_a_vllm_shaped_step_48_decodes_and_a_2048_token_chunk():
+    """VERDICT r03 'missing' 2: 48 decode rows + one 2048-token chunk over 2048 keys of context, fp8-e4m3 cache, Llama shape.
+    Until round 4 this fell to the register-staged kernel (too few query rows per sequence for the scratch route); now the
+    chunk runs on `prefill_mfma_pw_fp8` and the decode rows on the split-KV kernel, with no scratch."""
+    import gpu_util
+
+    query_lens = [1] * 48 + [2048]
+    kv_lens = [300 + 37 * i for i in range(48)] + [4096]
+    ks, vs = 0.11, 0.07
+    inp = orc.make_paged_inputs(74, query_lens, kv_lens, 32, 8, 128, 16, torch.bfloat16, kv_dtype=torch.float8_e4m3fn, kv_scale=ks)
+    d, out, kernel = _run(inp, ks, vs)
+    assert kernel.startswith("prefill_mfma_pw_fp8+decode_") and kernel.endswith("_fp8"), kernel
+    cu = inp["cu_seqlens_q"].tolist()
+    atol, rtol = golden_io.tolerance(torch.bfloat16, torch.float8_e4m3fn)
+    for s, t in [(0, 0), (17, 0), (47, 0), (48, 0), (48, 1), (48, 63), (48, 64), (48, 1000), (48, 2047)]:
+        row = cu[s] + t
+        n = kv_lens[s] - query_lens[s] + t + 1
+        ref = gpu_util.oracle_row(orc, inp["q"][row:row + 1], inp["k_cache"], inp["v_cache"], inp["block_table"][s], n, inp["scale"], k_scale=ks, v_scale=vs)
+        torch.testing.assert_close(out[row:row + 1].float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+def test_rows_that_leave_the_range_are_recomputed_from_the_fp8_cache():
+    """f16: a needle key 30 nats above a row's first sixteen keys overflows P; the flagged blocks are computed again by the
+    register-staged kernel's fp8 form (f16) - and a bf16 row far enough out goes through the in-launch per-row routine,
+    which reads the fp8 cache too."""
+    tokens, hq, hk, dd = 2304, 8, 2, 128
+    for dtype, gain in ((torch.float16, 30.0), (torch.bfloat16, 200.0)):
+        inp = orc.make_paged_inputs(75, [tokens], [tokens], hq, hk, dd, 16, dtype, kv_dtype=torch.float8_e4m3fn, kv_scale=1.0)
+        kc = inp["k_cache"].float()
+        page, slot = int(inp["block_table"][0, 300 // 16]), 300 % 16
+        direction = torch.nn.functional.normalize(torch.randn(dd, generator=torch.Generator().manual_seed(5)), dim=0)
+        kc[page, slot, :, :] = direction * 8.0
+        inp["k_cache"] = kc.to(torch.float8_e4m3fn)
+        q = inp["q"].float()
+        q[:, 0, :] = direction * (gain / inp["scale"] / 8.0)        # head 0: every row scores +gain nats on the needle
+        inp["q"] = q.to(dtype)
+        ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                           inp["scale"], k_scale=1.0, v_scale=1.0, mode="2d", block_n=64)
+        d, out, kernel = _run(inp, 1.0, None)
+        assert kernel.startswith("prefill_mfma_pw_fp8"), kernel
+        atol, rtol = golden_io.tolerance(dtype, torch.float8_e4m3fn)
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)

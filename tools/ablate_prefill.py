@@ -31,7 +31,7 @@ def main():
     names = sys.argv[2:] or list(VARIANTS)
     out_dir = os.path.join(ROOT, "gpurun_out", "ablate")
     os.makedirs(out_dir, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("api.hip", "generic_attn.hip", "cache_write.hip", "decode_splitkv.hip", "decode_splitkv_pack.hip", "prefill_mfma.hip", "prefill_lat.hip", "prefill_pw.hip", "prefill_pw_feat.hip", "prefill_pw_heads.hip", "repack.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("api.hip", "generic_attn.hip", "cache_write.hip", "decode_splitkv.hip", "decode_splitkv_pack.hip", "prefill_mfma.hip", "prefill_lat.hip", "prefill_pw.hip", "prefill_pw_feat.hip", "prefill_pw_heads.hip", "prefill_pw_fp8.hip", "repack.hip")]
     procs = []
     for n in names:
         so = os.path.join(out_dir, f"lib_{n}.so")

@@ -23,7 +23,7 @@ from mi355_attn import _lib  # noqa: E402
 
 def main():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("api.hip", "generic_attn.hip", "cache_write.hip", "decode_splitkv.hip", "decode_splitkv_pack.hip", "prefill_mfma.hip", "prefill_lat.hip", "prefill_pw.hip", "prefill_pw_feat.hip", "prefill_pw_heads.hip", "repack.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("api.hip", "generic_attn.hip", "cache_write.hip", "decode_splitkv.hip", "decode_splitkv_pack.hip", "prefill_mfma.hip", "prefill_lat.hip", "prefill_pw.hip", "prefill_pw_feat.hip", "prefill_pw_heads.hip", "prefill_pw_fp8.hip", "repack.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DMI355_PROFILE_PHASES", "-DMI355_LAB",
                            "-o", OUT, *srcs])
     _lib.LIB_PATH = OUT

@@ -1376,9 +1376,11 @@ static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
   // 1024-token chunk at 8k keys 919 -> 988; 512: 858 -> 954).
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   const long wgs8 = ((long)p.num_tokens * G / 256 + p.num_seqs) * p.num_kv_heads;
+  // an fp8 cache that prefill_pw_kernel reads itself (its KV8 instantiations, round 4): the wide plan, like a 16-bit cache
+  const bool fp8_direct = p.kv_dtype != p.q_dtype && prefill_pw_applicable(p);
   if (env) {
     splits = atoi(env);
-  } else if (!feat && p.head_size == 128 && p.kv_dtype == p.q_dtype && wgs8 < 512 && tiles >= 64 &&
+  } else if (!feat && p.head_size == 128 && (p.kv_dtype == p.q_dtype || fp8_direct) && wgs8 < 512 && tiles >= 64 &&
              prefill_bt_lds_bytes(p) <= bt_lds_max_bytes(3)) {
     splits = (int)std::min<long>(std::min<long>((512 + wgs8 - 1) / wgs8, tiles / 32), kMaxKeySplits);
     wide = splits > 1;
@@ -1387,6 +1389,8 @@ static KeySplitPlan plan_key_splits(const mi355_attn_params& p) {
     const int tps8 = (tiles + splits - 1) / splits;
     return {(tiles + tps8 - 1) / tps8, tps8, true};
   }
+  // ... and where the wide plan does not split, one pass on that kernel rather than key splits on the register-staged one
+  if (fp8_direct && !env && p.max_seqlen_k >= 2048) return {1, tiles, false};
   // the 4-wave kernel (and the register-staged one: features, fp8 KV, other head sizes):
   // two workgroups per CU, >= 8 tiles each (one sequence, Hq 32 / Hk 8: 512-token chunk at 8k keys 167 -> 79 us with 4
   // splits, at 32k keys 655 -> 275; two such chunks 112 -> 79 with 2; a 1024-token chunk at 32k keys 652 -> 534 with 2)
@@ -1638,7 +1642,9 @@ int launch_prefill(const mi355_attn_params& p, hipStream_t stream, const KeySpli
     static thread_local char pw_name[48];
     snprintf(pw_name, sizeof(pw_name), "%s", mi355_last_kernel_name());
     const int dpad = padded_head_size(p.head_size, false);
-    if (dpad == 64) rc = feat ? launch_prefill_t<f16_t, f16_t, 64, true>(p, stream, ks, flags) : launch_prefill_t<f16_t, f16_t, 64, false>(p, stream, ks, flags);
+    if (p.kv_dtype == MI355_FP8_E4M3) rc = launch_prefill_t<f16_t, e4m3_t, 128, false>(p, stream, ks, flags);        // (an fp8 cache: plain attention at head size 128 only, prefill_pw_applicable)
+    else if (p.kv_dtype == MI355_FP8_E5M2) rc = launch_prefill_t<f16_t, e5m2_t, 128, false>(p, stream, ks, flags);
+    else if (dpad == 64) rc = feat ? launch_prefill_t<f16_t, f16_t, 64, true>(p, stream, ks, flags) : launch_prefill_t<f16_t, f16_t, 64, false>(p, stream, ks, flags);
     else rc = feat ? launch_prefill_t<f16_t, f16_t, 128, true>(p, stream, ks, flags) : launch_prefill_t<f16_t, f16_t, 128, false>(p, stream, ks, flags);
     if (rc == MI355_OK) set_kernel_name(pw_name);
     return rc;

@@ -88,6 +88,10 @@ constexpr int kSlotBytes = 16384, kLdsK = 0, kLdsV = 3 * kSlotBytes, kLdsO = 6 *
 constexpr int kPwORS = 256 + 16;     // padded row stride of the parked O rows
 constexpr int kLdsT = kLdsO + 4 * 32 * kPwORS;   // two ints: the item index wave 0 drew, published to the workgroup
 constexpr int kPwLds = kLdsT + 16;
+// fp8 cache (KV8 instantiations): behind everything else, a staging area of 4 KiB per wave - its 16-key group of the next K tile
+// (2 KiB of fp8) and of the next V tile, as LDS-DMA delivers them
+constexpr int kLdsS = kPwLds, kPwLdsF8 = kLdsS + 4 * 4096;
+static_assert(kLdsS % 16 == 0 && kPwLdsF8 <= 160 * 1024, "prefill_pw_kernel: LDS map");
 constexpr size_t kPwCounterBytes = (size_t)256 << 10;   // the counter region at the head of every workspace (include/mi355_attn.h)
 
 struct PwArgs {
@@ -380,6 +384,31 @@ __device__ __forceinline__ void pw_sload(int& dst, uint64_t base, int byte_off) 
   asm volatile("s_load_dword %0, %1, %2" : "=s"(dst) : "s"(base), "s"(byte_off) : "memory");
 }
 
+// fp8 cache: 16 staged bytes of this lane -> VGPRs, and a widened 16-byte chunk -> its place in a ring slot. Fixed in the
+// instruction stream like everything else of the loop; the reads are retired by a counted s_waitcnt that names them.
+template <int OFF> __device__ __forceinline__ wu32x4_t pw_lds_read128(uint32_t addr) {
+  wu32x4_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int OFF> __device__ __forceinline__ void pw_lds_write128(uint32_t addr, const wu32x4_t& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%c2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void pw_lds_write128_rt(uint32_t addr, const wu32x4_t& v) {
+  asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+// one word of four fp8 -> two packed pairs of T (exact: every fp8 value is a bf16 / f16 value), in place in the stream
+template <typename T, typename KVT> __device__ __forceinline__ void pw_widen4(uint32_t w, uint32_t& lo, uint32_t& hi) {
+  if constexpr (__is_same(T, bf16_t) && __is_same(KVT, e4m3_t))
+    asm volatile("v_cvt_scalef32_pk_bf16_fp8 %0, %2, 1.0\n\tv_cvt_scalef32_pk_bf16_fp8 %1, %2, 1.0 op_sel:[1,0,0]" : "=&v"(lo), "=&v"(hi) : "v"(w));
+  else if constexpr (__is_same(T, bf16_t))
+    asm volatile("v_cvt_scalef32_pk_bf16_bf8 %0, %2, 1.0\n\tv_cvt_scalef32_pk_bf16_bf8 %1, %2, 1.0 op_sel:[1,0,0]" : "=&v"(lo), "=&v"(hi) : "v"(w));
+  else if constexpr (__is_same(KVT, e4m3_t))
+    asm volatile("v_cvt_scalef32_pk_f16_fp8 %0, %2, 1.0\n\tv_cvt_scalef32_pk_f16_fp8 %1, %2, 1.0 op_sel:[1,0,0]" : "=&v"(lo), "=&v"(hi) : "v"(w));
+  else
+    asm volatile("v_cvt_scalef32_pk_f16_bf8 %0, %2, 1.0\n\tv_cvt_scalef32_pk_f16_bf8 %1, %2, 1.0 op_sel:[1,0,0]" : "=&v"(lo), "=&v"(hi) : "v"(w));
+}
+
 __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int num_seqs, int qblock, int block_q) {
   int left = 0, right = num_seqs;     // largest i with cu[i] / block_q + i <= qblock (find_seq_idx, :32-52)
   while (left < right) {
@@ -393,14 +422,16 @@ __device__ __forceinline__ int pw_find_seq(const int32_t* __restrict__ cu, int n
 // textbook online softmax with a true running maximum in f32 (kernel_unified_attention_2d, :467-510, one key at a
 // time). Slow on purpose - it only ever runs for rows whose scores left the range prefill_pw_kernel's fixed
 // reference is good for - and independent of everything the fast path keeps on chip: K/V straight from the cache.
-template <typename T, typename ArgPtr>
+template <typename T, int KV8, typename ArgPtr>
 __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, const char* kbase, const char* vbase,
                                              int token, int hq, int key_lo, int key_hi, uint16_t* out_base, float* lse_base, int lane, int ctx_len) {
   const bool act = 2 * lane < kp->p.head_size;            // (head size 64: half the lanes; the others add 0 to every score and store nothing)
   const int dl = act ? 2 * lane : 0;
   const uint32_t qw = *(const uint32_t*)((const uint16_t*)kp->p.q + (int64_t)token * kp->p.q_stride_token + (int64_t)hq * kp->p.q_stride_head + dl);
   const float q0 = act ? pw_lo<T>(qw) : 0.0f, q1 = act ? pw_hi<T>(qw) : 0.0f;
-  const float scale2 = kp->p.scale * kPwLog2e;
+  using KVT = std::conditional_t<KV8 == 2, e5m2_t, std::conditional_t<KV8 == 1, e4m3_t, T>>;
+  const float k_sc = (KV8 && kp->p.k_scale) ? kp->p.k_scale[0] : 1.0f, v_sc = (KV8 && kp->p.v_scale) ? kp->p.v_scale[0] : 1.0f;   // (fp8 cache: the scales outside the sums, as in the fast path)
+  const float scale2 = kp->p.scale * kPwLog2e * k_sc;
   const float cap = kp->p.softcap, cap2 = cap * kPwLog2e;
   const float slope2 = kp->p.alibi_slopes ? kp->p.alibi_slopes[hq] * kPwLog2e : 0.0f;     // ALiBi: + slope * (key position - context length), :481-482
   const int page_mask = kp->p.page_size - 1;
@@ -408,8 +439,15 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
   for (int j = key_lo; j < key_hi; ++j) {
     const int64_t page = bt[j >> kp->page_shift];
     const int64_t slot = j & page_mask;
-    const uint32_t kw = *(const uint32_t*)(kbase + (page * kp->k_page_stride + slot * kp->k_slot_stride) * 2 + 2 * dl);
-    const uint32_t vw = *(const uint32_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) * 2 + 2 * dl);
+    uint32_t kw, vw;
+    if constexpr (KV8 == 0) {
+      kw = *(const uint32_t*)(kbase + (page * kp->k_page_stride + slot * kp->k_slot_stride) * 2 + 2 * dl);
+      vw = *(const uint32_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) * 2 + 2 * dl);
+    } else {
+      uint32_t hi_unused;
+      widen_fp8x4<T, KVT>(*(const uint16_t*)(kbase + (page * kp->k_page_stride + slot * kp->k_slot_stride) + dl), kw, hi_unused);
+      widen_fp8x4<T, KVT>(*(const uint16_t*)(vbase + (page * kp->v_page_stride + slot * kp->v_slot_stride) + dl), vw, hi_unused);
+    }
     float sc = wave_sum(q0 * pw_lo<T>(kw) + q1 * pw_hi<T>(kw)) * scale2;
     if (cap > 0.0f) sc = cap2 - 2.0f * cap2 / (1.0f + __builtin_amdgcn_exp2f(sc * (2.0f / cap)));   // cap tanh(s / cap) in log2 units: cap2 (1 - 2 / (1 + e^(2 s / cap))), e^(2 s / cap) = 2^(2 sc / cap)
     sc += slope2 * (float)(j - ctx_len);
@@ -421,7 +459,7 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
     a1 = a1 * alpha + pw_lo<T>(pr) * pw_hi<T>(vw);
     m = mn;
   }
-  const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+  const float inv = l > 0.0f ? v_sc / l : 0.0f;
   if (act) *(uint32_t*)(out_base + (int64_t)token * kp->p.out_stride_token + (int64_t)hq * kp->p.out_stride_head + dl) = pw_pack<T>(a0 * inv, a1 * inv);
   if (lse_base && lane == 0)
     lse_base[(int64_t)token * kp->p.lse_stride_token + hq] = l > 0.0f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
@@ -447,8 +485,18 @@ __device__ __forceinline__ void pw_row_fallback(ArgPtr kp, const int32_t* bt, co
 // SW (M16 only): sliding window. A Q block's tile range starts at the window of its first token (the reference's 2D kernel
 // only masks, :474-479; prefill_mfma_kernel tightens the same way), the tiles at the window's lower edge are general
 // iterations with the lower bound in their mask, and the steady stretch lies between the two masked ends.
-template <typename T, bool M16, bool SW, bool SC = false, bool AL = false, int D = 128>
+// KV8 (M16, plain, D = 128): the cache holds fp8 (1 = e4m3, 2 = e5m2; reference :434-455 dequantises on load). LDS-DMA cannot
+// convert, so a tile's 16-key group travels as fp8 into a STAGING area of its wave (2 KiB per matrix, half the pieces), and one
+// iteration later the same wave widens it - 16 fp8 per lane -> two 16-byte chunks, v_cvt_scalef32_pk_{bf16,f16}_{fp8,bf8}, exact -
+// and writes it where the 16-bit LDS-DMA would have put it, swizzle included: rings, fragment reads and the schedule of the
+// matrix instructions stay as they are. The cache's scales move out of the tiles: k_scale into Q', v_scale into 1 / l.
+// The fetch side runs one tile further ahead (FO): iteration t requests K(t+4) / V(t+3) and converts K(t+3) / V(t+2).
+template <typename T, bool M16, bool SW, bool SC = false, bool AL = false, int D = 128, int KV8 = 0>
 __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
+  static_assert(KV8 == 0 || (M16 && !SW && !SC && !AL && D == 128), "fp8 cache: the plain 16x16x32 instantiation at head size 128");
+  constexpr int EB = KV8 ? 1 : 2;              // bytes per cache element
+  constexpr int FO = KV8 ? 1 : 0;              // tiles the fetch side runs further ahead
+  using KVT = std::conditional_t<KV8 == 2, e5m2_t, std::conditional_t<KV8 == 1, e4m3_t, T>>;
   static_assert(M16 || !SW, "the sliding window is built into the 16x16x32 instantiation only");
   static_assert(M16 || !SC, "soft-cap is built into the 16x16x32 instantiation only");
   static_assert(!AL || (M16 && !SW && !SC), "ALiBi: the plain 16x16x32 instantiation only");
@@ -530,8 +578,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
   };
   const int head = (int)(blockIdx.x % p.num_kv_heads);
   const int slot = (int)(blockIdx.x / p.num_kv_heads);
-  const char* const kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
-  const char* const vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
+  const char* const kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * EB;
+  const char* const vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * EB;
 
   // Sequence of a Q block and its lengths in ONE memory round trip for batches of up to 63 sequences: lane i takes
   // cu_seqlens_q[i] and seqused_k[i], the search (largest i with cu[i] / BQ + i <= qblock, find_seq_idx :32-52) is a
@@ -748,8 +796,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   // ---- LDS-DMA constants: wave w stages key rows 16 w .. 16 w + 15 of every tile, four rows per instruction -
   const int page_mask = p.page_size - 1;
-  const uint32_t ksb = a.k_slot_stride * 2, vsb = a.v_slot_stride * 2;   // bytes between key rows of a page
-  const uint32_t kpb = a.k_page_stride * 2, vpb = a.v_page_stride * 2;   // bytes between pages
+  const uint32_t ksb = a.k_slot_stride * EB, vsb = a.v_slot_stride * EB;   // bytes between key rows of a page
+  const uint32_t kpb = a.k_page_stride * EB, vpb = a.v_page_stride * EB;   // bytes between pages
   // LDS row R = 4 i + r4 of the group, chunk position c16 holds logical chunk c16 ^ f(R) (swizzle on the source side);
   // rows past the sequence (R > maxr, last group only) re-read row maxr: finite data under a zero probability.
   // (The swizzle terms are recomputed from an opaque lane index at each - rare - call, not kept in eight registers.)
@@ -758,6 +806,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     int lo = lane;
     asm volatile("" : "+v"(lo));
     const int r4 = lo >> 4, c16 = lo & 15;
+    if constexpr (KV8) {       // fp8: a key row is 128 bytes, a piece covers eight rows, unswizzled (the swizzle is applied by the widening write)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int R = 8 * i + (lo >> 3); koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + ((lo & 7) << 4)); }
+      koff[2] = koff[3] = 0;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int R = 4 * i + r4; koff[i] = (uint32_t)(min(R, maxr) * (int)ksb + (min(c16 ^ R, kCM) << 4)); }
   };
@@ -765,6 +819,12 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     int lo = lane;
     asm volatile("" : "+v"(lo));
     const int r4 = lo >> 4, c16 = lo & 15;
+    if constexpr (KV8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int R = 8 * i + (lo >> 3); voff[i] = (uint32_t)(min(R, maxr) * (int)vsb + ((lo & 7) << 4)); }
+      voff[2] = voff[3] = 0;
+      return;
+    }
 #pragma unroll
     // V's chunk swizzle follows the transposed read of the instantiation: half a wave of it covers rows 0..3 x four chunks
     // (32x32x16 form: f = 4 (R & 3) | (R >> 2) & 3 keeps the rows apart) or rows 0..7 x two chunks (16x16x32 form: f = 2 (R & 7);
@@ -838,6 +898,81 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     v_rd16[db] = (uint32_t)(kLdsV + row * ROWB + (((2 * db + (pp >> 1)) ^ f) << 4) + 8 * (pp & 1));
   }
 
+  // ---- fp8 cache (KV8): where this lane's 16 staged bytes are, and where their two widened chunks go ------------------
+  // Piece i of a group = key rows 8 i + (lane >> 3), lane & 7 = the row's 16-byte piece c8 (head dims 16 c8 .. + 15), landing at
+  // 1024 i + 16 lane of the destination. Widened, they are the row's logical chunks 2 c8 and 2 c8 + 1, at chunk positions
+  // chunk ^ f(row) of the row's 256 bytes in the slot (f: the swizzles of set_k_offsets / set_v_offsets). V's f is even: its
+  // second chunk sits 16 bytes behind the first, piece 1 exactly 2048 bytes behind piece 0.
+  uint32_t st_rd = 0, kw8[2][2] = {{0, 0}, {0, 0}}, vw8 = 0;
+  if constexpr (KV8) {
+    const int R0 = lane >> 3, c8 = lane & 7;
+    st_rd = (uint32_t)(kLdsS + wave * 4096 + lane * 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) kw8[i][e] = (uint32_t)(kLdsK + wave * 4096 + (8 * i + R0) * ROWB + (((2 * c8 + e) ^ (8 * i + R0)) << 4));
+    vw8 = (uint32_t)(kLdsV + wave * 4096 + R0 * ROWB + (((2 * c8) ^ (2 * (R0 & 7))) << 4));
+  }
+  // 16 fp8 of one key row -> the row's two chunks
+  auto widen16 = [&](const wu32x4_t& in, wu32x4_t& c0, wu32x4_t& c1) __attribute__((always_inline)) {
+    uint32_t o[8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) pw_widen4<T, KVT>(in[w], o[2 * w], o[2 * w + 1]);
+    c0 = wu32x4_t{o[0], o[1], o[2], o[3]};
+    c1 = wu32x4_t{o[4], o[5], o[6], o[7]};
+  };
+  // a staged or freshly landed group (two pieces read from `src` + 1024 i) widened into ring slot byte offset SLOT (compile time)
+  auto widen_group = [&](auto ISV, auto SLOT, const wu32x4_t& p0, const wu32x4_t& p1) __attribute__((always_inline)) {
+    constexpr bool isv = decltype(ISV)::value != 0;
+    constexpr int slot = decltype(SLOT)::value;
+    wu32x4_t c0, c1;
+    widen16(p0, c0, c1);
+    if constexpr (isv) { pw_lds_write128<slot>(vw8, c0); pw_lds_write128<slot + 16>(vw8, c1); }
+    else { pw_lds_write128<slot>(kw8[0][0], c0); pw_lds_write128<slot>(kw8[0][1], c1); }
+    widen16(p1, c0, c1);
+    if constexpr (isv) { pw_lds_write128<slot + 2048>(vw8, c0); pw_lds_write128<slot + 2048 + 16>(vw8, c1); }
+    else { pw_lds_write128<slot>(kw8[1][0], c0); pw_lds_write128<slot>(kw8[1][1], c1); }
+  };
+
+  // The same in twelve steps of one statement each, for the tile loop (one step per gap): per piece, two words widened, the
+  // first chunk written, two words widened, the second chunk written. wq: the chunk under construction.
+  uint32_t wq0 = 0, wq1 = 0, wq2 = 0, wq3 = 0, wq4 = 0, wq5 = 0, wq6 = 0, wq7 = 0;
+  // ... and with two chunks under construction: a write never directly follows the statement that made its data (hipcc pads
+  // one s_nop there). Per piece: w0 w1 w2 W0 w3 | W1 rides behind the next piece's w0 (step 5 of the piece = that slot)
+  auto widen_step8 = [&](auto ISV, auto SLOT, auto KC, const wu32x4_t& p0, const wu32x4_t& p1) __attribute__((always_inline)) {
+    constexpr bool isv = decltype(ISV)::value != 0;
+    constexpr int slot = decltype(SLOT)::value, k = decltype(KC)::value;      // k = 0 .. 12
+    // order: 0:w(p0,0) 1:w(p0,1) 2:w(p0,2) 3:W(p0,c0) 4:w(p0,3) 5:w(p1,0)->(q0,q1) 6:W(p0,c1) 7:w(p1,1) 8:w(p1,2) 9:W(p1,c0) 10:w(p1,3) 11:(free) 12:W(p1,c1)
+    if constexpr (k == 0) pw_widen4<T, KVT>(p0[0], wq0, wq1);
+    else if constexpr (k == 1) pw_widen4<T, KVT>(p0[1], wq2, wq3);
+    else if constexpr (k == 2) pw_widen4<T, KVT>(p0[2], wq4, wq5);
+    else if constexpr (k == 4) pw_widen4<T, KVT>(p0[3], wq6, wq7);
+    else if constexpr (k == 5) pw_widen4<T, KVT>(p1[0], wq0, wq1);
+    else if constexpr (k == 7) pw_widen4<T, KVT>(p1[1], wq2, wq3);
+    else if constexpr (k == 8) pw_widen4<T, KVT>(p1[2], wq4, wq5);
+    else if constexpr (k == 10) pw_widen4<T, KVT>(p1[3], wq6, wq7);
+    else if constexpr (k == 3 || k == 9) {
+      constexpr int i = k == 9;
+      if constexpr (isv) pw_lds_write128<slot + 2048 * i>(vw8, wu32x4_t{wq0, wq1, wq2, wq3});
+      else pw_lds_write128<slot>(kw8[i][0], wu32x4_t{wq0, wq1, wq2, wq3});
+    } else if constexpr (k == 6 || k == 12) {
+      constexpr int i = k == 12;
+      if constexpr (isv) pw_lds_write128<slot + 2048 * i + 16>(vw8, wu32x4_t{wq4, wq5, wq6, wq7});
+      else pw_lds_write128<slot>(kw8[i][1], wu32x4_t{wq4, wq5, wq6, wq7});
+    }
+  };
+  auto widen_step = [&](auto ISV, auto SLOT, auto KC, const wu32x4_t& p0, const wu32x4_t& p1) __attribute__((always_inline)) {
+    constexpr bool isv = decltype(ISV)::value != 0;
+    constexpr int slot = decltype(SLOT)::value, k = decltype(KC)::value, i = k / 6, r = k % 6;
+    const wu32x4_t& in = i ? p1 : p0;
+    if constexpr (r == 0) pw_widen4<T, KVT>(in[0], wq0, wq1);
+    else if constexpr (r == 1) pw_widen4<T, KVT>(in[1], wq2, wq3);
+    else if constexpr (r == 3) pw_widen4<T, KVT>(in[2], wq0, wq1);
+    else if constexpr (r == 4) pw_widen4<T, KVT>(in[3], wq2, wq3);
+    else if constexpr (isv) pw_lds_write128<slot + 2048 * i + (r == 5 ? 16 : 0)>(vw8, wu32x4_t{wq0, wq1, wq2, wq3});
+    else pw_lds_write128<slot>(kw8[i][r == 5 ? 1 : 0], wu32x4_t{wq0, wq1, wq2, wq3});
+  };
+
   // ---- an item's first tiles on their way: K0 K1 V0 | K2 V1 (twenty pieces) ------------------------------
   int pg_k = 0, pg_v = 0;                        // block-table entries of K(t+3) / V(t+2) for the coming iteration (V's = K's of one iteration earlier)
   auto issue_first_tiles = [&](const Item& I) __attribute__((always_inline)) {
@@ -857,13 +992,43 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       tail_check(I, tile, ISV);
       const uint64_t base = group_base(I, tile, page, ISV);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pw_glds16(isv ? voff[i] : koff[i], base, lds_dst + lds_wave + i * 1024);
+      for (int i = 0; i < (KV8 ? 2 : 4); ++i) pw_glds16(isv ? voff[i] : koff[i], base, lds_dst + lds_wave + i * 1024);
     };
     group(I.tile_lo, pk0, ic<0>{}, kLdsK);
     group(I.tile_lo + 1, pk1, ic<0>{}, kLdsK + kSlotBytes);
     group(I.tile_lo, pv0, ic<1>{}, kLdsV);
     group(I.tile_lo + 2, pk2, ic<0>{}, kLdsK + 2 * kSlotBytes);
     group(I.tile_lo + 1, pv1, ic<1>{}, kLdsV + kSlotBytes);
+    if constexpr (KV8) {
+      // fp8: the five groups above landed as fp8 in the first half of their wave's region of their slot and are widened in place
+      // (widen_first_tiles, once the loads are back); K3 and V2 go to the staging area, where iteration 0 finds them, and the
+      // table entries run one tile further ahead
+      const int pk3 = pg_k;
+      pg_k = *(const __attribute__((address_space(4))) int*)(I.bt64 + (uint32_t)entry_off(I, I.tile_lo + 4));   // (an ordinary load: see setup)
+      group(I.tile_lo + 3, pk3, ic<0>{}, kLdsS);
+      group(I.tile_lo + 2, pk2, ic<1>{}, kLdsS + 2048);
+      pg_v = pk3;
+    }
+  };
+  // fp8: the first five groups, landed (the caller waited for them) as fp8, widened in place: both pieces into registers, then
+  // the four chunks over the same 4 KiB of this wave (LDS serves a wave's accesses in order)
+  auto widen_first_tiles = [&]() __attribute__((always_inline)) {
+    if constexpr (KV8) {
+      const uint32_t ip = st_rd - (uint32_t)kLdsS;        // wave * 4096 + lane * 16
+      const uint32_t ipv = ip + (uint32_t)kLdsV;          // (the V ring lies beyond what an instruction's offset field reaches)
+      auto one = [&](auto ISV, auto SLOT) __attribute__((always_inline)) {
+        constexpr int base = decltype(SLOT)::value;
+        const uint32_t src = decltype(ISV)::value ? ipv : ip + (uint32_t)kLdsK;
+        wu32x4_t p0 = pw_lds_read128<base>(src), p1 = pw_lds_read128<base + 1024>(src);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0), "+v"(p1) :: "memory");
+        widen_group(ISV, SLOT, p0, p1);
+      };
+      one(ic<0>{}, ic<0>{});
+      one(ic<0>{}, ic<kSlotBytes>{});
+      one(ic<1>{}, ic<0>{});
+      one(ic<0>{}, ic<2 * kSlotBytes>{});
+      one(ic<1>{}, ic<kSlotBytes>{});
+    }
   };
   // The next item's loads, hung in front of the output's first row tile (hook 0 of epilogue). Dealt over the output's four
   // row tiles they left the address unit to the output's own work - the seam's stamps shrank by 2.4 us - and the launch
@@ -880,11 +1045,13 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   // ---- O = 0 and Q' = Q * scale * log2(e), packed, in place in the accumulator registers the raw rows landed in ---
   // (SC: the scores come out as u = s * 2 log2(e) / cap, see a_softcap_exp_ho)
-  const float scale2 = SC ? p.scale * (2.0f * kPwLog2e) / p.softcap : p.scale * kPwLog2e;
+  const float scale2_plain = SC ? p.scale * (2.0f * kPwLog2e) / p.softcap : p.scale * kPwLog2e;
   auto zero_o_and_convert_q = [&](const Item& I, bool zero_o) __attribute__((always_inline)) {
     if (zero_o) sfor<128>([&](auto IC) { acc_zero<kAO + decltype(IC)::value>(); });
     // the item's query rows have landed (and everything older: its first tiles, the previous item's output)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (fp8 cache: K is widened unscaled, its scale rides in Q' - read per item, a scalar load, rather than held across the loop)
+    const float scale2 = KV8 ? scale2_plain * ((kp->p.k_scale != nullptr) ? kp->p.k_scale[0] : 1.0f) : scale2_plain;
     // One row's registers share one scale, 0 for a padding row (its raw words are the sequence's last query row: x 0
     // zeroes them, and were that row not finite, the NaN stays in a row that is never stored). Straight-line: with
     // "valid ? read : 0" per register hipcc wrapped every one of the 64 reads in an exec-mask branch - 940 instructions,
@@ -1300,21 +1467,27 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     if constexpr (!steady) {
       need_mask = (t * kPwTile + kPwTile - 1 > cur.ctx_len + cur.w_tok_lo) || (t * kPwTile + kPwTile > cur.seq_len);
       if constexpr (SW) need_mask = need_mask || (sa.window > 0 && t * kPwTile < cur.ctx_len + cur.w_tok_hi - sa.window + 1);   // below the window of the wave's last row
-      tail_check(cur, t + 3, ic<0>{});
-      tail_check(cur, t + 2, ic<1>{});
-      kb64 = group_base(cur, t + 3, pg_k, ic<0>{});
-      vb64 = group_base(cur, t + 2, pg_v, ic<1>{});
+      tail_check(cur, t + 3 + FO, ic<0>{});
+      tail_check(cur, t + 2 + FO, ic<1>{});
+      kb64 = group_base(cur, t + 3 + FO, pg_k, ic<0>{});
+      vb64 = group_base(cur, t + 2 + FO, pg_v, ic<1>{});
       pg_v = pg_k;                                 // V(t+3) lives in the page of K(t+3)
-      pw_sload(pg_k, cur.bt64, entry_off(cur, t + 4));
+      pw_sload(pg_k, cur.bt64, entry_off(cur, t + 4 + FO));
     }
     // piece j of this iteration's LDS-DMA: 0..3 = K(t+3), 4..7 = V(t+2)
     auto dma_piece = [&](auto JC) __attribute__((always_inline)) {
       constexpr int j = decltype(JC)::value;
 #ifndef PW_ABL_DMA
-      if constexpr (j < 4) pw_glds16(koff[j], kb64, KD + lds_wave + j * 1024);
+      if constexpr (KV8) {       // fp8: pieces 0, 1 = K(t+4), 2, 3 = V(t+3), into this wave's staging area
+        if constexpr (j < 2) pw_glds16(koff[j], kb64, kLdsS + lds_wave + j * 1024);
+        else pw_glds16(voff[j - 2], vb64, kLdsS + 2048 + lds_wave + (j - 2) * 1024);
+      }
+      else if constexpr (j < 4) pw_glds16(koff[j], kb64, KD + lds_wave + j * 1024);
       else pw_glds16(voff[j - 4], vb64, VD + lds_wave + (j - 4) * 1024);
 #endif
     };
+    // fp8: this wave's groups of K(t+3) / V(t+2), staged by the previous iteration's pieces
+    wu32x4_t st8[4];
 #ifdef PW_DMA_SPREAD
 #define PW_DMA_AT(seg, g) if constexpr ((g) == 1 || (g) == 9) dma_piece(ic<2 * ((seg) - 1) + ((g) == 9)>{})
 #else
@@ -1332,22 +1505,65 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         qk16(ic<0>{}, GC);
         if constexpr (steady && g == 0) {
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (fast_fetch) kb64 = group_base_fast(cur, t + 3, pg_k, ic<0>{});
-          else { tail_check(cur, t + 3, ic<0>{}); kb64 = group_base(cur, t + 3, pg_k, ic<0>{}); }
+          if constexpr (fast_fetch) kb64 = group_base_fast(cur, t + 3 + FO, pg_k, ic<0>{});
+          else { tail_check(cur, t + 3 + FO, ic<0>{}); kb64 = group_base(cur, t + 3 + FO, pg_k, ic<0>{}); }
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (steady && g == 1) {
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (fast_fetch) vb64 = group_base_fast(cur, t + 2, pg_v, ic<1>{});
-          else { tail_check(cur, t + 2, ic<1>{}); vb64 = group_base(cur, t + 2, pg_v, ic<1>{}); }
+          if constexpr (fast_fetch) vb64 = group_base_fast(cur, t + 2 + FO, pg_v, ic<1>{});
+          else { tail_check(cur, t + 2 + FO, ic<1>{}); vb64 = group_base(cur, t + 2 + FO, pg_v, ic<1>{}); }
           asm volatile("s_mov_b32 %0, %1" : "=s"(pg_v) : "s"(__builtin_amdgcn_readfirstlane(pg_k)));      // (a scalar copy: the compiler otherwise parks it in a VGPR and does V's page arithmetic on the VALU, v_mul_lo/hi + two v_readfirstlane)
-          if constexpr (fast_fetch) pw_sload(pg_k, cur.bt64, entry_off_fast(t + 4));
-          else pw_sload(pg_k, cur.bt64, entry_off(cur, t + 4));
+          if constexpr (!KV8) {        // (fp8: behind the staging reads' wait in gap 4, which would otherwise wait for this load as well)
+            if constexpr (fast_fetch) pw_sload(pg_k, cur.bt64, entry_off_fast(t + 4));
+            else pw_sload(pg_k, cur.bt64, entry_off(cur, t + 4));
+          }
           __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (KV8) {
+          // fp8: the turn-over of the staging area. Gap 0: last iteration's four pieces are back, the two staged groups go to
+          // registers; gap 4: they are there, and the next pieces may overwrite them (gaps 4, 6, 8, 10); the widening - sixteen
+          // steps of two conversions, a 16-byte write after every second - in the gaps from 5 on.
+          if constexpr (g == 0) {
+#if !defined(PW_F8_ABL) || PW_F8_ABL != 1      // (ablation builds, -DMI355_LAB: wrong results, timing only)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            st8[0] = pw_lds_read128<0>(st_rd); st8[1] = pw_lds_read128<1024>(st_rd);
+            st8[2] = pw_lds_read128<2048>(st_rd); st8[3] = pw_lds_read128<3072>(st_rd);
+          }
+          if constexpr (g == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st8[0]), "+v"(st8[1]), "+v"(st8[2]), "+v"(st8[3]) :: "memory");
+          if constexpr (g == 5 && steady) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (fast_fetch) pw_sload(pg_k, cur.bt64, entry_off_fast(t + 5));
+            else pw_sload(pg_k, cur.bt64, entry_off(cur, t + 5));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (g >= 4 && g <= 10 && (g & 1) == 0) dma_piece(ic<((g >= 4 && g <= 10) ? (g - 4) / 2 : 0)>{});
+#ifndef PW_F8_PLACE          // (a lab build may pick another placement, common.h)
+#define PW_F8_PLACE 2
+#endif
+          if constexpr (PW_F8_PLACE == 0) {           // (measurement: both groups widened in one go)
+            if constexpr (g == 12) widen_group(ic<0>{}, ic<KD>{}, st8[0], st8[1]);
+            if constexpr (g == 20) widen_group(ic<1>{}, ic<VD - kLdsV>{}, st8[2], st8[3]);
+          } else if constexpr (PW_F8_PLACE == 1) {    // K's twelve steps in gaps 5 .. 16, V's in segment 3
+            if constexpr (g >= 5 && g < 17) widen_step(ic<0>{}, ic<KD>{}, ic<(g >= 5 && g < 17) ? g - 5 : 0>{}, st8[0], st8[1]);
+          } else if constexpr (PW_F8_PLACE == 3) {    // both in this segment, thirteen slots each: gaps 5 .. 17, 18 .. 30
+            if constexpr (g >= 5 && g < 18) widen_step8(ic<0>{}, ic<KD>{}, ic<(g >= 5 && g < 18) ? g - 5 : 0>{}, st8[0], st8[1]);
+            if constexpr (g >= 18 && g < 31) widen_step8(ic<1>{}, ic<VD - kLdsV>{}, ic<(g >= 18 && g < 31) ? g - 18 : 0>{}, st8[2], st8[3]);
+          } else {                                     // both in this segment: gaps 5 .. 28
+#if defined(PW_F8_ABL) && PW_F8_ABL == 2
+            if constexpr (g < 0)
+#endif
+            if constexpr (g >= 5 && g < 17) widen_step(ic<0>{}, ic<KD>{}, ic<(g >= 5 && g < 17) ? g - 5 : 0>{}, st8[0], st8[1]);
+#if defined(PW_F8_ABL) && PW_F8_ABL == 2
+            if constexpr (g < 0)
+#endif
+            if constexpr (g >= 17 && g < 29) widen_step(ic<1>{}, ic<VD - kLdsV>{}, ic<(g >= 17 && g < 29) ? g - 17 : 0>{}, st8[2], st8[3]);
+          }
         }
         // (the four waves issue their pieces at the same time and the CU's address unit takes 64 cycles per round of four:
         // eight pieces in eight consecutive gaps stall the issue - K(t+3) here, V(t+2) in segment 3, every other gap)
-        if constexpr (g >= 2 && g < 10 && (g & 1) == 0) dma_piece(ic<((g >= 2 && g < 10) ? (g - 2) / 2 : 0)>{});
+        if constexpr (!KV8 && g >= 2 && g < 10 && (g & 1) == 0) dma_piece(ic<((g >= 2 && g < 10) ? (g - 2) / 2 : 0)>{});
         if constexpr (steady && g >= 10) eop16(ic<0>{}, ic<(g >= 10 ? g - 10 : 0)>{});
       });
       PW_SEG_STAMP(1);
@@ -1363,7 +1579,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       sfor<32>([&](auto GC) __attribute__((always_inline)) {
         constexpr int g = decltype(GC)::value;
         qk16(ic<1>{}, GC);
-        if constexpr (g < 8 && (g & 1) == 0) dma_piece(ic<(g < 8 ? 4 + g / 2 : 4)>{});
+        if constexpr (!KV8 && g < 8 && (g & 1) == 0) dma_piece(ic<(g < 8 ? 4 + g / 2 : 4)>{});
+        if constexpr (KV8 && PW_F8_PLACE == 1 && g < 12) widen_step(ic<1>{}, ic<VD - kLdsV>{}, ic<(g < 12 ? g : 0)>{}, st8[2], st8[3]);
         if constexpr (g == 1) vread16(ic<15>{}, ic<VR>{});
         if constexpr (g >= 3 && g < 10 && (g & 1) == 1) kread16(ic<((g >= 3 && g < 10) ? (g - 3) / 2 : 0)>{}, ic<KR>{});
         if constexpr (steady && g >= 10) eop16(ic<1>{}, ic<(g >= 10 ? g - 10 : 0)>{});
@@ -1439,7 +1656,9 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #ifdef PW_ABL_DMA
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(pg_k) :: "memory");
 #else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k) :: "memory");
+    // (fp8: this iteration's four pieces are waited for where the next one reads them, gap 0 of its first segment)
+    if constexpr (KV8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(pg_k) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" : "+s"(pg_k) :: "memory");
 #endif
     PW_SEG_STAMP(5);
 #ifdef MI355_PW_SEAM
@@ -1465,6 +1684,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     const gptr_t out0 = (gptr_t)uniform64((uint64_t)(I.out_base + (int64_t)(I.q_start + I.tok0) * (int64_t)sa.out_st + (int64_t)(head * G) * (int64_t)sa.out_sh));
     const uint32_t st_b = (uint32_t)sa.out_st * 2u, sh_b = (uint32_t)sa.out_sh * 2u;
     const uint32_t tok_left = (uint32_t)min(I.q_len - I.tok0, sa.BQ);   // tokens of this block inside the sequence
+    const float v_sc8 = (KV8 && kp->p.v_scale != nullptr) ? kp->p.v_scale[0] : 1.0f;
     bool bad[2];                                 // the row left the range the reference-0 arithmetic is good for
     bool bad16[2][2] = {{false, false}, {false, false}};   // M16: per (sub-block, row tile)
     if constexpr (M16) {
@@ -1492,7 +1712,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           const bool row_ok = row_of(I, 2 * x + rt, tok_local, hq);
           if (I.lse_base && row_ok && g4o == 0)
             I.lse_base[(int64_t)(I.q_start + tok_local) * sa.lse_st + hq] = l > 0.0f ? (__builtin_amdgcn_logf(l) - (AL ? al_base[x][rt] + al_sl[x][rt] * (float)I.ctx_len : R16[x][rt][0]) + sc_a) * 0.6931471805599453f : -INFINITY;   // P = 2^(score + R) (SC: 2^(capped score - A + R); AL: the bias as the reference counts it, from the context's end)
-          const float inv = (row_ok && l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;   // (1 ulp: the output is rounded to 16 bits next)
+          float inv = (row_ok && l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;   // (1 ulp: the output is rounded to 16 bits next)
+          if constexpr (KV8) inv *= v_sc8;                 // fp8 cache: V was widened unscaled
           l2[rt] = l; ok2[rt] = row_ok;
           if (__builtin_expect(wide_store, 1)) {
             tile_out(RT, inv, [&](auto DB, wu32x2_t w2) __attribute__((always_inline)) {
@@ -1619,7 +1840,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           if (lane == 0) kp->fix_flags[(int64_t)(I.q_start / kp->fix_bq + I.seq + tok / kp->fix_bq) * sa.num_kv_heads + head] = 1;
           continue;
         }
-        pw_row_fallback<T>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo_row, key_hi, I.out_base, I.lse_base, lane, I.ctx_len);
+        pw_row_fallback<T, KV8>(kp, (const int32_t*)I.bt64, kbase, vbase, I.q_start + tok, head * G + mod_g(m), key_lo_row, key_hi, I.out_base, I.lse_base, lane, I.ctx_len);
       }
     }
   };
@@ -1630,6 +1851,8 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
     const int tile_lo = cur.tile_lo, tile_hi = cur.tile_hi;
     // (every load behind the item - its query rows and its first tiles - has landed: zero_o_and_convert_q waited)
     if (tile_hi > tile_lo) {
+      widen_first_tiles();           // (fp8 cache: K0 K1 K2 V0 V1 from the fp8 they landed as, each wave its own groups)
+      if constexpr (KV8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       if constexpr (M16) sfor<16>([&](auto NC) __attribute__((always_inline)) { kread16(NC, ic<0>{}); });
       else sfor<16>([&](auto NC) __attribute__((always_inline)) { kread(NC, ic<0>{}); });
@@ -1647,7 +1870,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       // have the same barriers, so waves may sit in different ones): unmasked - wholly at or below the wave's first row's
       // last visible key and inside the sequence - with tile t + 4 inside the share and this wave's group of it inside
       // what the Q block can see (then the groups of t + 2, t + 3 are whole). Shifts, not divisions: the terms can be negative.
-      const int steady_hi = 1 + min(min(tile_hi - 5, ((cur.last_group - wave) >> 2) - 4),
+      const int steady_hi = 1 + min(min(tile_hi - 5 - FO, ((cur.last_group - wave) >> 2) - 4 - FO),
                                     min((cur.ctx_len + cur.w_tok_lo - (kPwTile - 1)) >> 6, (cur.seq_len >> 6) - 1));
       // The workgroup walks tile_hi tiles, but a wave's 64 rows see no key past their last row's limit: the tiles from
       // own_hi on are wholly masked for it (G < 4: up to three of a Q block's last four). It computes nothing for
@@ -1728,11 +1951,28 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
       for (; t < tile_hi; ++t) {
         const int ph = (t - tile_lo) % 3;
         const uint32_t kd = (uint32_t)(kLdsK + ph * kSlotBytes) + lds_wave, vd = (uint32_t)(kLdsV + ((ph + 2) % 3) * kSlotBytes) + lds_wave;
-        tail_check(cur, t + 3, ic<0>{});
-        tail_check(cur, t + 2, ic<1>{});
-        const uint64_t kb64 = group_base(cur, t + 3, pg_k, ic<0>{}), vb64 = group_base(cur, t + 2, pg_v, ic<1>{});
+        tail_check(cur, t + 3 + FO, ic<0>{});
+        tail_check(cur, t + 2 + FO, ic<1>{});
+        const uint64_t kb64 = group_base(cur, t + 3 + FO, pg_k, ic<0>{}), vb64 = group_base(cur, t + 2 + FO, pg_v, ic<1>{});
         pg_v = pg_k;
-        pg_k = *(const __attribute__((address_space(4))) int*)(cur.bt64 + (uint32_t)entry_off(cur, t + 4));   // (an ordinary load: see setup)
+        pg_k = *(const __attribute__((address_space(4))) int*)(cur.bt64 + (uint32_t)entry_off(cur, t + 4 + FO));   // (an ordinary load: see setup)
+        if constexpr (KV8) {       // the staging area's turn-over (see iteration), ring slots at run time
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          wu32x4_t s0 = pw_lds_read128<0>(st_rd), s1 = pw_lds_read128<1024>(st_rd), s2 = pw_lds_read128<2048>(st_rd), s3 = pw_lds_read128<3072>(st_rd);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) :: "memory");
+#pragma unroll
+          for (int j = 0; j < 2; ++j) pw_glds16(koff[j], kb64, kLdsS + lds_wave + j * 1024);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) pw_glds16(voff[j], vb64, kLdsS + 2048 + lds_wave + j * 1024);
+          const uint32_t ko = (uint32_t)(ph * kSlotBytes), vo = (uint32_t)(((ph + 2) % 3) * kSlotBytes);
+          wu32x4_t c0, c1;
+          widen16(s0, c0, c1); pw_lds_write128_rt(kw8[0][0] + ko, c0); pw_lds_write128_rt(kw8[0][1] + ko, c1);
+          widen16(s1, c0, c1); pw_lds_write128_rt(kw8[1][0] + ko, c0); pw_lds_write128_rt(kw8[1][1] + ko, c1);
+          widen16(s2, c0, c1); pw_lds_write128_rt(vw8 + vo, c0); pw_lds_write128_rt(vw8 + vo + 16, c1);
+          widen16(s3, c0, c1); pw_lds_write128_rt(vw8 + vo + 2048, c0); pw_lds_write128_rt(vw8 + vo + 2048 + 16, c1);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(pg_k) :: "memory");
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) pw_glds16(koff[j], kb64, kd + j * 1024);
 #pragma unroll
@@ -1792,12 +2032,13 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 #endif
 
 template <typename K>
-static int pw_go(K kernel, const PwArgs& a, int num_kv_heads, hipStream_t stream, std::atomic<uint64_t>& opted) {
-  const int rc1 = ensure_dynamic_lds((const void*)kernel, (int)kPwLds, opted, "hipFuncSetAttribute(prefill_pw)");
+static int pw_go(K kernel, const PwArgs& a, int num_kv_heads, hipStream_t stream, std::atomic<uint64_t>& opted, int lds = kPwLds) {
+  const int rc1 = ensure_dynamic_lds((const void*)kernel, lds, opted, "hipFuncSetAttribute(prefill_pw)");
   if (rc1 != MI355_OK) return rc1;
-  hipLaunchKernelGGL(kernel, dim3(a.slots * num_kv_heads), dim3(256), (size_t)kPwLds, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(a.slots * num_kv_heads), dim3(256), (size_t)lds, stream, a);
   return MI355_OK;
 }
+template <typename T> int launch_pw_fp8(const PwArgs& a, int num_kv_heads, bool e5m2, hipStream_t stream);                       // prefill_pw_fp8.hip
 template <typename T> int launch_pw_feat(const PwArgs& a, int num_kv_heads, bool sw, bool sc, bool al, hipStream_t stream);      // prefill_pw_feat.hip
 template <typename T> int launch_pw_heads(const PwArgs& a, int num_kv_heads, int head_size, bool sw, hipStream_t stream);       // prefill_pw_heads.hip
 
@@ -1810,6 +2051,16 @@ template <typename T> int launch_pw_feat(const PwArgs& a, int num_kv_heads, bool
 }
 template int launch_pw_feat<bf16_t>(const PwArgs&, int, bool, bool, bool, hipStream_t);
 template int launch_pw_feat<f16_t>(const PwArgs&, int, bool, bool, bool, hipStream_t);
+#endif
+
+#if PW_TU == 3
+template <typename T> int launch_pw_fp8(const PwArgs& a, int num_kv_heads, bool e5m2, hipStream_t stream) {
+  static std::atomic<uint64_t> o4{0}, o5{0};
+  if (e5m2) return pw_go(prefill_pw_kernel<T, true, false, false, false, 128, 2>, a, num_kv_heads, stream, o5, kPwLdsF8);
+  return pw_go(prefill_pw_kernel<T, true, false, false, false, 128, 1>, a, num_kv_heads, stream, o4, kPwLdsF8);
+}
+template int launch_pw_fp8<bf16_t>(const PwArgs&, int, bool, hipStream_t);
+template int launch_pw_fp8<f16_t>(const PwArgs&, int, bool, hipStream_t);
 #endif
 
 #if PW_TU == 2
@@ -1838,7 +2089,10 @@ bool prefill_pw_applicable(const mi355_attn_params& p) {
                           p.out_stride_token >= 0 && p.out_stride_token < lim && p.out_stride_head >= 0 && p.out_stride_head < lim;
   // (D = 64 / 96: plain; 96 - Phi-3's head size - also with a sliding window)
   const bool d_ok = p.head_size == 128 || ((p.head_size == 64 || p.head_size == 80 || p.head_size == 96) && p.softcap == 0.0f && !p.alibi_slopes && (p.sliding_window <= 0 || p.head_size == 96));
-  return !feat && strides_ok && d_ok && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && p.kv_dtype == p.q_dtype;
+  // an fp8 cache (round 4, the KV8 instantiations: widened inside the kernel, reference :434-455): plain attention at head size 128
+  const bool fp8 = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
+  const bool kv_ok = p.kv_dtype == p.q_dtype || (fp8 && p.head_size == 128 && p.softcap == 0.0f && !p.alibi_slopes && p.sliding_window <= 0);
+  return !feat && strides_ok && d_ok && G <= kPwRows && (p.q_dtype == MI355_BF16 || p.q_dtype == MI355_F16) && kv_ok;
 }
 
 template <typename T>
@@ -1893,7 +2147,10 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   const bool d64 = p.head_size == 64, d96 = p.head_size == 96, d80 = p.head_size == 80;
   const bool m16 = m16_env || sw || sc || al || d64 || d96 || d80 || !__is_same(T, bf16_t);      // the 32x32x16 instantiation: bf16, D = 128, no window, no soft-cap, no ALiBi
   int rc_l = MI355_OK;
-  if (d64 || d80 || d96) {
+  const bool fp8 = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;
+  if (fp8) {
+    rc_l = launch_pw_fp8<T>(a, p.num_kv_heads, p.kv_dtype == MI355_FP8_E5M2, stream);
+  } else if (d64 || d80 || d96) {
     rc_l = launch_pw_heads<T>(a, p.num_kv_heads, p.head_size, sw, stream);
   } else if (al || sc) {
     rc_l = launch_pw_feat<T>(a, p.num_kv_heads, sw, sc, al, stream);
@@ -1909,7 +2166,7 @@ static int launch_pw_t(const mi355_attn_params& p, int key_splits, int64_t out_s
   }
   if (rc_l != MI355_OK) return rc_l;
   const int rc = check_hip(hipGetLastError(), "prefill_pw_kernel launch");
-  if (rc == MI355_OK) set_kernel_name(al ? "prefill_mfma_pw_al" : sc ? (sw ? "prefill_mfma_pw_sw_sc" : "prefill_mfma_pw_sc") : sw ? "prefill_mfma_pw_sw" : "prefill_mfma_pw");
+  if (rc == MI355_OK) set_kernel_name(fp8 ? "prefill_mfma_pw_fp8" : al ? "prefill_mfma_pw_al" : sc ? (sw ? "prefill_mfma_pw_sw_sc" : "prefill_mfma_pw_sc") : sw ? "prefill_mfma_pw_sw" : "prefill_mfma_pw");
   return rc;
 }
 

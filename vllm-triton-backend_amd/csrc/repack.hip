@@ -307,8 +307,13 @@ mi355_attn_params repacked_params(const mi355_attn_params& p, void* scratch, siz
 // moves 3 bytes per cache element once, the attention does 2 q G flops per element: worth it when the sequences bring
 // many query rows (avg query_len * G >= 4096: the pass is then <= 15 % of the attention's time).
 static bool fp8_prefill_through_scratch(const mi355_attn_params& p) {
-  static const bool off = [] { const char* e = lab_env("MI355_FP8_PREFILL_SCRATCH"); return e && e[0] == '0'; }();   // A/B
+  static const char* const pin = lab_env("MI355_FP8_PREFILL_SCRATCH");   // A/B: 0 = never, 1 = also where the kernel reads fp8 itself
+  const bool off = pin && pin[0] == '0', forced = pin && pin[0] == '1';
   if (off || !is_fp8(p.kv_dtype) || p.k_new || p.max_seqlen_q <= 1 || p.max_seqlen_k < 2048) return false;
+  // Round 4: plain attention at head size 128 needs no scratch - prefill_pw_kernel's KV8 instantiations take the fp8 tiles by
+  // LDS-DMA and widen them on their way into the rings. What is left for this route: the window / soft-cap / ALiBi / small-head
+  // instantiations, which only read 16-bit tiles.
+  if (!forced && prefill_pw_applicable(p)) return false;
   // (soft-cap, and ALiBi by itself: the 64-rows-per-wave kernel's SC / AL instantiations serve them)
   if (p.alibi_slopes && (p.softcap > 0.0f || p.sliding_window > 0)) return false;
   if (!(p.head_size == 128 || ((p.head_size == 64 || p.head_size == 80 || p.head_size == 96) && !p.alibi_slopes && p.softcap == 0.0f && (p.sliding_window <= 0 || p.head_size == 96)))) return false;   // (what prefill_pw_applicable serves)
