@@ -26,9 +26,13 @@
 extern "C" {
 #endif
 
-#define MI355_ATTN_VERSION 600 /* major*10000 + minor*100 + patch */
+#define MI355_ATTN_VERSION 601 /* major*10000 + minor*100 + patch */
 /*
  * Version notes (what a caller written against an older header must know)
+ *   0.6.1  No change to the structs or the entry points. A prefill over an fp8 flash-layout cache (plain attention, head size
+ *          128, >= 2048 keys) is read as fp8 by the fast prefill kernel itself ("prefill_mfma_pw_fp8"): such a call no
+ *          longer asks for a 16-bit scratch cache - mi355_attn_workspace_bytes() answers the 256 KiB counter block, or
+ *          the key-split partials - and is served whatever the step's mix of prefill and decode rows.
  *   0.6.0  write_new_kv is accepted for steps with prefill rows too (see the field): mi355_decode_write_fusable() answers 1
  *          for them where the short-prompt kernel or an LDS-DMA kernel serves the prefill rows. Nothing else changes.
  *   0.5.1  No change to the structs or the entry points. The workspace's zero-filled 256 KiB head is now two regions:
@@ -295,7 +299,8 @@ MI355_API size_t mi355_attn_workspace_bytes(const mi355_attn_params* p);
  *     flash-layout scratch cache in the workspace (num_seqs * ceil(max_seqlen_k / 16) pages of K and V), the kernels
  *     above run on that; query_len == 1 rows of a mixed batch read the caller's cache directly when the v0 decode
  *     kernel covers it ("repack+<prefill kernel>[+<decode kernel>]")
- *     (an fp8 cache is dequantised into the 16-bit scratch: (fp8 -> f32) * scale -> query type)
+ *     (an fp8 cache is dequantised into the 16-bit scratch: (fp8 -> f32) * scale -> query type; since 0.6.1 a plain fp8
+ *     flash-layout prefill at head size 128 does not come this way: "prefill_mfma_pw_fp8" widens the tiles itself)
  *   everything else (f32, head sizes that are not a multiple of 8 or exceed 256, ...) -> "generic".
  */
 MI355_API int mi355_unified_attention(const mi355_attn_params* p, void* workspace, size_t workspace_bytes,
