@@ -242,6 +242,30 @@ def test_lds_dma_and_latency_prefill_kernels_use_no_scratch(tmp_path):
     assert seen >= 8, seen
 
 
+def test_the_build_refuses_a_kernel_whose_owned_registers_the_compiler_touched(tmp_path):
+    """__graft_entry__.build() audits the device assembly of the units whose kernels own accumulator registers through
+    asm statements: compiler-emitted v_accvgpr_* or scratch traffic outside the asm blocks fails the build.
+    A synthetic assembly file: one clean kernel, one in which the compiler parked a value in a0."""
+    import __graft_entry__ as g
+
+    clean = """
+_ZN5mi35517prefill_pw_kernelINS_6bf16_tELb1EEEvNS_6PwArgsE: ; @x
+\ts_load_dword s0, s[4:5], 0x0
+\t;;#ASMSTART
+\tv_accvgpr_write_b32 a0, 0
+\t;;#ASMEND
+\tv_mov_b32_e32 v1, v2
+.end_amdhsa_kernel
+"""
+    dirty = clean.replace("bf16_t", "5f16_t").replace("\tv_mov_b32_e32 v1, v2", "\tv_accvgpr_write_b32 a0, v221\n\tscratch_store_dword off, v3, s0")
+    f = tmp_path / "x.s"
+    f.write_text(clean + dirty)
+    bad = g._audit_owned_registers(str(f), "prefill_pw_kernel")
+    assert [(k.count("f16_t"), t.split()[0]) for k, _, t in bad] == [(1, "v_accvgpr_write_b32"), (1, "scratch_store_dword")], bad
+    assert g._audit_owned_registers(str(f), "Li256E") == []
+    assert set(g.AUDITED) >= {"prefill_pw.hip", "prefill_pw_feat.hip", "prefill_pw_heads.hip", "prefill_pw_fp8.hip", "prefill_mfma.hip"}
+
+
 def test_one_version_number(lib):
     """include/mi355_attn.h is the version source: the library, the Python package and setup.py report it."""
     import mi355_attn
