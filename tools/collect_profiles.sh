@@ -43,6 +43,15 @@ for v in "f16:--dtype f16" "sw1024:--window 1024" "fp8:--kvdtype fp8" "sc30:--so
   PMC_PASSES=1 python3 $REPO/tools/pmc_collect.py $OUT/pmc_v prefill_pw_kernel -- python3 $REPO/tools/bench_prefill.py --iters 5 $args > $OUT/pmc_variant_$name.txt 2>&1; grep -i "mfma\|busy" $OUT/pmc_variant_$name.txt | head -6
   rm -rf $OUT/pmc_v
 done
+echo "== fp8 cache: the kernel's own fp8 form vs the dequantising scratch vs a bf16 cache (same box), and a vLLM-shaped fp8 step"
+for a in "--batch 1 --seq 4096" "--batch 16 --seq 4096" "--batch 1 --seq 16384" "--batch 1 --seq 4096 --ctx 2048"; do
+  python3 $REPO/tools/bench_prefill.py $a --kvdtype fp8 2>&1 | grep -v amdgpu.ids | sed "s/^/fp8 direct:  /"
+  MI355_FP8_PREFILL_SCRATCH=1 python3 $REPO/tools/bench_prefill.py $a --kvdtype fp8 2>&1 | grep -v amdgpu.ids | sed "s/^/fp8 scratch: /"
+  python3 $REPO/tools/bench_prefill.py $a 2>&1 | grep -v amdgpu.ids | sed "s/^/bf16:        /"
+done > $OUT/fp8_prefill.log 2>&1
+python3 $REPO/tools/bench_fp8_step.py 2>&1 | grep -v amdgpu.ids >> $OUT/fp8_prefill.log
+python3 $REPO/tools/bench_fp8_step.py --kvdtype same 2>&1 | grep -v amdgpu.ids >> $OUT/fp8_prefill.log
+cut -c1-75,170- $OUT/fp8_prefill.log
 echo "== SQ counters, prefill_pw_kernel at C2"
 PMC_PASSES=0,1,2,3,4 MI355_PREFILL=pw python3 $REPO/tools/pmc_collect.py $OUT/pmc_prefill prefill_pw_kernel -- python3 $REPO/tools/bench_prefill.py --iters 5 > $OUT/pmc_prefill.txt 2>&1; cat $OUT/pmc_prefill.txt
 echo "== SQ counters, fp8 decode at C5"

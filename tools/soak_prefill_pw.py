@@ -34,7 +34,7 @@ def case(rng):
         feat = "plain"                     # (head sizes 64 / 96 are on the 64-rows-per-wave kernel without features)
     return dict(d=d, q_lens=q_lens, kv_lens=kv_lens, hq=hk * g, hk=hk, page=rng.choice([16, 16, 32, 64]), dtype=rng.choice([torch.bfloat16, torch.float16]),
                 window=rng.choice([9, 64, 300, 1000]) if "window" in feat else 0, softcap=rng.choice([20.0, 50.0]) if "softcap" in feat else 0.0,
-                alibi=feat == "alibi", kv_dtype=rng.choice([None, None, None, torch.float8_e4m3fn]))
+                alibi=feat == "alibi", kv_dtype=rng.choice([None, None, torch.float8_e4m3fn, torch.float8_e5m2]))
 
 
 def main():
