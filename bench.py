@@ -21,6 +21,7 @@ Three more workloads are timed the same way right after it and reported in the s
                                                                                      -> KV GB/s, strong scaling
   "prefill_512" the reference's own latency regime (scripts/bench_vllm_latency_range.py:48-50): one 512-token prompt per GPU
                                                                                      -> us per launch (and TFLOP/s)
+  "prefill_fp8" C2's shape over an fp8-e4m3 cache (round 4: the prefill kernel widens the fp8 tiles itself) -> TFLOP/s
 `--verify-gather` (prefill_b8): the ranks' outputs assembled by ONE all_gather (parallel.gather_outputs) and compared with
 the unsharded batch computed on rank 0 (bitwise: same kernel, same per-unit arithmetic order).
 Multi-GPU: the path shards over sequences with no data-path collective: C2/C3/C5 are weak scaling
@@ -52,7 +53,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 # 20 times right after its inputs were generated measures the device's clock/power ramp out of idle, not the kernel.
 PREWARM_S = float(os.environ.get("MI355_BENCH_PREWARM_S", "0.25"))
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
-ALL_LEGS = ("prefill", "decode", "decode_fp8", "mixed", "prefill_b8", "decode_b64", "prefill_512")
+ALL_LEGS = ("prefill", "decode", "decode_fp8", "mixed", "prefill_b8", "decode_b64", "prefill_512", "prefill_fp8")
 GLOBAL_LEGS = ("mixed", "prefill_b8", "decode_b64")       # ONE batch (same seed on every rank) dealt to the ranks: strong scaling
 
 
@@ -139,6 +140,8 @@ def make_workload(kind, device, seed, rank, world):
         Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 1, 4096, 4096, dt
     elif kind == "prefill_512":   # the latency regime: one 512-token prompt
         Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 1, 512, 512, dt
+    elif kind == "prefill_fp8":   # C2 over an fp8-e4m3 cache: the prefill kernel reads (and widens) the fp8 tiles itself, no 16-bit scratch
+        Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 1, 4096, 4096, torch.float8_e4m3fn
     elif kind == "decode":     # C3
         Hq, Hk, D, B, q_len, kv_len, kvdt = 32, 8, 128, 64, 1, 8192, dt
     else:                      # C5 "decode_fp8": Llama-3-70B shape, fp8-e4m3 KV (batch not given in BASELINE: 16)
@@ -155,7 +158,7 @@ def make_workload(kind, device, seed, rank, world):
     w = dict(kind=kind, q=q, k_cache=k, v_cache=v, block_table=bt, cu_seqlens_q=cu, seqused_k=sl, out=torch.empty_like(q), B=B, q_len=q_len,
              kv_len=kv_len, Hq=Hq, Hk=Hk, D=D, scale=1.0 / math.sqrt(D), global_work=False,
              k_scale=torch.ones(1, device=device) if kvdt != dt else None)
-    if kind in ("prefill", "prefill_512"):
+    if kind in ("prefill", "prefill_512", "prefill_fp8"):
         w["flops"] = 4.0 * q_len * kv_len * D * Hq / 2 * B
         w["bytes"] = (2 * q.numel() + 2 * B * kv_len * Hk * D) * 2.0
     else:
@@ -407,6 +410,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max, launch_max = t.tolist()
         results[kind] = dict(w=w, kernel=kernel, wall=wall_max, per_launch=launch_max)
+        if kind == "prefill_fp8":
+            import ctypes
+            results[kind]["workspace_bytes"] = int(_lib.load().mi355_attn_workspace_bytes(ctypes.byref(w["_keep"][0])))
         if kind == "prefill_b8" and args.verify_gather:
             results[kind]["gather"] = verify_gather(w, device, distributed)
         for key in ("shard", "whole"):
@@ -420,6 +426,7 @@ def main():
         K = args.steps
         pf, dc, d8, mx = results.get("prefill"), results.get("decode"), results.get("decode_fp8"), results.get("mixed")
         b8, d64, p512 = results.get("prefill_b8"), results.get("decode_b64"), results.get("prefill_512")
+        pf8 = results.get("prefill_fp8")
         line = {"legs": legs}
         if pf:
             pf_val = pf["w"]["flops"] * n_gpus * K / pf["wall"] / 1e12
@@ -484,6 +491,14 @@ def main():
                                    "us_per_launch_events": round(p512["per_launch"] * 1e6, 2),
                                    "config": {"workload": "Hq32/Hk8/D128, 1 seq x 512 tokens per GPU, causal, paged KV (16-token pages), launches back to back",
                                               "kernel": p512["kernel"]}}
+        if pf8:
+            pf8_val = pf8["w"]["flops"] * n_gpus * K / pf8["wall"] / 1e12
+            line["prefill_fp8"] = {"metric": "attn fwd TFLOPS (prefill over an fp8-e4m3 KV cache, bf16 queries)", "value": round(pf8_val, 2), "unit": "TFLOP/s",
+                                   "ms_per_step": round(pf8["wall"] / K * 1e3, 4), "frac_of_mfma_peak": round(pf8_val / n_gpus / MFMA_BF16_PEAK_TFLOPS, 4),
+                                   "workspace_bytes": pf8.get("workspace_bytes"),
+                                   "config": {"workload": "C2's shape over an fp8-e4m3 cache: Hq32/Hk8/D128, 1 seq x 4096 tokens per GPU, causal, paged KV (16-token pages), "
+                                                          "scales 1.0; the tiles are widened inside the kernel (reference :434-455), no 16-bit copy of the cache",
+                                              "kernel": pf8["kernel"]}}
         if n_gpus == 1 and not args.no_cpu_baseline:
             if pf:
                 line["cpu_baseline"] = cpu_baseline(pf["w"], pf["w"]["out"])

@@ -164,7 +164,7 @@ def test_bench_one_gpu_gather_check_and_new_legs():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--legs", "prefill_b8,decode_b64,prefill_512", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--legs", "prefill_b8,decode_b64,prefill_512,prefill_fp8", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline", "--verify-gather"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MI355_BENCH_PREWARM_S="0.02"), timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -173,3 +173,6 @@ def test_bench_one_gpu_gather_check_and_new_legs():
     assert line["decode_b64"]["unit"] == "GB/s" and line["decode_b64"]["value"] > 1000
     assert line["prefill_512"]["unit"] == "us" and 3 < line["prefill_512"]["value"] < 200
     assert line["prefill_512"]["config"]["kernel"] == "prefill_mfma_lat"
+    # C2's shape over an fp8 cache: the prefill kernel's own fp8 form, the workspace is the 256 KiB counter block
+    assert line["prefill_fp8"]["config"]["kernel"] == "prefill_mfma_pw_fp8" and line["prefill_fp8"]["workspace_bytes"] == 256 << 10
+    assert line["prefill_fp8"]["frac_of_mfma_peak"] > 0.3

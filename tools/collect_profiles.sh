@@ -16,7 +16,7 @@ echo "== bench.py (default protocol)"
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench.py failed"
 tail -c 3000 $OUT/bench.json
 echo "== rocprofv3 --kernel-trace --stats of bench.py, one leg per run (a kernel symbol serves several legs)"
-for leg in prefill decode decode_fp8 mixed prefill_b8 decode_b64 prefill_512; do
+for leg in prefill decode decode_fp8 mixed prefill_b8 decode_b64 prefill_512 prefill_fp8; do
   rm -rf $OUT/stats_$leg && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$leg -- python3 $REPO/bench.py --no-cpu-baseline --legs $leg > $OUT/stats_bench_$leg.json 2> $OUT/stats_$leg.err
   f=$(find $OUT/stats_$leg -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats_$leg.csv; cut -c1-230 $OUT/bench_kernel_stats_$leg.csv; fi
