@@ -32,7 +32,8 @@ extern "C" {
  *   0.6.1  No change to the structs or the entry points. A prefill over an fp8 flash-layout cache (plain attention, head size
  *          128, >= 2048 keys) is read as fp8 by the fast prefill kernel itself ("prefill_mfma_pw_fp8"): such a call no
  *          longer asks for a 16-bit scratch cache - mi355_attn_workspace_bytes() answers the 256 KiB counter block, or
- *          the key-split partials - and is served whatever the step's mix of prefill and decode rows.
+ *          the key-split partials - and is served whatever the step's mix of prefill and decode rows. Short fp8 prompts
+ *          (what the short-prompt kernel serves for 16-bit caches) run on that kernel's fp8 form ("prefill_mfma_lat_fp8").
  *   0.6.0  write_new_kv is accepted for steps with prefill rows too (see the field): mi355_decode_write_fusable() answers 1
  *          for them where the short-prompt kernel or an LDS-DMA kernel serves the prefill rows. Nothing else changes.
  *   0.5.1  No change to the structs or the entry points. The workspace's zero-filled 256 KiB head is now two regions:

@@ -135,3 +135,45 @@ def test_rows_that_leave_the_range_are_recomputed_from_the_fp8_cache():
         assert kernel.startswith("prefill_mfma_pw_fp8"), kernel
         atol, rtol = golden_io.tolerance(dtype, torch.float8_e4m3fn)
         torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+# ---- short prompts: the latency kernel's fp8 form (csrc/prefill_lat.hip, KV8 instantiations) ---------------------------------
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kv_dtype", FP8)
+@pytest.mark.parametrize("tokens", [512, 500, 1024, 17])
+def test_one_short_prompt_over_an_fp8_cache(dtype, kv_dtype, tokens):
+    """The reference protocol's shape (batch 1, ~500 input tokens, Hq 32 / Hk 8 / D 128) with an fp8 cache: eight waves per Q
+    block at 512 tokens, four at 1024; 17 tokens leave most of the only Q block's rows empty and the only tile's groups short."""
+    ks, vs = 0.37, 0.61
+    inp = orc.make_paged_inputs(300 + tokens, [tokens], [tokens], 32, 8, 128, 16, dtype, kv_dtype=kv_dtype, kv_scale=ks)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], k_scale=ks, v_scale=vs, mode="2d", block_n=64)
+    d, out, kernel = _run(inp, ks, vs)
+    assert kernel == "prefill_mfma_lat_fp8", kernel
+    atol, rtol = golden_io.tolerance(dtype, kv_dtype)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("hq,hk", [(8, 2), (4, 4), (6, 2), (32, 1)])
+@pytest.mark.parametrize("page", [16, 64])
+def test_ragged_chunks_over_an_fp8_cache_on_the_latency_kernel(hq, hk, page):
+    """Prefill-only ragged batches with contexts (chunked prefill), sequences that end inside a 16-key group and inside a tile,
+    group sizes that leave padding rows, a mixed step whose decode rows ride the split-KV kernel's fp8 form."""
+    import gpu_util
+
+    query_lens = [5, 129, 64, 33, 200, 2, 1]
+    kv_lens = [5, 129, 257, 100, 777, 1500, 900]
+    ks, vs = 0.5, 1.75
+    inp = orc.make_paged_inputs(331, query_lens, kv_lens, hq, hk, 128, page, torch.bfloat16, kv_dtype=torch.float8_e4m3fn, kv_scale=ks)
+    ref = orc.unified_attention_oracle(inp["q"], inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"],
+                                       inp["scale"], k_scale=ks, v_scale=vs, mode="2d", block_n=64)
+    d = gpu_util.to_dev(inp)
+    lse = torch.full((inp["q"].shape[0], hq), float("nan"), dtype=torch.float32, device=gpu_util.DEV)
+    out, kernel = gpu_util.run_unified(d, inp["scale"], kv_scale=ks, v_scale=vs, lse=lse)
+    assert kernel.startswith("prefill_mfma_lat_fp8+decode_") if hq // hk <= 8 else "prefill" in kernel, kernel
+    assert not torch.isnan(out).any() and not torch.isnan(lse).any()
+    atol, rtol = golden_io.tolerance(torch.bfloat16, torch.float8_e4m3fn)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)
+    out9, _ = gpu_util.run_unified(d, inp["scale"], kv_scale=ks, v_scale=vs, force=9, lse=(lse9 := torch.full_like(lse, float("nan"))))
+    torch.testing.assert_close(lse, lse9, atol=5e-2, rtol=0)

@@ -26,7 +26,9 @@ namespace mi355 {
 // getenv for the measurement switches: nullptr unless the process also carries MI355_LAB=1 (read once).
 inline const char* lab_env(const char* name) {
   static const bool lab = [] { const char* e = std::getenv("MI355_LAB"); return e && e[0] && e[0] != '0'; }();
-  return lab ? std::getenv(name) : nullptr;
+  if (!lab) return nullptr;
+  const char* e = std::getenv(name);
+  return (e && e[0]) ? e : nullptr;          // (a variable set to the empty string is an unset one: `VAR=$x cmd` with an empty x pins nothing)
 }
 
 // ---------------------------------------------------------------------------------------------

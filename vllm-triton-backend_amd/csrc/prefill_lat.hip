@@ -24,6 +24,7 @@
 // (launch_prefill, prefill_mfma.hip) picks it where the key range is short and the wider kernels' grids underfill the chip.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -109,8 +110,16 @@ __device__ __forceinline__ void lat_glds16(uint32_t voff, uint64_t sbase, uint32
 //   NKQ 4: eight waves (two per SIMD), 128-key tiles, 128 KiB - one workgroup per CU with twice the waves on a Q block's
 //          keys: the form for launches of at most one workgroup per CU, where the heaviest Q block IS the launch.
 // WR: the instantiation that carries the fused cache write (write_new_kv) - apart, so that the plain one keeps its stream.
-template <typename T, int NKQ, bool WR = false>
+// KV8: an fp8 cache (1 = e4m3, 2 = e5m2; reference :434-455 dequantises on load), the scheme of prefill_pw_kernel's KV8
+// instantiations: a wave's 16-key group of the next tile travels as fp8 - two 1 KiB pieces per matrix instead of four - into
+// a 4 KiB staging area of the wave behind the stages; when it has landed (the wait the loop has anyway) the same wave widens
+// it (v_cvt_scalef32_pk_*: exact) into the rows the 16-bit LDS-DMA would have filled, swizzle included, in front of the
+// tile's barrier. k_scale rides in Q', v_scale in 1 / l.
+template <typename T, int NKQ, bool WR = false, int KV8 = 0>
 __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kernel(const LatArgs a) {
+  static_assert(!(WR && KV8), "the fused cache write is built for 16-bit caches");
+  constexpr int EB = KV8 ? 1 : 2;                   // bytes per cache element
+  using KVT = std::conditional_t<KV8 == 2, e5m2_t, std::conditional_t<KV8 == 1, e4m3_t, T>>;
   constexpr int D = 128, ROWB = D * 2;              // 256-byte rows of 16 chunks of 16 bytes
   constexpr int NW = 2 * NKQ, TILE = 32 * NKQ;      // waves; keys per staged tile (one 16-key group per wave)
   constexpr int KBUF = TILE * ROWB, STAGE = 2 * KBUF;   // K tile then V tile
@@ -177,8 +186,8 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
 
   // ---- LDS-DMA staging (the 4-wave form of prefill_dma_kernel): lane handles chunk (row = tid >> 4, c = tid & 15) of a
   // 16-row piece; a tile is four pieces of K and of V --------------------------------------------------------------------
-  const char* kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * 2;
-  const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * 2;
+  const char* kbase = (const char*)p.k_cache + (int64_t)head * p.k_stride_head * EB;
+  const char* vbase = (const char*)p.v_cache + (int64_t)head * p.v_stride_head * EB;
   const int last_group = (max(n_keys_wg, 1) - 1) >> 4;
   const int page_mask = p.page_size - 1;
   // fused cache write (see issue_dma): the linear key / value rows of this KV head, and this Q block's own tokens stored
@@ -215,8 +224,13 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
     k_voff[j] = (uint32_t)(rig * (int)a.k_slot_stride * 2 + ((ch ^ rig) << 4));
     v_voff[j] = (uint32_t)(rig * (int)a.v_slot_stride * 2 + ((ch ^ (2 * (rig & 7))) << 4));
   }
-  const uint32_t k_page_bytes = a.k_page_stride * 2, v_page_bytes = a.v_page_stride * 2;
+  const uint32_t k_page_bytes = a.k_page_stride * EB, v_page_bytes = a.v_page_stride * EB;
   const uint32_t smem_base = lds_addr(smem);
+  // fp8 cache: a piece covers eight 128-byte key rows, unswizzled (the widening write applies the swizzle); lane = (row lane >> 3,
+  // 16-byte piece lane & 7 = head dims 16 c8 .. + 15)
+  const int r8 = lane >> 3, c8 = lane & 7;
+  char* const stg = smem + NST * STAGE + wave * 4096;          // this wave's staging area: K group, then V group
+  const uint32_t stg_lds = smem_base + NST * STAGE + (uint32_t)wave * 4096;
   auto issue_dma = [&](int tile, uint32_t stage_off) {
     const int e0 = (min(tile * NW, last_group) << 4) >> a.page_shift;
     if ((e0 >> 6) != bt_chunk) {            // wave-uniform; entries only ever move forward
@@ -228,10 +242,20 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
     const int key0 = gi << 4;
     const int slot0 = key0 & page_mask;
     const uint32_t page = (uint32_t)__builtin_amdgcn_readlane(bt_cur, (key0 >> a.page_shift) & 63);
-    const uint64_t k_off = (uint64_t)page * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * 2;
-    const uint64_t v_off = a.kv_same_strides ? k_off : (uint64_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * 2;
+    const uint64_t k_off = (uint64_t)page * k_page_bytes + (uint64_t)((uint32_t)slot0 * a.k_slot_stride) * EB;
+    const uint64_t v_off = a.kv_same_strides ? k_off : (uint64_t)page * v_page_bytes + (uint64_t)((uint32_t)slot0 * a.v_slot_stride) * EB;
     const uint64_t kb = (uint64_t)kbase + k_off, vb = (uint64_t)vbase + v_off;
     const uint32_t dst = smem_base + stage_off + (uint32_t)wave * (16 * ROWB);
+    if constexpr (KV8) {       // two pieces per matrix into the staging area; rows past the sequence fetch its last row
+      const int maxr = max(seq_len - 1 - key0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = min(8 * j + r8, maxr);
+        lat_glds16((uint32_t)(r * (int)a.k_slot_stride + (c8 << 4)), kb, stg_lds + j * 1024);
+        lat_glds16((uint32_t)(r * (int)a.v_slot_stride + (c8 << 4)), vb, stg_lds + 2048 + j * 1024);
+      }
+      return;
+    }
     if (fused && key0 + 16 > ctx_len) {        // (fused: compile time)
       // FUSED CACHE WRITE (write_new_kv): keys at positions >= ctx_len are this call's own tokens and come from the linear
       // key / value tensors, never from the cache (whoever stores them - the Q block that owns the token, above - need not have
@@ -274,6 +298,26 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
       }
     }
   };
+  // fp8: this wave's staged group (landed: the caller waited) widened into its sixteen rows of stage `stage_off`
+  auto widen_staged = [&](uint32_t stage_off) {
+    if constexpr (KV8) {
+      char* const kd = smem + stage_off + wave * (16 * ROWB);
+      char* const vd = kd + KBUF;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)            // K, V
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const lu32x4_t in = *(const lu32x4_t*)(stg + m * 2048 + j * 1024 + lane * 16);
+          uint32_t o[8];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) widen_fp8x4<T, KVT>(in[w], o[2 * w], o[2 * w + 1]);
+          const int rig = 8 * j + r8, f = m ? 2 * (rig & 7) : rig;
+          char* const row = (m ? vd : kd) + rig * ROWB;
+          *(lu32x4_t*)(row + (((2 * c8) ^ f) << 4)) = lu32x4_t{o[0], o[1], o[2], o[3]};
+          *(lu32x4_t*)(row + (((2 * c8 + 1) ^ f) << 4)) = lu32x4_t{o[4], o[5], o[6], o[7]};
+        }
+    }
+  };
 #pragma unroll
   for (int t = 0; t < PD; ++t)
     if (t < tile_hi) issue_dma(t, t * STAGE);
@@ -298,7 +342,8 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
 #pragma unroll
   for (int b = 0; b < DBLK; ++b) v_ch[b] = (uint32_t)(((2 * b + (pp >> 1)) ^ vsw) << 4);
 
-  const float scale2 = p.scale * kLatLog2e;
+  const float scale2 = p.scale * kLatLog2e * ((KV8 && p.k_scale) ? p.k_scale[0] : 1.0f);     // (fp8: K is widened unscaled)
+  const float v_sc = (KV8 && p.v_scale) ? p.v_scale[0] : 1.0f;
   // Softmax state per row (column group): a REFERENCE m_ref instead of a running maximum - P = 2^(s - m_ref) is the same
   // softmax for any reference as long as P stays in range - moved only when a row's tile maximum exceeds it by 2^kLatDefer
   // (the 4-wave kernel's scheme, prefill_mfma.hip): a calm tile costs no exchange across the lane groups and no rescaling
@@ -333,6 +378,7 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
     for (int c = 0; c < KSTEPS; ++c) asm volatile("" : "+v"(qf[cg][c]));
   LAT_WG_STAMP(wg_tb);   // Q landed, first tiles requested
   wait_next_tile(max(0, min(PD - 1, tile_hi - 1)));      // the first tile has landed
+  if (tile_hi > 0) widen_staged(0);
   __syncthreads();
   LAT_WG_STAMP(wg_t1);
 
@@ -433,6 +479,7 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
         if (t + PD < tile_hi) issue_dma(t + PD, ((u + PD) % NST) * STAGE);
         if (t * TILE + kh * 32 < wave_keys) compute_tile(t, cur);
         wait_next_tile(max(0, min(t + PD, tile_hi - 1) - (t + 1)));     // this wave's pieces of tile t+1 have landed ...
+        if (t + 1 < tile_hi) widen_staged(((u + 1) % NST) * STAGE);     // (fp8: ... in its staging area; widened into tile t+1's stage, which tile t-1 left at the last barrier)
         __syncthreads();                                 // ... and so have everyone else's; stage `cur` is free
       }
     }
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(128 * NKQ, NKQ == 2 ? 2 : 1) void prefill_lat_kerne
     const int tok = q_start + tok_local[cg], hqx = hq[cg];
     if (p.lse && ok && grp == 0 && kh == 0)
       p.lse[(int64_t)tok * p.lse_stride_token + hqx] = l_all > 0.0f ? (m_all + __builtin_amdgcn_logf(l_all)) * kLatLn2 : -INFINITY;
-    const float inv = l_all > 0.0f ? 1.0f / l_all : 0.0f;        // a row that sees no key: 0 (:494)
+    const float inv = l_all > 0.0f ? v_sc / l_all : 0.0f;        // a row that sees no key: 0 (:494)
     uint16_t* op = (uint16_t*)p.out + (int64_t)tok * p.out_stride_token + (int64_t)hqx * p.out_stride_head + 4 * grp;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -547,10 +594,11 @@ bool prefill_lat_applicable(const mi355_attn_params& p) {
   if (!prefill_supported(p)) return false;
   const bool feat = p.softcap > 0.0f || p.alibi_slopes != nullptr || p.sliding_window > 0;
   const int G = p.num_q_heads / p.num_kv_heads;
-  return !feat && p.head_size == 128 && p.kv_dtype == p.q_dtype && G <= kLatRows && ((uintptr_t)p.out & 7) == 0;
+  const bool fp8 = p.kv_dtype == MI355_FP8_E4M3 || p.kv_dtype == MI355_FP8_E5M2;      // (round 4: its KV8 instantiations; no fused cache write there)
+  return !feat && p.head_size == 128 && (p.kv_dtype == p.q_dtype || (fp8 && !p.write_new_kv)) && G <= kLatRows && ((uintptr_t)p.out & 7) == 0;
 }
 
-template <typename T, int NKQ, bool WR>
+template <typename T, int NKQ, bool WR, int KV8 = 0>
 static int launch_lat_t(const mi355_attn_params& p, hipStream_t stream) {
   LatArgs a;
   a.p = p;
@@ -563,13 +611,15 @@ static int launch_lat_t(const mi355_attn_params& p, hipStream_t stream) {
   const int qblocks = p.num_tokens / a.block_q + p.num_seqs;    // static upper bound (:886-889,:935-943)
   // two stages of a K and a V tile; the waves' partials meet in the same bytes afterwards (a little more than the stages)
   constexpr size_t stages = (size_t)2 * 2 * (32 * NKQ) * 256, xch = (size_t)2 * NKQ * (2 * 8 * 1024 + 1024);
-  constexpr size_t lds = stages > xch ? stages : xch;
+  constexpr size_t staging = KV8 ? (size_t)2 * NKQ * 4096 : 0;       // fp8: 4 KiB per wave behind the stages
+  constexpr size_t lds = (stages + staging > xch ? stages + staging : xch);
+  static_assert(lds <= 160 * 1024, "prefill_lat_kernel: LDS");
   static std::atomic<uint64_t> lds_opt_in{0};
-  const int rc0 = ensure_dynamic_lds((const void*)prefill_lat_kernel<T, NKQ, WR>, (int)lds, lds_opt_in, "hipFuncSetAttribute(prefill_lat)");
+  const int rc0 = ensure_dynamic_lds((const void*)prefill_lat_kernel<T, NKQ, WR, KV8>, (int)lds, lds_opt_in, "hipFuncSetAttribute(prefill_lat)");
   if (rc0 != MI355_OK) return rc0;
-  hipLaunchKernelGGL((prefill_lat_kernel<T, NKQ, WR>), dim3(qblocks * p.num_kv_heads), dim3(128 * NKQ), lds, stream, a);
+  hipLaunchKernelGGL((prefill_lat_kernel<T, NKQ, WR, KV8>), dim3(qblocks * p.num_kv_heads), dim3(128 * NKQ), lds, stream, a);
   const int rc = check_hip(hipGetLastError(), "prefill_lat_kernel launch");
-  if (rc == MI355_OK) set_kernel_name("prefill_mfma_lat");
+  if (rc == MI355_OK) set_kernel_name(KV8 ? "prefill_mfma_lat_fp8" : "prefill_mfma_lat");
   return rc;
 }
 
@@ -581,6 +631,14 @@ int launch_prefill_lat(const mi355_attn_params& p, hipStream_t stream) {
   const long wgs = ((long)p.num_tokens / (kLatRows / (p.num_q_heads / p.num_kv_heads)) + p.num_seqs) * p.num_kv_heads;
   const bool eight = pin ? pin == 8 : wgs <= 288;
   const bool bf = p.q_dtype == MI355_BF16;
+  if (p.kv_dtype == MI355_FP8_E4M3) {
+    if (eight) return bf ? launch_lat_t<bf16_t, 4, false, 1>(p, stream) : launch_lat_t<f16_t, 4, false, 1>(p, stream);
+    return bf ? launch_lat_t<bf16_t, 2, false, 1>(p, stream) : launch_lat_t<f16_t, 2, false, 1>(p, stream);
+  }
+  if (p.kv_dtype == MI355_FP8_E5M2) {
+    if (eight) return bf ? launch_lat_t<bf16_t, 4, false, 2>(p, stream) : launch_lat_t<f16_t, 4, false, 2>(p, stream);
+    return bf ? launch_lat_t<bf16_t, 2, false, 2>(p, stream) : launch_lat_t<f16_t, 2, false, 2>(p, stream);
+  }
   if (p.write_new_kv) {
     if (eight) return bf ? launch_lat_t<bf16_t, 4, true>(p, stream) : launch_lat_t<f16_t, 4, true>(p, stream);
     return bf ? launch_lat_t<bf16_t, 2, true>(p, stream) : launch_lat_t<f16_t, 2, true>(p, stream);
