@@ -90,7 +90,11 @@ def test_prefill_fp8_kv_cache_on_the_mfma_path(dtype, kv_dtype, hq, hk, d):
     kv_lens = [9, 5, 129, 300, 257, 777]
     inp = orc.make_paged_inputs(25, query_lens, kv_lens, hq, hk, d, 16, dtype, kv_dtype=kv_dtype, kv_scale=0.5)
     _check(inp, dtype, expect="prefill_mfma", kv_dtype=kv_dtype, kv_scale=0.5)
-    _check(inp, dtype, force=2, expect="prefill_mfma_fp8", kv_dtype=kv_dtype, kv_scale=0.5)
+    # (round 4: short fp8 prompts at head size 128 run on the latency kernel's fp8 form; tests/test_gpu_variants.py runs this test
+    # again with the register-staged kernel pinned)
+    import os
+    staged = d != 128 or os.environ.get("MI355_PREFILL") == "v1"
+    _check(inp, dtype, force=2, expect="prefill_mfma_fp8" if staged else "prefill_mfma_lat_fp8", kv_dtype=kv_dtype, kv_scale=0.5)
 
 
 def test_prefill_fp8_kv_page32_and_features():
@@ -117,7 +121,8 @@ def test_prefill_fp8_kv_stale_nan_bytes_beyond_the_sequence_are_ignored():
         raw[~used] = 0x7F
     d = gpu_util.to_dev(inp)
     out, kernel = gpu_util.run_unified(d, inp["scale"], kv_scale=0.5, force=2)
-    assert kernel.startswith("prefill_mfma_fp8"), kernel
+    import os
+    assert kernel.startswith("prefill_mfma_fp8" if os.environ.get("MI355_PREFILL") == "v1" else "prefill_mfma_lat_fp8"), kernel
     assert not torch.isnan(out).any()
     atol, rtol = golden_io.tolerance(torch.bfloat16, torch.float8_e4m3fn)
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=atol, rtol=rtol)

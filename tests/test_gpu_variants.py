@@ -42,6 +42,9 @@ def test_prefill_narrow_workgroup_variant_at_full_size():
 def test_prefill_register_staged_kernel_for_plain_head_size_128():
     _run({"MI355_PREFILL": "v1"}, ["tests/test_gpu_prefill.py::test_prefill_mixed_batches", "tests/test_gpu_prefill.py::test_prefill_c2_full_size_properties"],
          keyword="(mixed and 128 and (8-2 or 32-1)) or c2_full")
+    # ... and its fp8-cache form at head size 128, which short fp8 prompts left for the latency kernel's fp8 form in round 4
+    _run({"MI355_PREFILL": "v1"}, ["tests/test_gpu_prefill.py::test_prefill_fp8_kv_cache_on_the_mfma_path",
+                                   "tests/test_gpu_prefill.py::test_prefill_fp8_kv_stale_nan_bytes_beyond_the_sequence_are_ignored"], keyword="128 or stale")
 
 
 def test_prefill_64_rows_per_wave_kernel_on_small_shapes():
