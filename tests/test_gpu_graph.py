@@ -287,3 +287,95 @@ def test_multi_token_decode_graph_replays_other_lengths_and_draft_counts():
         assert not torch.isnan(out[:T]).any(), q_lens
         torch.testing.assert_close(out[:T].float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
         assert torch.isnan(out[T:]).all()          # token rows past the batch stay untouched
+
+
+@pytest.mark.parametrize("query_lens,kv_lens,expect", [([500], [500], "prefill_mfma_lat"), ([300, 200, 260], [300, 712, 260], "prefill_mfma"),
+                                                        ([1, 130, 1, 64], [300, 130, 77, 320], "+decode")])
+def test_prefill_step_with_the_cache_write_inside_replays_with_new_data(query_lens, kv_lens, expect):
+    """Round 4 (library 0.6.0): a prefill step as ONE call - `prefill_attention_and_cache_write`: the step's keys attended over
+    from the linear tensors, stored by the launch - captured in a HIP graph and replayed with new queries / keys / values in
+    the same buffers (what `tools/e2e_proxy.py` times): output against the oracle over the cache as the replay left it, the
+    new rows' bytes in the cache. A one-prompt step (the latency kernel), a ragged step (the LDS-DMA kernel), a mixed step."""
+    import gpu_util
+    from mi355_attn import _lib
+    from mi355_attn.kernels.unified import prefill_attention_and_cache_write
+
+    dev = gpu_util.DEV
+    Hq, Hk, D, page = 32, 8, 128, 16
+    inp = orc.make_paged_inputs(43, query_lens, kv_lens, Hq, Hk, D, page, torch.bfloat16)
+    d = gpu_util.to_dev(inp)
+    T = sum(query_lens)
+    slots = []
+    for i, (ql, kl) in enumerate(zip(query_lens, kv_lens)):
+        for j in range(kl - ql, kl):
+            slots.append(int(inp["block_table"][i, j // page]) * page + j % page)
+    slot_mapping = torch.tensor(slots, dtype=torch.int64, device=dev)
+    k_new = torch.zeros(T, Hk, D, dtype=torch.bfloat16, device=dev)
+    v_new = torch.zeros_like(k_new)
+    out = torch.zeros_like(d["q"])
+
+    def step():
+        ok = prefill_attention_and_cache_write(d["q"], k_new, v_new, d["k_cache"], d["v_cache"], out, d["cu_seqlens_q"], max(query_lens), d["seqused_k"],
+                                               max(kv_lens), inp["scale"], d["block_table"], slot_mapping)
+        assert ok, "this step is served with the write inside the attention launches"
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.synchronize()
+    assert expect in _lib.last_kernel(), _lib.last_kernel()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        step()
+    for seed in (1, 2):
+        g = torch.Generator().manual_seed(seed)
+        q2 = (torch.rand(T, Hq, D, generator=g) * 2 - 1).to(torch.bfloat16)
+        kn = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+        vn = (torch.rand(T, Hk, D, generator=g) * 2 - 1).to(torch.bfloat16)
+        d["q"].copy_(q2.to(dev)); k_new.copy_(kn.to(dev)); v_new.copy_(vn.to(dev))
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        kc, vc = d["k_cache"].cpu(), d["v_cache"].cpu()
+        ref = orc.unified_attention_oracle(q2, kc, vc, inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"])
+        assert not torch.isnan(out).any()
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=2e-2, rtol=2e-2)
+        idx = torch.tensor(slots)
+        assert torch.equal(kc.view(-1, Hk, D)[idx].view(torch.int16), kn.view(torch.int16))
+        assert torch.equal(vc.view(-1, Hk, D)[idx].view(torch.int16), vn.view(torch.int16))
+
+
+@pytest.mark.parametrize("query_lens,kv_lens,expect", [([500], [500], "prefill_mfma_lat_fp8"), ([2100, 1], [2300, 900], "prefill_mfma_pw_fp8")])
+def test_prefill_over_an_fp8_cache_replays_with_new_queries(query_lens, kv_lens, expect):
+    """The fp8 forms of the prefill kernels (round 4) under capture: a short prompt and a long chunk + a decode row, replayed
+    with new queries over the same fp8 cache."""
+    import gpu_util
+    from mi355_attn import _lib
+
+    dev = gpu_util.DEV
+    ks = 0.31
+    inp = orc.make_paged_inputs(44, query_lens, kv_lens, 8, 2, 128, 16, torch.bfloat16, kv_dtype=torch.float8_e4m3fn, kv_scale=ks)
+    d = gpu_util.to_dev(inp)
+    out = torch.zeros_like(d["q"])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        gpu_util.run_unified(d, inp["scale"], kv_scale=ks, out=out)
+    assert _lib.last_kernel().startswith(expect), _lib.last_kernel()
+    graph = torch.cuda.CUDAGraph()
+    from mi355_attn.kernels import unified_attention
+    kst = torch.tensor([ks], dtype=torch.float32, device=dev)
+    with torch.cuda.graph(graph, stream=s):
+        unified_attention(q=d["q"], k=d["k_cache"], v=d["v_cache"], out=out, cu_seqlens_q=d["cu_seqlens_q"], max_seqlen_q=max(query_lens),
+                          seqused_k=d["seqused_k"], max_seqlen_k=max(kv_lens), avg_seqlen_q=1, avg_seqlen_k=1, softmax_scale=inp["scale"],
+                          causal=True, window_size=(-1, -1), block_table=d["block_table"], softcap=0, q_descale=None, k_descale=kst, v_descale=kst)
+    for seed in (1, 2):
+        g = torch.Generator().manual_seed(seed)
+        q2 = (torch.rand(*inp["q"].shape, generator=g) * 2 - 1).to(torch.bfloat16)
+        d["q"].copy_(q2.to(dev))
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = orc.unified_attention_oracle(q2, inp["k_cache"], inp["v_cache"], inp["cu_seqlens_q"], inp["seqused_k"], inp["block_table"], inp["scale"],
+                                           k_scale=ks, v_scale=ks)
+        assert not torch.isnan(out).any()
+        torch.testing.assert_close(out.float().cpu(), ref.float(), atol=3e-2, rtol=3e-2)
