@@ -16,7 +16,7 @@
 #if !defined(MI355_LAB) && (defined(MI355_PROFILE_WG) || defined(MI355_PROFILE_PHASES) || defined(MI355_PW_STAMP) || defined(MI355_PW_SEAM) || \
                             defined(PW_ABL_DMA) || defined(PW_FORCE_FALLBACK) || defined(PW_DMA_SPREAD) || defined(MI355_ABLATE_QK) || defined(MI355_ABLATE_DMA) || \
                             defined(MI355_ABLATE_SOFTMAX) || defined(MI355_ABLATE_PV) || defined(MI355_ABLATE_BARRIER) || defined(MI355_PACKED_ROWSUM) || \
-                            defined(MI355_DECODE_PF) || defined(MI355_DECODE_PLAIN_LOADS) || defined(PW_F8_ABL) || defined(PW_F8_PLACE))
+                            defined(MI355_DECODE_PF) || defined(MI355_DECODE_PLAIN_LOADS))
 #error "diagnostic / ablation macros are lab builds: add -DMI355_LAB"
 #endif
 #include <cstdlib>

@@ -936,31 +936,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
 
   // The same in twelve steps of one statement each, for the tile loop (one step per gap): per piece, two words widened, the
   // first chunk written, two words widened, the second chunk written. wq: the chunk under construction.
-  uint32_t wq0 = 0, wq1 = 0, wq2 = 0, wq3 = 0, wq4 = 0, wq5 = 0, wq6 = 0, wq7 = 0;
-  // ... and with two chunks under construction: a write never directly follows the statement that made its data (hipcc pads
-  // one s_nop there). Per piece: w0 w1 w2 W0 w3 | W1 rides behind the next piece's w0 (step 5 of the piece = that slot)
-  auto widen_step8 = [&](auto ISV, auto SLOT, auto KC, const wu32x4_t& p0, const wu32x4_t& p1) __attribute__((always_inline)) {
-    constexpr bool isv = decltype(ISV)::value != 0;
-    constexpr int slot = decltype(SLOT)::value, k = decltype(KC)::value;      // k = 0 .. 12
-    // order: 0:w(p0,0) 1:w(p0,1) 2:w(p0,2) 3:W(p0,c0) 4:w(p0,3) 5:w(p1,0)->(q0,q1) 6:W(p0,c1) 7:w(p1,1) 8:w(p1,2) 9:W(p1,c0) 10:w(p1,3) 11:(free) 12:W(p1,c1)
-    if constexpr (k == 0) pw_widen4<T, KVT>(p0[0], wq0, wq1);
-    else if constexpr (k == 1) pw_widen4<T, KVT>(p0[1], wq2, wq3);
-    else if constexpr (k == 2) pw_widen4<T, KVT>(p0[2], wq4, wq5);
-    else if constexpr (k == 4) pw_widen4<T, KVT>(p0[3], wq6, wq7);
-    else if constexpr (k == 5) pw_widen4<T, KVT>(p1[0], wq0, wq1);
-    else if constexpr (k == 7) pw_widen4<T, KVT>(p1[1], wq2, wq3);
-    else if constexpr (k == 8) pw_widen4<T, KVT>(p1[2], wq4, wq5);
-    else if constexpr (k == 10) pw_widen4<T, KVT>(p1[3], wq6, wq7);
-    else if constexpr (k == 3 || k == 9) {
-      constexpr int i = k == 9;
-      if constexpr (isv) pw_lds_write128<slot + 2048 * i>(vw8, wu32x4_t{wq0, wq1, wq2, wq3});
-      else pw_lds_write128<slot>(kw8[i][0], wu32x4_t{wq0, wq1, wq2, wq3});
-    } else if constexpr (k == 6 || k == 12) {
-      constexpr int i = k == 12;
-      if constexpr (isv) pw_lds_write128<slot + 2048 * i + 16>(vw8, wu32x4_t{wq4, wq5, wq6, wq7});
-      else pw_lds_write128<slot>(kw8[i][1], wu32x4_t{wq4, wq5, wq6, wq7});
-    }
-  };
+  uint32_t wq0 = 0, wq1 = 0, wq2 = 0, wq3 = 0;
   auto widen_step = [&](auto ISV, auto SLOT, auto KC, const wu32x4_t& p0, const wu32x4_t& p1) __attribute__((always_inline)) {
     constexpr bool isv = decltype(ISV)::value != 0;
     constexpr int slot = decltype(SLOT)::value, k = decltype(KC)::value, i = k / 6, r = k % 6;
@@ -1525,9 +1501,7 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
           // registers; gap 4: they are there, and the next pieces may overwrite them (gaps 4, 6, 8, 10); the widening - sixteen
           // steps of two conversions, a 16-byte write after every second - in the gaps from 5 on.
           if constexpr (g == 0) {
-#if !defined(PW_F8_ABL) || PW_F8_ABL != 1      // (ablation builds, -DMI355_LAB: wrong results, timing only)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             st8[0] = pw_lds_read128<0>(st_rd); st8[1] = pw_lds_read128<1024>(st_rd);
             st8[2] = pw_lds_read128<2048>(st_rd); st8[3] = pw_lds_read128<3072>(st_rd);
           }
@@ -1539,27 +1513,10 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr (g >= 4 && g <= 10 && (g & 1) == 0) dma_piece(ic<((g >= 4 && g <= 10) ? (g - 4) / 2 : 0)>{});
-#ifndef PW_F8_PLACE          // (a lab build may pick another placement, common.h)
-#define PW_F8_PLACE 2
-#endif
-          if constexpr (PW_F8_PLACE == 0) {           // (measurement: both groups widened in one go)
-            if constexpr (g == 12) widen_group(ic<0>{}, ic<KD>{}, st8[0], st8[1]);
-            if constexpr (g == 20) widen_group(ic<1>{}, ic<VD - kLdsV>{}, st8[2], st8[3]);
-          } else if constexpr (PW_F8_PLACE == 1) {    // K's twelve steps in gaps 5 .. 16, V's in segment 3
-            if constexpr (g >= 5 && g < 17) widen_step(ic<0>{}, ic<KD>{}, ic<(g >= 5 && g < 17) ? g - 5 : 0>{}, st8[0], st8[1]);
-          } else if constexpr (PW_F8_PLACE == 3) {    // both in this segment, thirteen slots each: gaps 5 .. 17, 18 .. 30
-            if constexpr (g >= 5 && g < 18) widen_step8(ic<0>{}, ic<KD>{}, ic<(g >= 5 && g < 18) ? g - 5 : 0>{}, st8[0], st8[1]);
-            if constexpr (g >= 18 && g < 31) widen_step8(ic<1>{}, ic<VD - kLdsV>{}, ic<(g >= 18 && g < 31) ? g - 18 : 0>{}, st8[2], st8[3]);
-          } else {                                     // both in this segment: gaps 5 .. 28
-#if defined(PW_F8_ABL) && PW_F8_ABL == 2
-            if constexpr (g < 0)
-#endif
-            if constexpr (g >= 5 && g < 17) widen_step(ic<0>{}, ic<KD>{}, ic<(g >= 5 && g < 17) ? g - 5 : 0>{}, st8[0], st8[1]);
-#if defined(PW_F8_ABL) && PW_F8_ABL == 2
-            if constexpr (g < 0)
-#endif
-            if constexpr (g >= 17 && g < 29) widen_step(ic<1>{}, ic<VD - kLdsV>{}, ic<(g >= 17 && g < 29) ? g - 17 : 0>{}, st8[2], st8[3]);
-          }
+          // (placement, profiles/r04/fp8_direct_prefill.log: both groups in one go costs 4 % more; V's steps in segment 3 keep sixteen
+          // more registers live and hipcc then parks values in accumulator registers - which belong to the asm statements)
+          if constexpr (g >= 5 && g < 17) widen_step(ic<0>{}, ic<KD>{}, ic<(g >= 5 && g < 17) ? g - 5 : 0>{}, st8[0], st8[1]);
+          if constexpr (g >= 17 && g < 29) widen_step(ic<1>{}, ic<VD - kLdsV>{}, ic<(g >= 17 && g < 29) ? g - 17 : 0>{}, st8[2], st8[3]);
         }
         // (the four waves issue their pieces at the same time and the CU's address unit takes 64 cycles per round of four:
         // eight pieces in eight consecutive gaps stall the issue - K(t+3) here, V(t+2) in segment 3, every other gap)
@@ -1580,7 +1537,6 @@ __global__ __launch_bounds__(256, 1) void prefill_pw_kernel(const PwArgs a) {
         constexpr int g = decltype(GC)::value;
         qk16(ic<1>{}, GC);
         if constexpr (!KV8 && g < 8 && (g & 1) == 0) dma_piece(ic<(g < 8 ? 4 + g / 2 : 4)>{});
-        if constexpr (KV8 && PW_F8_PLACE == 1 && g < 12) widen_step(ic<1>{}, ic<VD - kLdsV>{}, ic<(g < 12 ? g : 0)>{}, st8[2], st8[3]);
         if constexpr (g == 1) vread16(ic<15>{}, ic<VR>{});
         if constexpr (g >= 3 && g < 10 && (g & 1) == 1) kread16(ic<((g >= 3 && g < 10) ? (g - 3) / 2 : 0)>{}, ic<KR>{});
         if constexpr (steady && g >= 10) eop16(ic<1>{}, ic<(g >= 10 ? g - 10 : 0)>{});
