@@ -14,7 +14,8 @@ When the key ranges differ from the query ranges (`cu_seqlens_k is not cu_seqlen
 Served: the "thd" variable-length layout (`q [total_q, Hq, D]`, `k, v [total_k, Hk, D]`), causal masking with the
 reference's bottom-right alignment (query t of a sequence sees keys j <= t + seqlen_k - seqlen_q), non-causal attention
 (every query row sees its sequence's whole key range), grouped-query heads. Not served (raise `NotImplementedError`,
-nothing silently ignored): `bias`, softmax encodings, dropout.
+nothing silently ignored): softmax encodings, dropout; `bias` raises `AssertionError` exactly where the reference's own wrapper
+does (its argument check rejects a bias for the variable-length layout it always sets, :126-128, :1341-1342).
 """
 
 from __future__ import annotations
@@ -96,7 +97,11 @@ def prefill_flash_attention(
     if not q.is_cuda:
         raise RuntimeError("mi355_attn.prefill_flash_attention needs tensors on an MI355X (cuda/hip) device; there is no CPU path")
     if bias is not None:
-        raise NotImplementedError("prefill_flash_attention: bias is not supported")
+        # The reference's wrapper sets the variable-length parameters unconditionally (triton_flash_attention.py:1341-1342) and its
+        # argument check then asserts `bias is None` for that layout (:126-128, "TODO: Remove once bias is supported with
+        # varlen"): a bias reaches neither kernel there. Same behaviour here: an AssertionError before any launch.
+        raise AssertionError("prefill_flash_attention: bias is not supported with the variable-length layout (as in the reference, "
+                             "triton_flash_attention.py:126-128)")
     if not do_not_return_softmax_encodings:
         raise NotImplementedError("prefill_flash_attention: softmax encodings are not produced")
     if cu_seqlens_q is None or cu_seqlens_k is None:
