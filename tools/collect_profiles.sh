@@ -29,7 +29,12 @@ for s in "--seq 256" "--seq 512" "--seq 768" "--seq 1024" "--seq 1536" "--seq 51
   MI355_PREFILL=lat MI355_LAT_WAVES=8 python3 $REPO/tools/bench_prefill.py $s 2>&1 | grep -v amdgpu.ids | sed "s/^/lat8:    /"
   MI355_PREFILL=lat MI355_LAT_WAVES=4 python3 $REPO/tools/bench_prefill.py $s 2>&1 | grep -v amdgpu.ids | sed "s/^/lat4:    /"
   MI355_PREFILL=d4 python3 $REPO/tools/bench_prefill.py $s 2>&1 | grep -v amdgpu.ids | sed "s/^/dma4:    /"
-done > $OUT/short_prompts.log 2>&1; cut -c1-60,170- $OUT/short_prompts.log
+done > $OUT/short_prompts.log 2>&1
+for s in "--seq 256" "--seq 512" "--seq 1024" "--seq 1536" "--seq 640 --batch 4 --ctx 512" "--seq 512 --batch 8"; do      # ... and over an fp8 cache
+  python3 $REPO/tools/bench_prefill.py $s --kvdtype fp8 2>&1 | grep -v amdgpu.ids | sed "s/^/fp8 default: /"
+  MI355_PREFILL=v1 python3 $REPO/tools/bench_prefill.py $s --kvdtype fp8 2>&1 | grep -v amdgpu.ids | sed "s/^/fp8 staged:  /"
+done >> $OUT/short_prompts.log 2>&1
+cut -c1-60,170- $OUT/short_prompts.log
 rm -rf $OUT/stats_sp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sp -- python3 $REPO/tools/bench_prefill.py --seq 512 > /dev/null 2>&1
 f=$(find $OUT/stats_sp -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then (head -1 "$f"; grep "mi355::" "$f") > $OUT/bench_kernel_stats_short_1x512.csv; cut -c1-200 $OUT/bench_kernel_stats_short_1x512.csv; fi; rm -rf $OUT/stats_sp
 echo "== the 2D kernel's matrix: every prefill variant at 1 x 4096 / 16 x 4096, then kernel stats + MFMA busy of the variants on the 64-rows-per-wave kernel"
