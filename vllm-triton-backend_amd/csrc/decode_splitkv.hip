@@ -189,12 +189,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_splitkv_kernel(const Decode
   static_assert(PACK != 2 || D <= 128, "two column groups: O, Q and the K/V tiles in flight fit the register file up to head size 128");
   constexpr int NCG = PACK == 2 ? 2 : 1;            // column groups (16 matrix columns each) per wave
   constexpr bool FP8 = !__is_same(T, KVT);
-  // tiles in flight HBM -> VGPR per wave: an fp8 tile is half the bytes of a 16-bit one, so two of
-  // them are kept in flight to put the same number of bytes on the wire per CU
+  // tiles in flight HBM -> VGPR per wave. Rounds 2-3 kept TWO fp8 tiles in flight (half the bytes of a 16-bit tile each);
+  // re-measured in round 4 on the kernel as it is now (nt loads, hardware converts), ONE is 3 % faster wherever the fp8 kernel
+  // streams - C5 178.8 -> 173.3 us, 64 x 8192 177.5 -> 172.1, 256 x 2048 169.5 -> 164.6, batch 1 .. 4 unchanged
+  // (profiles/r04/decode_experiments.log); three: 224 us. -DMI355_DECODE_PF=n (lab build) sets another depth.
 #ifdef MI355_DECODE_PF
   constexpr int PF = MI355_DECODE_PF;
 #else
-  constexpr int PF = (FP8 && D <= 128) ? 2 : 1;
+  constexpr int PF = 1;
 #endif
   constexpr int KVB = FP8 ? 1 : 2;                  // bytes per cache element
   constexpr int PPR = D * KVB / 16;                 // 16-byte pieces per key row in HBM
